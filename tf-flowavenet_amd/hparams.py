@@ -1,0 +1,63 @@
+"""Hyper-parameter surface of the flow path.
+
+Mirrors the attribute names and default values of the reference's
+``hparams.py:6-50`` (22.05 kHz) and ``hparams8000.py:6-50`` (8 kHz) so that
+scripts written as ``from hparams import hparams`` keep working with
+``from tf_flowavenet_amd.hparams import hparams``.  The reference object is a
+``tf.contrib.training.HParams``; this is a plain attribute bag with the same
+``.values()`` / ``.parse()``-free read surface.  ``dtype`` is a string here
+("bfloat16" replaces the reference's tf.float16: bf16 needs no loss scale,
+utils.py:3-31 / train.py:64,77) and ``scale`` is kept only for surface parity.
+"""
+from __future__ import annotations
+
+import copy
+
+_COMMON = dict(
+    num_gpus=1, ps_device_type="GPU", dtype="bfloat16", scale=64.0,
+    num_mels=80, rescaling_max=0.999,
+    min_level_db=-100, ref_level_db=20, fmin=125,
+    eval_samples=1, split_random_state=123, shuffle_random_seed=42, test_size=10,
+    batch_size=8, gin_channels=-1, n_speakers=7,
+    causal=False, n_flow=6, n_layer=2, affine=True, causality=False,
+    tf_random_seed=75, temp=0.7,
+)
+
+_22K = dict(n_fft=1024, hop_size=256, sample_rate=22050, fmax=7600, max_time_steps=6400,
+            eval_max_time_steps=22050 * 4, n_block=8, upsample_scales=[16, 16])
+_8K = dict(n_fft=512, hop_size=96, sample_rate=8000, fmax=4000, max_time_steps=2320,
+           eval_max_time_steps=22050 * 4, n_block=5, upsample_scales=[8, 12])
+
+
+class HParams:
+    """Attribute bag; unknown attributes raise AttributeError like the reference object."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(copy.deepcopy(kw))
+
+    def values(self):
+        return dict(self.__dict__)
+
+    def replace(self, **kw):
+        new = HParams(**self.__dict__)
+        for k, v in kw.items():
+            if k not in new.__dict__:
+                raise AttributeError("unknown hparam %r" % k)
+            setattr(new, k, v)
+        return new
+
+    def __repr__(self):
+        return "HParams(%s)" % ", ".join("%s=%r" % kv for kv in sorted(self.__dict__.items()))
+
+
+def default_hparams() -> HParams:
+    """22.05 kHz configuration (reference hparams.py)."""
+    return HParams(**_COMMON, **_22K)
+
+
+def hparams8000() -> HParams:
+    """8 kHz configuration (reference hparams8000.py)."""
+    return HParams(**_COMMON, **_8K)
+
+
+hparams = default_hparams()
