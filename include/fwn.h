@@ -1,0 +1,148 @@
+/*
+ * fwn.h - C ABI of libfwn.so: the MI355X (gfx950) FloWaveNet flow forward / inverse path.
+ *
+ * The reference (ryhorv/tf-flowavenet) has no FFI seam: its hot path sits behind the Python
+ * class FloWaveNet (model.py:282-404) whose arithmetic is delegated to TensorFlow 1.12 ops.
+ * This header is the boundary a maintainer binds instead of those TF ops (ctypes stub in
+ * INTEGRATION.md).  Conventions:
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless marked "host";
+ *   - sizes are explicit, the HIP stream is the last argument (void*, may be NULL = default);
+ *   - no allocation, no synchronisation, no hidden global state: calls are asynchronous on
+ *     `stream` and safe to issue concurrently on distinct streams with distinct workspaces;
+ *   - return 0 on success, <0 on error; fwn_last_error() returns a thread-local message.
+ *
+ * Device data layouts (DESIGN.md "Data layout in HBM"):
+ *   flow state   : fp32 planes[2][B][T/2]; plane q holds samples 2s+q.  At block i a plane is the
+ *                  row-major matrix [M = B*T_i][Ch = 2^i], T_i = T / 2^(i+1).  The reference's
+ *                  squeeze / unsqueeze (model.py:226-239,260-273) and change_order (:166-174)
+ *                  are index bookkeeping on these planes: no data moves.
+ *   conditioning : bf16 cplanes[2][B][T][num_mels/2]; plane q holds mel bins [q*half, (q+1)*half).
+ *   hidden       : bf16 [M][256].
+ *   weights      : bf16, weight-norm folded, [N][K] with K contiguous, permuted to the plane
+ *                  orders above (tf-flowavenet_amd/packing.py builds the index tables).
+ */
+#ifndef FWN_H
+#define FWN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FWN_VERSION 100            /* 0.1.0 */
+#define FWN_MAX_LAYERS 8
+#define FWN_MAX_UPSAMPLE 4
+
+#define FWN_OK 0
+#define FWN_ERR_ARG (-1)           /* bad argument (null pointer, size, alignment, config) */
+#define FWN_ERR_HIP (-2)           /* a HIP launch or runtime call failed */
+#define FWN_ERR_WORKSPACE (-3)     /* workspace too small */
+
+int fwn_version(void);
+const char* fwn_last_error(void);
+
+/* ---- K10: weight-norm + bf16 packing (replaces convolutional.py:73-80 + utils.py:19-29) ----
+ * v is the TF-layout kernel flattened to [k_src][n_src] (k_src = kernel_size*C_in, n fastest).
+ * scale[n] = g[n] / sqrt(max(sum_k v[k][n]^2, 1e-12)). */
+int fwn_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, void* stream);
+/* out[n'*ld_dst + k'] = bf16(v[src_k[k']][src_n[n']] * scale[src_n[n']]) for n' < n_dst, k' < k_dst.
+ * src_k[k'] < 0 writes 0 (K padding); rows with src_n[n'] < 0 are left untouched; scale may be NULL. */
+int fwn_pack_bf16(const float* v, const float* scale, const int32_t* src_k, const int32_t* src_n,
+                  int n_src, int k_dst, int n_dst, int64_t ld_dst, void* out_bf16, void* stream);
+
+/* ---- K1: one upsampling stage (replaces Conv2DTranspose.call + leaky_relu, model.py:301-311,
+ * 398-404).  in [B][H][W] fp32, wk = weight-normed kernel [2s][3] fp32 (device), out rows H*s.
+ * Exactly one of out_f32 ([B][H*s][W]) / out_cplanes (bf16 [2][B][H*s][W/2]) may be NULL. */
+int fwn_upsample_stage(const float* in, int B, int H, int W, const float* wk, float bias, int s,
+                       float* out_f32, void* out_cplanes, void* stream);
+
+/* ---- K2: x[B][T] <-> planes[2][B][T/2] (squeeze / unsqueeze entry and exit) ---- */
+int fwn_split_planes(const float* x, int64_t B, int64_t T, float* planes, void* stream);
+int fwn_merge_planes(const float* planes, int64_t B, int64_t T, float* x, void* stream);
+
+/* ---- K3 (init only): ActNorm data-dependent init of one flow (model.py:30-83).
+ * an[2][4][Ch] <- per (a|b) plane: shift b, scale exp(3 logs), inverse scale, 3*logs. */
+int fwn_actnorm_ddi(const float* xa, const float* xb, int M, int Ch, float* an, void* stream);
+
+/* Static description of one flow (model.py:176-205 Flow = ActNorm + AffineCoupling(WaveNet)).
+ * All pointers are device pointers to packed weights; layouts in packing.py. */
+typedef struct fwn_flow_desc {
+    int32_t Ch;          /* channels per plane at this block = 2^i */
+    int32_t cin;         /* conditioning channels of c_a = (num_mels/2) * 2^(i+1) */
+    int32_t kcpad;       /* cin rounded up to 64 */
+    int32_t kfpad;       /* 3*Ch rounded up to 64 */
+    int32_t npt;         /* ZeroConv pair tiles = max(1, ceil(Ch/32)) */
+    int32_t L;           /* n_layer */
+    const void* Wfront;  const float* bfront;               /* [256][kfpad], [256]            */
+    const void* Wd[FWN_MAX_LAYERS];                         /* [512][768] gate-packed rows     */
+    const void* Wc[FWN_MAX_LAYERS];                         /* [512][kcpad]                    */
+    const float* bgate[FWN_MAX_LAYERS];                     /* [512] conv bias + cond bias     */
+    const void* Wres[FWN_MAX_LAYERS];                       /* [256][256] (layers 0..L-2)      */
+    const float* bres[FWN_MAX_LAYERS];
+    const void* Wskip;   const float* bskip;                /* [256][L*256], [256] (sum)       */
+    const void* Wfinal;  const float* bfinal;               /* [256][256], [256]               */
+    const void* Wzero;   const float* bzero; const float* ezero;   /* [npt*64][256], [npt*64]x2 */
+    float* an;                                              /* [2][4][Ch] ActNorm (DDI writes)  */
+} fwn_flow_desc;
+
+/* ---- stage entry points (K4..K8), exposed so each kernel can be parity-tested alone ---- */
+/* K4 front conv k=3 + ReLU over in_a (modules.py:144,164-165); apply_an: ActNorm on load. */
+int fwn_front(const fwn_flow_desc* d, const float* xa, void* h_out, int M, int Ti, int apply_an, void* stream);
+/* K5 gated dilated layer `layer` (modules.py:113-124).  ca==NULL uses P (precomputed c_a@Wc). */
+int fwn_gate(const fwn_flow_desc* d, int layer, const void* h, const void* ca, const float* P, void* o,
+             int M, int Ti, void* stream);
+/* K6 residual 1x1 (modules.py:126-128): h_out = (h_in + res_conv(o)) * sqrt(0.5). */
+int fwn_res(const fwn_flow_desc* d, int layer, const void* o, const void* h_in, void* h_out, int M,
+            void* stream);
+/* K5' conditioning projections of a parity group of flows in one launch: for j = flow0, flow0 +
+ * flow_step, ... (nflow flows) and every layer: P[j*L+l] = ca @ Wc[j][l].  Wc_base/w_stride address
+ * the block-contiguous weights, P_base/p_stride the outputs ([M][512] fp32 each). */
+int fwn_cond(const void* ca, const void* Wc_base, float* P_base, int64_t w_stride, int64_t p_stride,
+             int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, void* stream);
+/* K6'+K7+K8 tail: skip sum, final 1x1, ZeroConv1d, affine coupling, ActNorm, log-det partials
+ * (modules.py:175-180,51-56; model.py:86-102,124-141,146-161).  o = [L][M][256]. */
+int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
+             int inverse, void* stream);
+
+/* ---- one whole flow (replaces Flow.forward / Flow.reverse, model.py:185-202) ----
+ * xa / xb: the planes holding in_a / in_b for this flow's swap parity, ca the matching
+ * conditioning plane.  h0/h1: [M][256] bf16 scratch, o: [L][M][256] bf16 scratch,
+ * P: NULL or [L][M][512] fp32 precomputed conditioning projections for this flow,
+ * partial: NULL or [ceil(M/64)] log-det partial sums (forward).  ddi: run fwn_actnorm_ddi first. */
+int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
+                 void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
+                 void* stream);
+
+/* ---- K9: prior + log-det finalisation (model.py:342-347) ----
+ * out2[0] = mean(0.5(-log 2pi - z^2)) over n = B*T plane elements, out2[1] = sum(partial)/(B*T). */
+int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_partial, float* out2,
+                   void* stream);
+
+/* ---- whole model (replaces FloWaveNet.forward / .reverse, model.py:317-396) ---- */
+typedef struct fwn_model_desc {
+    int32_t n_block, n_flow, n_layer, num_mels;
+    int32_t n_up;
+    int32_t up_scale[FWN_MAX_UPSAMPLE];
+    const float* up_w[FWN_MAX_UPSAMPLE];      /* device [2s][3] weight-normed kernels */
+    float up_bias[FWN_MAX_UPSAMPLE];
+    const fwn_flow_desc* flows;               /* HOST array [n_block*n_flow] */
+    int32_t cond_mode;                        /* 0 auto, 1 always fused in gate, 2 always hoisted */
+} fwn_model_desc;
+
+size_t fwn_workspace_bytes(const fwn_model_desc* m, int64_t B, int64_t T);
+/* x [B][T] fp32, mel [B][T/hop][num_mels] fp32 -> out2 = (log_p, logdet) fp32 on device.
+ * z_planes (optional) receives the final flow state planes[2][B][T/2].  init != 0 performs the
+ * ActNorm data-dependent init flow by flow (train.py:221,229 with init=True). */
+int fwn_model_forward(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
+                      void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
+                      void* stream);
+/* z [B][T] fp32, mel -> x_out [B][T] fp32. */
+int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float* z, const float* mel,
+                      void* workspace, size_t workspace_bytes, float* x_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FWN_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of ``csrc/libfwn.so`` (C ABI declared in ``include/fwn.h``).
+
+There is deliberately no fallback: if the shared library is missing or a symbol
+is absent, importing/using the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+FWN_MAX_LAYERS = 8
+FWN_MAX_UPSAMPLE = 4
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfwn.so")
+
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+
+
+class FlowDesc(C.Structure):
+    """Mirror of ``fwn_flow_desc`` (include/fwn.h)."""
+    _fields_ = [
+        ("Ch", i32), ("cin", i32), ("kcpad", i32), ("kfpad", i32), ("npt", i32), ("L", i32),
+        ("Wfront", vp), ("bfront", vp),
+        ("Wd", vp * FWN_MAX_LAYERS), ("Wc", vp * FWN_MAX_LAYERS), ("bgate", vp * FWN_MAX_LAYERS),
+        ("Wres", vp * FWN_MAX_LAYERS), ("bres", vp * FWN_MAX_LAYERS),
+        ("Wskip", vp), ("bskip", vp), ("Wfinal", vp), ("bfinal", vp),
+        ("Wzero", vp), ("bzero", vp), ("ezero", vp),
+        ("an", vp),
+    ]
+
+
+class ModelDesc(C.Structure):
+    """Mirror of ``fwn_model_desc`` (include/fwn.h)."""
+    _fields_ = [
+        ("n_block", i32), ("n_flow", i32), ("n_layer", i32), ("num_mels", i32),
+        ("n_up", i32),
+        ("up_scale", i32 * FWN_MAX_UPSAMPLE),
+        ("up_w", vp * FWN_MAX_UPSAMPLE),
+        ("up_bias", C.c_float * FWN_MAX_UPSAMPLE),
+        ("flows", C.POINTER(FlowDesc)),
+        ("cond_mode", i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/fwn.h declares.
+SIGNATURES = {
+    "fwn_version": (C.c_int, []),
+    "fwn_last_error": (C.c_char_p, []),
+    "fwn_wn_scale": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "fwn_pack_bf16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, i64, vp, vp]),
+    "fwn_upsample_stage": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp]),
+    "fwn_split_planes": (C.c_int, [vp, i64, i64, vp, vp]),
+    "fwn_merge_planes": (C.c_int, [vp, i64, i64, vp, vp]),
+    "fwn_actnorm_ddi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "fwn_front": (C.c_int, [C.POINTER(FlowDesc), vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "fwn_gate": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "fwn_res": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, vp]),
+    "fwn_cond": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                           C.c_int, vp]),
+    "fwn_tail": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "fwn_flow_run": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,
+                               C.c_int, vp]),
+    "fwn_prior_logp": (C.c_int, [vp, i64, vp, C.c_int, vp, vp]),
+    "fwn_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), i64, i64]),
+    "fwn_model_forward": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp,
+                                    C.c_int, vp]),
+    "fwn_model_reverse": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp]),
+}
+
+_lib = None
+
+
+class FwnError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libfwn.so and bind every symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FwnError(
+            "HIP extension %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C tf-flowavenet_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().fwn_last_error()
+        raise FwnError("%s failed (%d): %s" % (what or "libfwn call", rc, msg.decode() if msg else "?"))

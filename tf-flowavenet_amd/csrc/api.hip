@@ -1,0 +1,411 @@
+// C-ABI of libfwn.so (declared in include/fwn.h): argument validation, workspace carving and
+// launch sequencing for the flow forward / inverse path.  No allocation, no synchronisation.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fwn.h"
+#include "fwn_internal.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FWN_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return FWN_OK;
+}
+#define REQUIRE(cond, ...) do { if (!(cond)) return fail(FWN_ERR_ARG, __VA_ARGS__); } while (0)
+#define ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+extern "C" {
+
+int fwn_version(void) { return FWN_VERSION; }
+const char* fwn_last_error(void) { return g_err; }
+
+int fwn_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, void* stream) {
+    REQUIRE(v && g && scale, "fwn_wn_scale: null pointer");
+    REQUIRE(k_src > 0 && n_src > 0, "fwn_wn_scale: bad shape %d x %d", k_src, n_src);
+    fwn_launch_wn_scale(v, g, k_src, n_src, scale, (hipStream_t)stream);
+    return check_launch("fwn_wn_scale");
+}
+
+int fwn_pack_bf16(const float* v, const float* scale, const int32_t* src_k, const int32_t* src_n,
+                  int n_src, int k_dst, int n_dst, int64_t ld_dst, void* out_bf16, void* stream) {
+    REQUIRE(v && src_k && src_n && out_bf16, "fwn_pack_bf16: null pointer");
+    REQUIRE(n_src > 0 && k_dst > 0 && n_dst > 0 && ld_dst >= k_dst, "fwn_pack_bf16: bad shape");
+    fwn_launch_pack(v, scale, src_k, src_n, n_src, k_dst, n_dst, (long)ld_dst, out_bf16, (hipStream_t)stream);
+    return check_launch("fwn_pack_bf16");
+}
+
+int fwn_upsample_stage(const float* in, int B, int H, int W, const float* wk, float bias, int s,
+                       float* out_f32, void* out_cplanes, void* stream) {
+    REQUIRE(in && wk, "fwn_upsample_stage: null pointer");
+    REQUIRE((out_f32 != nullptr) != (out_cplanes != nullptr), "fwn_upsample_stage: exactly one output");
+    REQUIRE(B > 0 && H > 0 && W > 0 && s > 0 && (s % 2) == 0, "fwn_upsample_stage: bad shape (s must be even)");
+    REQUIRE(!out_cplanes || (W % 2) == 0, "fwn_upsample_stage: W must be even for planes");
+    fwn_launch_upsample(in, B, H, W, wk, bias, s, out_f32, out_cplanes, (hipStream_t)stream);
+    return check_launch("fwn_upsample_stage");
+}
+
+int fwn_split_planes(const float* x, int64_t B, int64_t T, float* planes, void* stream) {
+    REQUIRE(x && planes && B > 0 && T > 0 && (T % 2) == 0, "fwn_split_planes: bad argument");
+    fwn_launch_split(x, B, T, planes, (hipStream_t)stream);
+    return check_launch("fwn_split_planes");
+}
+int fwn_merge_planes(const float* planes, int64_t B, int64_t T, float* x, void* stream) {
+    REQUIRE(x && planes && B > 0 && T > 0 && (T % 2) == 0, "fwn_merge_planes: bad argument");
+    fwn_launch_merge(planes, B, T, x, (hipStream_t)stream);
+    return check_launch("fwn_merge_planes");
+}
+
+int fwn_actnorm_ddi(const float* xa, const float* xb, int M, int Ch, float* an, void* stream) {
+    REQUIRE(xa && xb && an && M > 0 && Ch > 0, "fwn_actnorm_ddi: bad argument");
+    fwn_launch_ddi(xa, xb, M, Ch, an, (hipStream_t)stream);
+    return check_launch("fwn_actnorm_ddi");
+}
+
+static int check_desc(const fwn_flow_desc* d) {
+    REQUIRE(d, "flow desc is null");
+    REQUIRE(d->Ch >= 1 && (d->Ch & (d->Ch - 1)) == 0, "flow desc: Ch=%d must be a power of two", d->Ch);
+    REQUIRE(d->L >= 1 && d->L <= FWN_MAX_LAYERS, "flow desc: L=%d out of range", d->L);
+    REQUIRE(d->cin > 0 && d->cin % 8 == 0, "flow desc: cin=%d must be a multiple of 8", d->cin);
+    REQUIRE(d->kcpad % 64 == 0 && d->kcpad >= d->cin, "flow desc: kcpad=%d", d->kcpad);
+    REQUIRE(d->kfpad % 64 == 0 && d->kfpad >= 3 * d->Ch, "flow desc: kfpad=%d", d->kfpad);
+    REQUIRE(d->npt >= 1 && d->npt * 32 >= d->Ch, "flow desc: npt=%d", d->npt);
+    REQUIRE(d->Wfront && d->bfront && d->Wskip && d->bskip && d->Wfinal && d->bfinal && d->Wzero &&
+            d->bzero && d->ezero && d->an, "flow desc: null weight pointer");
+    for (int l = 0; l < d->L; ++l) {
+        REQUIRE(d->Wd[l] && d->Wc[l] && d->bgate[l], "flow desc: null gate weights (layer %d)", l);
+        REQUIRE(l == d->L - 1 || (d->Wres[l] && d->bres[l]), "flow desc: null res weights (layer %d)", l);
+        REQUIRE(ALIGNED16(d->Wd[l]) && ALIGNED16(d->Wc[l]), "flow desc: weights must be 16-byte aligned");
+    }
+    REQUIRE(ALIGNED16(d->Wfront) && ALIGNED16(d->Wskip) && ALIGNED16(d->Wfinal) && ALIGNED16(d->Wzero),
+            "flow desc: weights must be 16-byte aligned");
+    return FWN_OK;
+}
+
+int fwn_front(const fwn_flow_desc* d, const float* xa, void* h_out, int M, int Ti, int apply_an, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(xa && h_out && M > 0 && Ti > 0 && M % Ti == 0, "fwn_front: bad argument");
+    REQUIRE(ALIGNED16(xa) && ALIGNED16(h_out), "fwn_front: buffers must be 16-byte aligned");
+    fwn_launch_front(xa, d->an, d->Wfront, d->bfront, h_out, M, Ti, d->Ch, d->kfpad, apply_an,
+                     (hipStream_t)stream);
+    return check_launch("fwn_front");
+}
+
+static int dilation_of(int layer) {  // kernel_size ** n, modules.py:152
+    int dil = 1;
+    for (int i = 0; i < layer; ++i) dil *= 3;
+    return dil;
+}
+
+int fwn_gate(const fwn_flow_desc* d, int layer, const void* h, const void* ca, const float* P, void* o,
+             int M, int Ti, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(layer >= 0 && layer < d->L, "fwn_gate: layer %d out of range", layer);
+    REQUIRE(h && o && M > 0 && Ti > 0 && M % Ti == 0, "fwn_gate: bad argument");
+    REQUIRE((ca != nullptr) != (P != nullptr), "fwn_gate: exactly one of ca / P");
+    REQUIRE(ALIGNED16(h) && ALIGNED16(o) && ALIGNED16(ca), "fwn_gate: buffers must be 16-byte aligned");
+    fwn_launch_gate(h, ca, P, d->Wd[layer], d->Wc[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
+                    d->cin, d->kcpad, (hipStream_t)stream);
+    return check_launch("fwn_gate");
+}
+
+int fwn_res(const fwn_flow_desc* d, int layer, const void* o, const void* h_in, void* h_out, int M,
+            void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(layer >= 0 && layer < d->L - 1, "fwn_res: layer %d has no live res_conv", layer);
+    REQUIRE(o && h_in && h_out && M > 0, "fwn_res: bad argument");
+    fwn_launch_res(o, h_in, d->Wres[layer], d->bres[layer], h_out, M, (hipStream_t)stream);
+    return check_launch("fwn_res");
+}
+
+int fwn_cond(const void* ca, const void* Wc_base, float* P_base, int64_t w_stride, int64_t p_stride,
+             int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, void* stream) {
+    REQUIRE(ca && Wc_base && P_base, "fwn_cond: null pointer");
+    REQUIRE(nflow > 0 && L > 0 && M > 0 && cin > 0 && cin % 8 == 0 && kcpad % 64 == 0 && kcpad >= cin,
+            "fwn_cond: bad shape");
+    REQUIRE(flow0 >= 0 && flow_step > 0, "fwn_cond: bad flow group");
+    fwn_launch_cond(ca, Wc_base, P_base, (long)w_stride, (long)p_stride, flow0, flow_step, nflow, L, M, cin,
+                    kcpad, (hipStream_t)stream);
+    return check_launch("fwn_cond");
+}
+
+int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
+             int inverse, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(o && xa && xb && M > 0, "fwn_tail: bad argument");
+    fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
+                    d->ezero, d->an, xa, xb, partial, M, d->Ch, d->npt, inverse, (hipStream_t)stream);
+    return check_launch("fwn_tail");
+}
+
+int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
+                 void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
+                 void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(B > 0 && T > 0 && T % (2 * (int64_t)d->Ch) == 0, "fwn_flow_run: T=%lld not divisible by 2*Ch=%d",
+            (long long)T, 2 * d->Ch);
+    REQUIRE(B * T < ((int64_t)1 << 31), "fwn_flow_run: B*T too large");
+    REQUIRE(xa && xb && h0 && h1 && o, "fwn_flow_run: null buffer");
+    REQUIRE((ca != nullptr) != (P != nullptr), "fwn_flow_run: exactly one of ca / P");
+    REQUIRE(!(ddi && inverse), "fwn_flow_run: data-dependent init runs in the forward direction only");
+    hipStream_t st = (hipStream_t)stream;
+    const int Ti = (int)(T / (2 * d->Ch));
+    const int M = (int)(B * Ti);
+    if (ddi) fwn_launch_ddi(xa, xb, M, d->Ch, d->an, st);
+    fwn_launch_front(xa, d->an, d->Wfront, d->bfront, h0, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1, st);
+    void* hc = h0;
+    void* hn = h1;
+    for (int l = 0; l < d->L; ++l) {
+        void* ol = (char*)o + (size_t)l * M * 256 * 2;
+        fwn_launch_gate(hc, ca, P ? P + (size_t)l * M * 512 : nullptr, d->Wd[l], d->Wc[l], d->bgate[l], ol, M,
+                        Ti, dilation_of(l), d->cin, d->kcpad, st);
+        if (l + 1 < d->L) {
+            fwn_launch_res(ol, hc, d->Wres[l], d->bres[l], hn, M, st);
+            void* t = hc; hc = hn; hn = t;
+        }
+    }
+    fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
+                    d->ezero, d->an, xa, xb, inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, st);
+    return check_launch("fwn_flow_run");
+}
+
+int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_partial, float* out2,
+                   void* stream) {
+    REQUIRE(planes && out2 && n > 0 && n_partial >= 0 && (partial || n_partial == 0), "fwn_prior_logp: bad argument");
+    fwn_launch_prior(planes, (long)n, partial, n_partial, 1.0 / (double)n, out2, (hipStream_t)stream);
+    return check_launch("fwn_prior_logp");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-model sequencing
+// ---------------------------------------------------------------------------------------------
+struct Carve {
+    size_t cplanes, up0, up1, planes, h0, h1, o, P, partial, total;
+    int n_partial;
+};
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static bool hoist_cond(const fwn_model_desc* m, int64_t M) {
+    if (m->cond_mode == 1) return false;
+    if (m->cond_mode == 2) return true;
+    return M < 4096;  // small-M blocks: batch the weight-streaming cond GEMMs of all flows
+}
+
+static int hop_of(const fwn_model_desc* m) {
+    int hop = 1;
+    for (int i = 0; i < m->n_up; ++i) hop *= m->up_scale[i];
+    return hop;
+}
+
+static int check_model(const fwn_model_desc* m, int64_t B, int64_t T) {
+    REQUIRE(m && m->flows, "model desc is null");
+    REQUIRE(m->n_block >= 1 && m->n_block <= 16 && m->n_flow >= 1 && m->n_layer >= 1 &&
+            m->n_layer <= FWN_MAX_LAYERS, "model desc: bad n_block/n_flow/n_layer");
+    REQUIRE(m->n_up >= 1 && m->n_up <= FWN_MAX_UPSAMPLE, "model desc: n_up=%d", m->n_up);
+    REQUIRE(m->num_mels > 0 && m->num_mels % 2 == 0, "model desc: num_mels must be even");
+    REQUIRE(B > 0 && T > 0, "B and T must be positive");
+    REQUIRE(T % hop_of(m) == 0, "T=%lld must be a multiple of hop_size=%d (model.py:231)", (long long)T, hop_of(m));
+    REQUIRE(T % ((int64_t)1 << m->n_block) == 0, "T=%lld must be a multiple of 2^n_block (model.py:226)",
+            (long long)T);
+    REQUIRE(B * T < ((int64_t)1 << 31), "B*T too large");
+    for (int i = 0; i < m->n_block; ++i)
+        for (int j = 0; j < m->n_flow; ++j) {
+            const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
+            int rc = check_desc(d);
+            if (rc) return rc;
+            REQUIRE(d->Ch == (1 << i) && d->L == m->n_layer && d->cin == (m->num_mels / 2) * (2 << i),
+                    "model desc: flow (%d,%d) geometry mismatch", i, j);
+        }
+    for (int i = 0; i < m->n_up; ++i) REQUIRE(m->up_w[i], "model desc: null upsample kernel");
+    return FWN_OK;
+}
+
+static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
+    Carve c;
+    size_t off = 0;
+    const size_t half = m->num_mels / 2;
+    c.cplanes = off; off = align_up(off + 2 * (size_t)B * T * half * 2);
+    const size_t up_elems = (m->n_up > 1) ? (size_t)B * (T / m->up_scale[m->n_up - 1]) * m->num_mels : 0;
+    c.up0 = off; off = align_up(off + up_elems * 4);
+    c.up1 = off; off = align_up(off + (m->n_up > 2 ? up_elems * 4 : 0));
+    c.planes = off; off = align_up(off + (size_t)B * T * 4);
+    const size_t Mmax = (size_t)B * T / 2;
+    c.h0 = off; off = align_up(off + Mmax * 256 * 2);
+    c.h1 = off; off = align_up(off + Mmax * 256 * 2);
+    c.o = off; off = align_up(off + (size_t)m->n_layer * Mmax * 256 * 2);
+    size_t pbytes = 0;
+    int npart = 0;
+    for (int i = 0; i < m->n_block; ++i) {
+        const int64_t M = B * T / ((int64_t)2 << i);
+        if (hoist_cond(m, M)) {
+            const size_t need = (size_t)m->n_flow * m->n_layer * M * 512 * 4;
+            if (need > pbytes) pbytes = need;
+        }
+        npart += m->n_flow * (int)((M + 63) / 64);
+    }
+    c.P = off; off = align_up(off + pbytes);
+    c.partial = off; off = align_up(off + (size_t)npart * 4);
+    c.n_partial = npart;
+    c.total = off;
+    return c;
+}
+
+size_t fwn_workspace_bytes(const fwn_model_desc* m, int64_t B, int64_t T) {
+    if (check_model(m, B, T) != FWN_OK) return 0;
+    return carve(m, B, T).total;
+}
+
+static void run_upsample(const fwn_model_desc* m, int64_t B, int64_t T, const float* mel, char* ws,
+                         const Carve& c, hipStream_t st) {
+    int H = (int)(T / hop_of(m));
+    const float* in = mel;
+    for (int i = 0; i < m->n_up; ++i) {
+        const bool last = (i == m->n_up - 1);
+        float* outf = last ? nullptr : (float*)(ws + ((i & 1) ? c.up1 : c.up0));
+        fwn_launch_upsample(in, (int)B, H, m->num_mels, m->up_w[i], m->up_bias[i], m->up_scale[i], outf,
+                            last ? (void*)(ws + c.cplanes) : nullptr, st);
+        H *= m->up_scale[i];
+        in = outf;
+    }
+}
+
+static void run_cond_groups(const fwn_model_desc* m, int blk, int64_t M, const int* parity_of_flow,
+                            char* ws, const Carve& c, int64_t B, int64_t T, hipStream_t st) {
+    const fwn_flow_desc* f0 = &m->flows[blk * m->n_flow];
+    const size_t half = m->num_mels / 2;
+    const size_t plane_elems = (size_t)B * T * half;
+    for (int g = 0; g < 2 && g < m->n_flow; ++g) {
+        const int nfl = (m->n_flow - g + 1) / 2;
+        const char* ca = ws + c.cplanes + (size_t)parity_of_flow[g] * plane_elems * 2;
+        fwn_launch_cond(ca, f0->Wc[0], (float*)(ws + c.P), (long)512 * f0->kcpad, (long)M * 512, g, 2, nfl,
+                        m->n_layer, (int)M, f0->cin, f0->kcpad, st);
+    }
+}
+
+static int check_block_contiguity(const fwn_model_desc* m, int blk) {
+    const fwn_flow_desc* f0 = &m->flows[blk * m->n_flow];
+    const size_t stride = (size_t)512 * f0->kcpad * 2;
+    for (int j = 0; j < m->n_flow; ++j)
+        for (int l = 0; l < m->n_layer; ++l)
+            REQUIRE((const char*)m->flows[blk * m->n_flow + j].Wc[l] ==
+                        (const char*)f0->Wc[0] + (size_t)(j * m->n_layer + l) * stride,
+                    "block %d: Wc must be contiguous in (flow, layer) order for hoisted conditioning", blk);
+    return FWN_OK;
+}
+
+int fwn_model_forward(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
+                      void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
+                      void* stream) {
+    int rc = check_model(m, B, T);
+    if (rc) return rc;
+    REQUIRE(x && mel && workspace && out2, "fwn_model_forward: null pointer");
+    REQUIRE((((uintptr_t)workspace) & 255) == 0, "workspace must be 256-byte aligned");
+    const Carve c = carve(m, B, T);
+    if (workspace_bytes < c.total)
+        return fail(FWN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, c.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const size_t half = m->num_mels / 2;
+    const size_t cplane_bytes = (size_t)B * T * half * 2;
+    const size_t plane_elems = (size_t)B * T / 2;
+    float* planes = (float*)(ws + c.planes);
+
+    run_upsample(m, B, T, mel, ws, c, st);
+    fwn_launch_split(x, B, T, planes, st);
+    int p = 0;
+    float* partial = (float*)(ws + c.partial);
+    int poff = 0;
+    for (int i = 0; i < m->n_block; ++i) {
+        const int64_t M = B * T / ((int64_t)2 << i);
+        const bool hoist = hoist_cond(m, M);
+        if (hoist) {
+            rc = check_block_contiguity(m, i);
+            if (rc) return rc;
+            const int par[2] = {p, p ^ 1};
+            run_cond_groups(m, i, M, par, ws, c, B, T, st);
+        }
+        for (int j = 0; j < m->n_flow; ++j) {
+            const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
+            const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
+            const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
+            rc = fwn_flow_run(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
+                              ws + c.h0, ws + c.h1, ws + c.o, P, partial + poff, 0, init, stream);
+            if (rc) return rc;
+            poff += (int)((M + 63) / 64);
+            p ^= 1;   // change_order (model.py:190)
+        }
+    }
+    fwn_launch_prior(planes, (long)(B * T), partial, poff, 1.0 / (double)(B * T), out2, st);
+    if (z_planes) {
+        hipError_t e = hipMemcpyAsync(z_planes, planes, (size_t)B * T * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return fail(FWN_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
+    }
+    return check_launch("fwn_model_forward");
+}
+
+int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float* z, const float* mel,
+                      void* workspace, size_t workspace_bytes, float* x_out, void* stream) {
+    int rc = check_model(m, B, T);
+    if (rc) return rc;
+    REQUIRE(z && mel && workspace && x_out, "fwn_model_reverse: null pointer");
+    REQUIRE((((uintptr_t)workspace) & 255) == 0, "workspace must be 256-byte aligned");
+    REQUIRE(((m->n_block * m->n_flow) & 1) == 0,
+            "reverse with odd n_block*n_flow ends in swapped channel order (model.py:199,254); unsupported");
+    const Carve c = carve(m, B, T);
+    if (workspace_bytes < c.total)
+        return fail(FWN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, c.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const size_t half = m->num_mels / 2;
+    const size_t cplane_bytes = (size_t)B * T * half * 2;
+    const size_t plane_elems = (size_t)B * T / 2;
+    float* planes = (float*)(ws + c.planes);
+
+    run_upsample(m, B, T, mel, ws, c, st);
+    fwn_launch_split(z, B, T, planes, st);   // the n_block pre-squeezes of model.py:374-392 are index math
+    int p = 0;
+    for (int i = m->n_block - 1; i >= 0; --i) {
+        const int64_t M = B * T / ((int64_t)2 << i);
+        const bool hoist = hoist_cond(m, M);
+        if (hoist) {
+            rc = check_block_contiguity(m, i);
+            if (rc) return rc;
+            // parity seen by flow j: p is flipped before each flow, visiting j = n_flow-1 .. 0
+            int par[2] = {0, 0};
+            int pc = p;
+            for (int j = m->n_flow - 1; j >= 0; --j) {
+                pc ^= 1;
+                if (j < 2) par[j] = pc;
+            }
+            run_cond_groups(m, i, M, par, ws, c, B, T, st);
+        }
+        for (int j = m->n_flow - 1; j >= 0; --j) {
+            p ^= 1;   // change_order first (model.py:199)
+            const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
+            const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
+            const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
+            rc = fwn_flow_run(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
+                              ws + c.h0, ws + c.h1, ws + c.o, P, nullptr, 1, 0, stream);
+            if (rc) return rc;
+        }
+    }
+    fwn_launch_merge(planes, B, T, x_out, st);
+    return check_launch("fwn_model_reverse");
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+// HBM-bound helper kernels around the flow chain (gfx950):
+//   weight-norm + bf16 packing (convolutional.py:73-80), mel upsampling by two transposed
+//   convs (model.py:398-404), even/odd plane split/merge (the squeeze of model.py:226-239 is
+//   pure index math on these planes), ActNorm data-dependent init (model.py:30-83) and the
+//   prior / log-det finalisation (model.py:342-343).
+#include "common.h"
+#include "fwn_internal.h"
+
+// ---- weight-norm scale: scale[n] = g[n] / sqrt(max(sum_k V[k][n]^2, 1e-12)) ----------------
+__global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                       int k_src, int n_src, float* __restrict__ scale) {
+    __shared__ double red[4][64];
+    const int nl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + nl;
+    double s = 0.0;
+    if (n < n_src)
+        for (int k = kg; k < k_src; k += 4) {
+            const double x = v[(size_t)k * n_src + n];
+            s += x * x;
+        }
+    red[kg][nl] = s;
+    __syncthreads();
+    if (kg == 0 && n < n_src) {
+        const double ss = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
+        scale[n] = (float)((double)g[n] / sqrt(fmax(ss, 1e-12)));
+    }
+}
+
+// ---- gather + scale + cast: out[n'][k'] = bf16(V[src_k[k']][src_n[n']] * scale[src_n[n']]) --
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                   const int* __restrict__ src_k, const int* __restrict__ src_n,
+                                                   int n_src, int k_dst, long ld_dst, long total,
+                                                   bf16* __restrict__ out) {
+    // rows with src_n < 0 are skipped (left as the caller initialised them); columns with
+    // src_k < 0 are written as zero (K padding).
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int kd = (int)(i % k_dst), nd = (int)(i / k_dst);
+        const int sk = src_k[kd], sn = src_n[nd];
+        if (sn < 0) continue;
+        float val = 0.0f;
+        if (sk >= 0) {
+            val = v[(size_t)sk * n_src + sn];
+            if (scale) val *= scale[sn];
+        }
+        out[(size_t)nd * ld_dst + kd] = (bf16)val;
+    }
+}
+
+// ---- one Conv2DTranspose(filters=1, kernel (2s,3), strides (s,1), 'same') + LeakyReLU(0.4) --
+// Gather form of SURVEY Appendix A: y[tau, w] = bias + sum over (i,k) with i*s + k - s/2 = tau
+// and kw of x[i, w - kw + 1] * wk[k][kw].
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, int B, int H, int W,
+                                                       const float* __restrict__ wk, float bias, int s,
+                                                       float* __restrict__ out_f32, bf16* __restrict__ out_planes) {
+    const long total = (long)B * H * s * W;
+    const int half = W >> 1;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int w = (int)(idx % W);
+        const long rt = idx / W;
+        const int tau = (int)(rt % ((long)H * s));
+        const int b = (int)(rt / ((long)H * s));
+        const int i1 = (tau + s / 2) / s;
+        const int k1 = tau + s / 2 - i1 * s;
+        float acc = bias;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = i1 - j, k = k1 + j * s;
+            if (i >= 0 && i < H) {
+                const float* xr = in + ((size_t)b * H + i) * W;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ws = w - kw + 1;
+                    if (ws >= 0 && ws < W) acc += xr[ws] * wk[k * 3 + kw];
+                }
+            }
+        }
+        acc = fmaxf(acc, 0.4f * acc);
+        if (out_f32) out_f32[idx] = acc;
+        if (out_planes) {
+            // planes[q][b][tau][w - q*half], q = mel half (conditioning half of change_order)
+            const int q = w >= half;
+            out_planes[(((size_t)q * B + b) * ((size_t)H * s) + tau) * half + (w - q * half)] = (bf16)acc;
+        }
+    }
+}
+
+// ---- x[B][T] <-> planes[2][B][T/2] (even / odd samples) ------------------------------------
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, long B, long T,
+                                                    float* __restrict__ planes) {
+    const long n = B * T, hT = T >> 1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long b = i / T, t = i % T;
+        planes[((t & 1) * B + b) * hT + (t >> 1)] = x[i];
+    }
+}
+__global__ __launch_bounds__(256) void merge_kernel(const float* __restrict__ planes, long B, long T,
+                                                    float* __restrict__ x) {
+    const long n = B * T, hT = T >> 1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long b = i / T, t = i % T;
+        x[i] = planes[((t & 1) * B + b) * hT + (t >> 1)];
+    }
+}
+
+// ---- ActNorm data-dependent init for one flow -----------------------------------------------
+// One workgroup per (plane role, channel).  an[role][0..3][tau] = shift b, scale exp(3 logs),
+// inverse scale, 3*logs.  model.py:55-56 (b = -mean), :65-71 (logs from mean((x+b)^2)).
+__device__ double block_sum(double v, double* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(256) void ddi_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                  int M, int Ch, float* __restrict__ an) {
+    __shared__ double red[256];
+    const int role = blockIdx.x / Ch, tau = blockIdx.x % Ch;
+    const float* src = role ? xb : xa;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < M; r += 256) s += src[(size_t)r * Ch + tau];
+    const double mean = block_sum(s, red) / M;
+    const float bshift = (float)(-mean);
+    double s2 = 0.0;
+    for (int r = threadIdx.x; r < M; r += 256) {
+        const double d = (double)(src[(size_t)r * Ch + tau] + bshift);
+        s2 += d * d;
+    }
+    const double var = block_sum(s2, red) / M;
+    if (threadIdx.x == 0) {
+        const double den = sqrt(var) + 1e-7;
+        float* o = an + (size_t)role * 4 * Ch;
+        o[tau] = bshift;
+        o[Ch + tau] = (float)(1.0 / den);
+        o[2 * Ch + tau] = (float)den;
+        o[3 * Ch + tau] = (float)(-log(den));
+    }
+}
+
+// ---- prior + log-det finalisation: out2 = (log_p, logdet), model.py:342-347 -----------------
+__global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ z, long n,
+                                                     const float* __restrict__ partial, int n_partial,
+                                                     double inv_bt, float* __restrict__ out2) {
+    __shared__ double r1[1024], r2[1024];
+    const int tid = threadIdx.x;
+    double s = 0.0, p = 0.0;
+    for (long i = tid; i < n; i += 1024) {
+        const double v = z[i];
+        s += v * v;
+    }
+    for (int i = tid; i < n_partial; i += 1024) p += partial[i];
+    r1[tid] = s;
+    r2[tid] = p;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (tid < st) { r1[tid] += r1[tid + st]; r2[tid] += r2[tid + st]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out2[0] = (float)(0.5 * (-1.8378770664093453 - r1[0] / (double)n));
+        out2[1] = (float)(r2[0] * inv_bt);
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------
+static inline int grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st) {
+    hipLaunchKernelGGL(wn_scale_kernel, dim3((n_src + 63) / 64), dim3(256), 0, st, v, g, k_src, n_src, scale);
+}
+void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,
+                     int k_dst, int n_dst, long ld_dst, void* out, hipStream_t st) {
+    const long total = (long)k_dst * n_dst;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, st, v, scale, src_k, src_n, n_src,
+                       k_dst, ld_dst, total, (bf16*)out);
+}
+void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, float bias, int s,
+                         float* out_f32, void* out_planes, hipStream_t st) {
+    const long total = (long)B * H * s * W;
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, B, H, W, wk, bias, s,
+                       out_f32, (bf16*)out_planes);
+}
+void fwn_launch_split(const float* x, long B, long T, float* planes, hipStream_t st) {
+    hipLaunchKernelGGL(split_kernel, dim3(grid_for(B * T)), dim3(256), 0, st, x, B, T, planes);
+}
+void fwn_launch_merge(const float* planes, long B, long T, float* x, hipStream_t st) {
+    hipLaunchKernelGGL(merge_kernel, dim3(grid_for(B * T)), dim3(256), 0, st, planes, B, T, x);
+}
+void fwn_launch_ddi(const float* xa, const float* xb, int M, int Ch, float* an, hipStream_t st) {
+    hipLaunchKernelGGL(ddi_kernel, dim3(2 * Ch), dim3(256), 0, st, xa, xb, M, Ch, an);
+}
+void fwn_launch_prior(const float* planes, long n, const float* partial, int n_partial, double inv_bt,
+                      float* out2, hipStream_t st) {
+    hipLaunchKernelGGL(prior_kernel, dim3(1), dim3(1024), 0, st, planes, n, partial, n_partial, inv_bt, out2);
+}

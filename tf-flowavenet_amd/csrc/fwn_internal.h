@@ -1,0 +1,27 @@
+// Internal launcher prototypes shared by the kernel translation units and api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+void fwn_launch_front(const float* xa, const float* an_a, const void* W, const float* bias, void* hout,
+                      int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st);
+void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc,
+                     const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, hipStream_t st);
+void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M,
+                    hipStream_t st);
+void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
+                     int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, hipStream_t st);
+void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
+                     const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,
+                     float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse,
+                     hipStream_t st);
+
+void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st);
+void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,
+                     int k_dst, int n_dst, long ld_dst, void* out, hipStream_t st);
+void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, float bias, int s,
+                         float* out_f32, void* out_planes, hipStream_t st);
+void fwn_launch_split(const float* x, long B, long T, float* planes, hipStream_t st);
+void fwn_launch_merge(const float* planes, long B, long T, float* x, hipStream_t st);
+void fwn_launch_ddi(const float* xa, const float* xb, int M, int Ch, float* an, hipStream_t st);
+void fwn_launch_prior(const float* planes, long n, const float* partial, int n_partial, double inv_bt,
+                      float* out2, hipStream_t st);

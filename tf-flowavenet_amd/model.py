@@ -1,0 +1,185 @@
+"""``FloWaveNet`` - the reference's model surface (model.py:282-404) on MI355X.
+
+Same class name, constructor arguments, method names, argument order, shapes and
+return arity as the reference; torch tensors on a HIP device replace TF tensors
+and calls execute eagerly on the current HIP stream.  All arithmetic runs in
+``csrc/libfwn.so`` (C ABI in ``include/fwn.h``); there is no fallback path.
+
+Differences that are deliberate (DESIGN.md "Deviations"):
+  * ``hparams.dtype`` float16 -> bfloat16 hidden activations / weights with fp32
+    accumulation; the flow state, ActNorm, coupling and all reductions stay fp32
+    (the reference takes its means in fp16, model.py:135,343);
+  * ``reverse`` returns fp32 (the reference returns ``hparams.dtype``);
+  * global (speaker) conditioning is inert in the reference (``WaveNet.__call__``
+    drops ``g``, modules.py:188-189): ``g`` is validated like the reference does
+    (model.py:320-321,353-354) and otherwise ignored;
+  * ``affine=False`` / ``causality=True`` are not BASELINE configurations: rejected.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, packing, weights
+
+
+class FloWaveNet:
+    def __init__(self, hparams, init=False, scope="FloWaveNet", device="cuda", cond_mode=0):
+        if not hparams.affine:
+            raise NotImplementedError("affine=False (additive coupling, model.py:136-139) is out of scope")
+        if hparams.causality:
+            raise NotImplementedError("causality=True (modules.py:12-13,30-31) is out of scope")
+        if hparams.n_block < 1 or hparams.n_flow < 1 or hparams.n_layer < 1:
+            raise ValueError("n_block, n_flow and n_layer must be >= 1")
+        self._hparams = hparams
+        self._scope = scope
+        self._init = bool(init)
+        self._device = device
+        self._cond_mode = cond_mode
+        self._packed = None
+        self._ws = {}
+        self._lib = _lib.load()     # fails loudly when libfwn.so is missing
+        self.hop = int(np.prod(hparams.upsample_scales))
+        if self.hop != hparams.hop_size:
+            raise ValueError("prod(upsample_scales)=%d must equal hop_size=%d (model.py:231)"
+                             % (self.hop, hparams.hop_size))
+
+    # ------------------------------------------------------------------ parameters
+    def load_params(self, params):
+        """params: dict name -> array in the reference's layouts (weights.param_shapes)."""
+        shapes = weights.param_shapes(self._hparams)
+        for name, shape in shapes.items():
+            if name not in params:
+                raise KeyError("missing parameter %r" % name)
+            if tuple(np.shape(params[name])) != tuple(shape):
+                raise ValueError("parameter %r has shape %r, expected %r"
+                                 % (name, tuple(np.shape(params[name])), tuple(shape)))
+        self._packed = packing.pack_model(params, self._hparams, self._device, self._cond_mode)
+        return self
+
+    def init_synthetic(self, seed=1234, **kw):
+        return self.load_params(weights.synthetic_params(self._hparams, seed, **kw))
+
+    def export_actnorm(self):
+        """ActNorm (b, logs) per flow in the reference's layout (after a DDI forward)."""
+        out = {}
+        hp = self._hparams
+        for i in range(hp.n_block):
+            for j in range(hp.n_flow):
+                an = self._packed.an[(i, j)].cpu().numpy()
+                b, logs = packing.actnorm_from_table(an, i)
+                out[weights.flow_prefix(i, j) + "/ActNorm/b"] = b
+                out[weights.flow_prefix(i, j) + "/ActNorm/logs"] = logs
+        return out
+
+    @property
+    def weight_bytes(self):
+        return self._packed.weight_bytes
+
+    # ------------------------------------------------------------------ helpers
+    def _check_g(self, g):
+        if g is None and self._hparams.gin_channels > 0:
+            raise ValueError("g is None")   # model.py:320-321,353-354
+
+    def _prep(self, x, c, what):
+        import torch
+        if self._packed is None:
+            raise RuntimeError("no parameters loaded: call load_params() / init_synthetic() first")
+        hp = self._hparams
+        if x.dim() != 3 or x.shape[2] != 1:
+            raise ValueError("%s must have shape [B, T, 1], got %r" % (what, tuple(x.shape)))
+        if c.dim() != 3 or c.shape[2] != hp.num_mels:
+            raise ValueError("c must have shape [B, T/hop, %d], got %r" % (hp.num_mels, tuple(c.shape)))
+        b, t = int(x.shape[0]), int(x.shape[1])
+        if c.shape[0] != b or int(c.shape[1]) * self.hop != t:
+            raise ValueError("c has %d frames for T=%d samples (hop_size=%d)" % (c.shape[1], t, self.hop))
+        if t % (1 << hp.n_block):
+            raise ValueError("T=%d must be a multiple of 2^n_block=%d (model.py:226)" % (t, 1 << hp.n_block))
+        dev = torch.device(self._device)
+        x32 = x.to(device=dev, dtype=torch.float32).contiguous()
+        c32 = c.to(device=dev, dtype=torch.float32).contiguous()
+        return b, t, x32, c32
+
+    def _workspace(self, b, t):
+        import torch
+        key = (b, t)
+        ws = self._ws.get(key)
+        if ws is None:
+            n = self._lib.fwn_workspace_bytes(C.byref(self._packed.model_desc), b, t)
+            if n == 0:
+                _lib.check(-1, "fwn_workspace_bytes")
+            self._ws.clear()     # one live workspace; sized for 288 GB parts, not hoarded
+            ws = torch.empty(n + 256, dtype=torch.uint8, device=self._device)
+            self._ws[key] = ws
+        off = (-ws.data_ptr()) % 256
+        return ws.data_ptr() + off, ws.numel() - off
+
+    def _stream(self):
+        import torch
+        return torch.cuda.current_stream(torch.device(self._device)).cuda_stream
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, x, c, g=None, return_z=False):
+        """x [B,T,1], c [B,T/hop,num_mels] -> (log_p, logdet) fp32 0-dim tensors (model.py:317-347)."""
+        import torch
+        self._check_g(g)
+        b, t, x32, c32 = self._prep(x, c, "x")
+        wsp, wsn = self._workspace(b, t)
+        out2 = torch.empty(2, dtype=torch.float32, device=self._device)
+        zp = torch.empty(2, b, t // 2, dtype=torch.float32, device=self._device) if return_z else None
+        rc = self._lib.fwn_model_forward(C.byref(self._packed.model_desc), b, t, x32.data_ptr(), c32.data_ptr(),
+                                         wsp, wsn, out2.data_ptr(), zp.data_ptr() if return_z else None,
+                                         1 if self._init else 0, self._stream())
+        _lib.check(rc, "fwn_model_forward")
+        self._init = False       # the reference feeds init=True for one step only (train.py:221,229)
+        if return_z:
+            return out2[0], out2[1], zp
+        return out2[0], out2[1]
+
+    def reverse(self, z, c, g=None):
+        """z [B,T,1], c [B,T/hop,num_mels] -> x [B,T,1] fp32 (model.py:350-396)."""
+        import torch
+        self._check_g(g)
+        b, t, z32, c32 = self._prep(z, c, "z")
+        wsp, wsn = self._workspace(b, t)
+        x = torch.empty(b, t, 1, dtype=torch.float32, device=self._device)
+        rc = self._lib.fwn_model_reverse(C.byref(self._packed.model_desc), b, t, z32.data_ptr(), c32.data_ptr(),
+                                         wsp, wsn, x.data_ptr(), self._stream())
+        _lib.check(rc, "fwn_model_reverse")
+        return x
+
+    def upsample(self, c):
+        """c [B,F,num_mels] -> [B,F*hop,num_mels] fp32 (model.py:398-404)."""
+        import torch
+        if self._packed is None:
+            raise RuntimeError("no parameters loaded")
+        hp = self._hparams
+        cur = c.to(device=self._device, dtype=torch.float32).contiguous()
+        md = self._packed.model_desc
+        for n, s in enumerate(hp.upsample_scales):
+            b, h, w = cur.shape
+            out = torch.empty(b, h * s, w, dtype=torch.float32, device=self._device)
+            rc = self._lib.fwn_upsample_stage(cur.data_ptr(), b, h, w, md.up_w[n], md.up_bias[n], int(s),
+                                              out.data_ptr(), None, self._stream())
+            _lib.check(rc, "fwn_upsample_stage")
+            cur = out
+        return cur
+
+    __call__ = forward
+
+
+def z_planes_to_squeezed(zp, n_block):
+    """planes[2][B][T/2] (device layout) -> the reference's final ``out`` [B, T/2^n, 2^n]
+    (canonical squeezed channel order), for comparisons against the oracle."""
+    import torch
+    two, b, ht = zp.shape
+    n = n_block
+    ch = 1 << (n - 1)
+    rows = ht // ch
+    v = zp.reshape(2, b, rows, ch)                       # [q][b][t][tau']
+    br = torch.as_tensor(packing.bitrev_table(n - 1).astype(np.int64), device=zp.device)
+    out = torch.empty(b, rows, 2 * ch, dtype=zp.dtype, device=zp.device)
+    for q in range(2):
+        out[:, :, q * ch + br] = v[q]
+    return out

@@ -1,0 +1,285 @@
+"""Host logic for K10: index tables that map the reference's parameter layouts
+(TF ``(k, C_in, C_out)`` kernels, logical squeezed channel order) onto the device
+layouts the HIP kernels read, and the driver that runs the packing kernels.
+
+Plane algebra (DESIGN.md "Data layout in HBM"):
+  * n squeezes turn time offset ``tau`` (0..2^n-1) inside a row into canonical channel
+    ``bitrev_n(tau)``; the even/odd planes are the two channel halves, and inside a plane
+    natural position ``tau'`` is logical channel ``bitrev_{n-1}(tau')``;
+  * ``change_order`` (model.py:166-174) only flips which plane plays ``in_a``;
+  * the conditioning half ``c_a`` is a mel-bin half at all phases: natural K index
+    ``tau*half + m'`` is logical channel ``m'*2^n + bitrev_n(tau)``.
+
+Everything in this file except ``pack_model`` is pure NumPy and runs without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .weights import FILTER, flow_prefix
+
+GATE_N = 2 * FILTER  # filter + gate output channels
+
+
+def bitrev(v: int, nbits: int) -> int:
+    out = 0
+    for _ in range(nbits):
+        out = (out << 1) | (v & 1)
+        v >>= 1
+    return out
+
+
+def bitrev_table(nbits: int) -> np.ndarray:
+    return np.array([bitrev(v, nbits) for v in range(1 << nbits)], dtype=np.int32)
+
+
+def roundup(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def gate_row_channel() -> "tuple[np.ndarray, np.ndarray]":
+    """Packed gate row n' = nb*128 + wn*64 + fg*32 + j -> (fg, channel nb*64 + wn*32 + j)."""
+    n = np.arange(GATE_N)
+    nb, wn, fg, j = n // 128, (n // 64) % 2, (n // 32) % 2, n % 32
+    return fg.astype(np.int32), (nb * 64 + wn * 32 + j).astype(np.int32)
+
+
+def front_src_k(block: int) -> np.ndarray:
+    """[kfpad] -> source row of the (3*Ch, 256) front kernel, -1 = K padding."""
+    ch = 1 << block
+    br = bitrev_table(block)
+    out = np.full(roundup(3 * ch, 64), -1, dtype=np.int32)
+    for tap in range(3):
+        out[tap * ch: (tap + 1) * ch] = tap * ch + br
+    return out
+
+
+def cond_src_k(block: int, half: int) -> np.ndarray:
+    """[kcpad] -> source row of the (cin, 256) conditioning kernel for natural K = tau*half + m'."""
+    n = block + 1
+    p = 1 << n
+    cin = half * p
+    br = bitrev_table(n)
+    out = np.full(roundup(cin, 64), -1, dtype=np.int32)
+    tau, m = np.divmod(np.arange(cin), half)
+    out[:cin] = m * p + br[tau]
+    return out
+
+
+def zero_src_n(block: int) -> np.ndarray:
+    """[npt*64] -> source column of the (256, C) ZeroConv kernel; -1 = unused pad row.
+
+    Row pt*64 + fg*32 + j serves natural position tau' = pt*32 + j; fg 0 = log_s, 1 = t
+    (model.py:133 split order)."""
+    ch = 1 << block
+    npt = max(1, (ch + 31) // 32)
+    br = bitrev_table(block)
+    out = np.full(npt * 64, -1, dtype=np.int32)
+    for pt in range(npt):
+        for j in range(32):
+            tau = pt * 32 + j
+            if tau < ch:
+                out[pt * 64 + j] = br[tau]
+                out[pt * 64 + 32 + j] = ch + br[tau]
+    return out
+
+
+def actnorm_table(b: np.ndarray, logs: np.ndarray, block: int) -> np.ndarray:
+    """ActNorm (b, logs) in logical channel order -> an[2][4][Ch] (shift, scale, 1/scale, 3*logs)."""
+    ch = 1 << block
+    br = bitrev_table(block).astype(np.int64)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    l3 = 3.0 * np.asarray(logs, dtype=np.float64).reshape(-1)
+    out = np.empty((2, 4, ch), dtype=np.float64)
+    for role in range(2):
+        idx = role * ch + br
+        out[role, 0] = b[idx]
+        out[role, 1] = np.exp(l3[idx])
+        out[role, 2] = np.exp(-l3[idx])
+        out[role, 3] = l3[idx]
+    return out.astype(np.float32)
+
+
+def actnorm_from_table(an: np.ndarray, block: int):
+    """Inverse of ``actnorm_table``: an[2][4][Ch] -> (b, logs) in the reference's (1,1,C) layout."""
+    ch = 1 << block
+    br = bitrev_table(block).astype(np.int64)
+    b = np.empty(2 * ch, dtype=np.float32)
+    logs = np.empty(2 * ch, dtype=np.float32)
+    for role in range(2):
+        b[role * ch + br] = an[role, 0]
+        logs[role * ch + br] = an[role, 3] / 3.0
+    return b.reshape(1, 1, -1), logs.reshape(1, 1, -1)
+
+
+def upsample_kernel(params, n: int) -> "tuple[np.ndarray, float]":
+    """Weight-normed (2s,3) kernel of upsampling stage n: l2_normalize over axis [0,2]
+    (convolutional.py:186) times g; returns (kernel fp32 [2s][3], bias)."""
+    v = np.asarray(params["upsample_%d/kernel" % n], dtype=np.float64)
+    nrm = np.sqrt(np.maximum(np.sum(v * v, axis=(0, 2), keepdims=True), 1e-12))
+    w = v / nrm * float(np.asarray(params["upsample_%d/g" % n]).reshape(-1)[0])
+    return np.ascontiguousarray(w[:, :, 0, 0], dtype=np.float32), float(
+        np.asarray(params["upsample_%d/bias" % n]).reshape(-1)[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# Device side
+# ---------------------------------------------------------------------------------------------
+class PackedModel:
+    """Owns the packed device tensors and the ctypes descriptors that point into them."""
+
+    def __init__(self, hp, device):
+        self.hp = hp
+        self.device = device
+        self.tensors = []        # keeps every device buffer alive
+        self.an = {}             # (i, j) -> fp32 [2][4][Ch] tensor
+        self.flow_descs = (_lib.FlowDesc * (hp.n_block * hp.n_flow))()
+        self.model_desc = _lib.ModelDesc()
+        self.weight_bytes = 0
+
+    def keep(self, t):
+        self.tensors.append(t)
+        return t
+
+
+def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
+    """Upload ``params`` (reference layouts, fp32) and run the packing kernels (K10)."""
+    import torch
+
+    lib = _lib.load()
+    if hp.n_layer > _lib.FWN_MAX_LAYERS:
+        raise ValueError("n_layer=%d exceeds FWN_MAX_LAYERS" % hp.n_layer)
+    if hp.num_mels % 8:
+        raise ValueError("num_mels must be a multiple of 8 (16-byte rows of the mel half planes)")
+    half = hp.num_mels // 2
+    pm = PackedModel(hp, device)
+    dev = torch.device(device)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    L = hp.n_layer
+    idx_cache = {}
+
+    def dev_i32(key, fn):
+        if key not in idx_cache:
+            idx_cache[key] = pm.keep(torch.from_numpy(np.ascontiguousarray(fn(), dtype=np.int32)).to(dev))
+        return idx_cache[key]
+
+    def dev_f32(a):
+        return pm.keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev))
+
+    ident256 = dev_i32("id256", lambda: np.arange(FILTER))
+    ident768 = dev_i32("id768", lambda: np.arange(3 * FILTER))
+    fg, gch = gate_row_channel()
+    gate_rows = [dev_i32("gate_rows%d" % s, lambda s=s: np.where(fg == s, gch, -1)) for s in (0, 1)]
+    scale_buf = torch.empty(FILTER, dtype=torch.float32, device=dev)
+
+    def pack(name, src_k, src_n, k_dst, n_dst, out, ld_dst, col_off=0, weight_norm=True):
+        """Pack params[name + '/kernel'] into out[:, col_off: col_off + k_dst]."""
+        v = torch.from_numpy(np.ascontiguousarray(params[name + "/kernel"], dtype=np.float32)).to(dev)
+        k_src = v.shape[0] * v.shape[1]
+        n_src = v.shape[2]
+        sc = None
+        if weight_norm:
+            g = torch.from_numpy(np.ascontiguousarray(params[name + "/g"], dtype=np.float32)).to(dev)
+            _lib.check(lib.fwn_wn_scale(v.data_ptr(), g.data_ptr(), k_src, n_src, scale_buf.data_ptr(), stream),
+                       "fwn_wn_scale")
+            sc = scale_buf.data_ptr()
+        _lib.check(lib.fwn_pack_bf16(v.data_ptr(), sc, src_k.data_ptr(), src_n.data_ptr(), n_src, k_dst, n_dst,
+                                     ld_dst, out.data_ptr() + 2 * col_off, stream), "fwn_pack_bf16")
+        # v / g are freed by the caching allocator only after the stream passes this point
+        v.record_stream(torch.cuda.current_stream(dev))
+
+    def bf16_zeros(*shape):
+        t = pm.keep(torch.zeros(*shape, dtype=torch.bfloat16, device=dev))
+        pm.weight_bytes += t.numel() * 2
+        return t
+
+    for i in range(hp.n_block):
+        ch = 1 << i
+        cin = half * (2 << i)
+        kcpad = roundup(cin, 64)
+        kfpad = roundup(3 * ch, 64)
+        npt = max(1, (ch + 31) // 32)
+        f_src_k = dev_i32(("front", i), lambda: front_src_k(i))
+        c_src_k = dev_i32(("cond", i), lambda: cond_src_k(i, half))
+        z_src_n = dev_i32(("zero", i), lambda: zero_src_n(i))
+        zsn_host = zero_src_n(i)
+        wc_blk = bf16_zeros(hp.n_flow, L, GATE_N, kcpad)     # contiguous: hoisted conditioning
+        for j in range(hp.n_flow):
+            fp = flow_prefix(i, j)
+            wp = fp + "/WaveNet"
+            d = pm.flow_descs[i * hp.n_flow + j]
+            d.Ch, d.cin, d.kcpad, d.kfpad, d.npt, d.L = ch, cin, kcpad, kfpad, npt, L
+
+            wfront = bf16_zeros(FILTER, kfpad)
+            pack(wp + "/Conv_front", f_src_k, ident256, kfpad, FILTER, wfront, kfpad)
+            d.Wfront = wfront.data_ptr()
+            d.bfront = dev_f32(params[wp + "/Conv_front/bias"]).data_ptr()
+
+            wskip = bf16_zeros(FILTER, L * FILTER)
+            bskip = np.zeros(FILTER, dtype=np.float64)
+            for l in range(L):
+                rp = "%s/ResBlock_%d" % (wp, l)
+                wd = bf16_zeros(GATE_N, 3 * FILTER)
+                pack(rp + "/Conv_filter", ident768, gate_rows[0], 3 * FILTER, GATE_N, wd, 3 * FILTER)
+                pack(rp + "/Conv_gate", ident768, gate_rows[1], 3 * FILTER, GATE_N, wd, 3 * FILTER)
+                wc = wc_blk[j, l]
+                pack(rp + "/filter_conv_c", c_src_k, gate_rows[0], kcpad, GATE_N, wc, kcpad)
+                pack(rp + "/gate_conv_c", c_src_k, gate_rows[1], kcpad, GATE_N, wc, kcpad)
+                bsum = [np.asarray(params[rp + "/Conv_filter/bias"], np.float32)
+                        + np.asarray(params[rp + "/filter_conv_c/bias"], np.float32),
+                        np.asarray(params[rp + "/Conv_gate/bias"], np.float32)
+                        + np.asarray(params[rp + "/gate_conv_c/bias"], np.float32)]
+                bg = np.where(fg == 0, bsum[0][gch], bsum[1][gch])
+                d.Wd[l] = wd.data_ptr()
+                d.Wc[l] = wc.data_ptr()
+                d.bgate[l] = dev_f32(bg).data_ptr()
+                if l + 1 < L:   # the last layer's res_conv is dead (modules.py:126-128,175-176)
+                    wr = bf16_zeros(FILTER, FILTER)
+                    pack(rp + "/res_conv", ident256, ident256, FILTER, FILTER, wr, FILTER)
+                    d.Wres[l] = wr.data_ptr()
+                    d.bres[l] = dev_f32(params[rp + "/res_conv/bias"]).data_ptr()
+                pack(rp + "/skip_conv", ident256, ident256, FILTER, FILTER, wskip, L * FILTER, col_off=l * FILTER)
+                bskip += np.asarray(params[rp + "/skip_conv/bias"], np.float64)
+            d.Wskip = wskip.data_ptr()
+            d.bskip = dev_f32(bskip).data_ptr()
+
+            wfin = bf16_zeros(FILTER, FILTER)
+            pack(wp + "/Conv_final", ident256, ident256, FILTER, FILTER, wfin, FILTER)
+            d.Wfinal = wfin.data_ptr()
+            d.bfinal = dev_f32(params[wp + "/Conv_final/bias"]).data_ptr()
+
+            wz = bf16_zeros(npt * 64, FILTER)
+            pack(wp + "/ZeroConv1d", ident256, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
+            zb = np.asarray(params[wp + "/ZeroConv1d/bias"], np.float64).reshape(-1)
+            zs = np.asarray(params[wp + "/ZeroConv1d/scale"], np.float64).reshape(-1)
+            valid = zsn_host >= 0
+            bz = np.zeros(npt * 64)
+            ez = np.ones(npt * 64)
+            bz[valid] = zb[zsn_host[valid]]
+            ez[valid] = np.exp(3.0 * zs[zsn_host[valid]])
+            d.Wzero = wz.data_ptr()
+            d.bzero = dev_f32(bz).data_ptr()
+            d.ezero = dev_f32(ez).data_ptr()
+
+            an = dev_f32(actnorm_table(params[fp + "/ActNorm/b"], params[fp + "/ActNorm/logs"], i))
+            pm.an[(i, j)] = an
+            d.an = an.data_ptr()
+
+    md = pm.model_desc
+    md.n_block, md.n_flow, md.n_layer, md.num_mels = hp.n_block, hp.n_flow, L, hp.num_mels
+    md.n_up = len(hp.upsample_scales)
+    if md.n_up > _lib.FWN_MAX_UPSAMPLE:
+        raise ValueError("too many upsample stages")
+    for n, s in enumerate(hp.upsample_scales):
+        wk, bias = upsample_kernel(params, n)
+        md.up_scale[n] = int(s)
+        md.up_w[n] = dev_f32(wk).data_ptr()
+        md.up_bias[n] = bias
+    md.flows = C.cast(pm.flow_descs, C.POINTER(_lib.FlowDesc))
+    md.cond_mode = int(cond_mode)
+    torch.cuda.current_stream(dev).synchronize()
+    return pm
