@@ -102,7 +102,9 @@ int fwn_res(const fwn_flow_desc* d, int layer, const void* o, const void* h_in, 
 int fwn_cond(const void* ca, const void* Wc_base, float* P_base, int64_t w_stride, int64_t p_stride,
              int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, void* stream);
 /* K6'+K7+K8 tail: skip sum, final 1x1, ZeroConv1d, affine coupling, ActNorm, log-det partials
- * (modules.py:175-180,51-56; model.py:86-102,124-141,146-161).  o = [L][M][256]. */
+ * (modules.py:175-180,51-56; model.py:86-102,124-141,146-161).  o = [L][M][256].
+ * partial (forward only, may be NULL) receives fwn_tail_partials(M) per-workgroup sums. */
+int fwn_tail_partials(int M);
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
              int inverse, void* stream);
 
@@ -110,7 +112,7 @@ int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float*
  * xa / xb: the planes holding in_a / in_b for this flow's swap parity, ca the matching
  * conditioning plane.  h0/h1: [M][256] bf16 scratch, o: [L][M][256] bf16 scratch,
  * P: NULL or [L][M][512] fp32 precomputed conditioning projections for this flow,
- * partial: NULL or [ceil(M/64)] log-det partial sums (forward).  ddi: run fwn_actnorm_ddi first. */
+ * partial: NULL or [fwn_tail_partials(M)] log-det partial sums (forward).  ddi: run fwn_actnorm_ddi first. */
 int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
                  void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
                  void* stream);

@@ -203,3 +203,8 @@ def reverse(fp, z, c, hp):
     if parity:
         raise NotImplementedError("odd n_block*n_flow leaves a swapped tensor; not a BASELINE config")
     return cur.transpose(1, 2).contiguous()
+
+
+def forward_z(fp, x, c, hp):
+    """Differentiable z (channels-last, squeezed) for Jacobian tests."""
+    return forward(fp, x, c, hp)[2]

@@ -1,0 +1,66 @@
+"""CPU tests of the C-ABI boundary: the library loads, exports every symbol include/fwn.h
+declares, and validates arguments (error code + message) before any launch.  No compute."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from tf_flowavenet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "fwn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fwn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libfwn.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "ctypes binding missing for %s" % n
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version(lib):
+    assert lib.fwn_version() == 100
+
+
+def test_struct_layout_matches_header():
+    # 6 int32 + (2 + 5*8 + 7 + 1) pointers
+    assert C.sizeof(_lib.FlowDesc) == 24 + 8 * (2 + 5 * _lib.FWN_MAX_LAYERS + 7 + 1)
+    assert _lib.ModelDesc.flows.offset % 8 == 0 and _lib.ModelDesc.up_w.offset == 40
+
+
+def test_argument_validation_reports_errors(lib):
+    assert lib.fwn_split_planes(None, 1, 8, None, None) == -1
+    assert b"fwn_split_planes" in lib.fwn_last_error()
+    assert lib.fwn_split_planes(1 << 20, 1, 7, 1 << 20, None) == -1          # odd T
+    assert lib.fwn_upsample_stage(1 << 20, 1, 4, 80, 1 << 20, 0.0, 3, 1 << 20, None, None) == -1   # odd s
+    assert b"even" in lib.fwn_last_error()
+    assert lib.fwn_pack_bf16(None, None, None, None, 1, 1, 1, 1, None, None) == -1
+    d = _lib.FlowDesc()
+    assert lib.fwn_front(C.byref(d), 1 << 20, 1 << 20, 64, 64, 1, None) == -1
+    assert b"power of two" in lib.fwn_last_error() or b"flow desc" in lib.fwn_last_error()
+    m = _lib.ModelDesc()
+    assert lib.fwn_workspace_bytes(C.byref(m), 1, 256) == 0
+    assert lib.fwn_model_forward(C.byref(m), 1, 256, None, None, None, 0, None, None, 0, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.FwnError, match="no CPU fallback"):
+        _lib.load()

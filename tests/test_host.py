@@ -1,0 +1,220 @@
+"""CPU tests of the host logic: the packing index tables and the plane algebra (squeeze /
+change_order as index bookkeeping) are checked by emulating, in fp64 NumPy, exactly what the
+HIP kernels compute from the packed layouts, and comparing with the oracle on the reference's
+logical layouts.  No GPU, no libfwn compute calls."""
+import numpy as np
+import pytest
+
+from oracle import flowavenet_np as onp
+from tf_flowavenet_amd import packing as P
+from tf_flowavenet_amd import weights as W
+from tf_flowavenet_amd.hparams import HParams, default_hparams, hparams8000
+
+from conftest import small_hparams
+
+
+def wn_pack(params, name, src_k, src_n, weight_norm=True):
+    """NumPy twin of fwn_wn_scale + fwn_pack_bf16 (without the bf16 cast)."""
+    v = np.asarray(params[name + "/kernel"], np.float64)
+    v2 = v.reshape(v.shape[0] * v.shape[1], v.shape[2])
+    if weight_norm:
+        sc = np.asarray(params[name + "/g"], np.float64) / np.sqrt(np.maximum((v2 ** 2).sum(0), 1e-12))
+    else:
+        sc = np.ones(v2.shape[1])
+    out = np.zeros((len(src_n), len(src_k)))
+    for nd, sn in enumerate(src_n):
+        if sn < 0:
+            continue
+        for kd, sk in enumerate(src_k):
+            if sk >= 0:
+                out[nd, kd] = v2[sk, sn] * sc[sn]
+    return out
+
+
+def to_planes(x):
+    """[B,T,1] -> planes[2][B][T/2] (fwn_split_planes)."""
+    return np.stack([x[:, 0::2, 0], x[:, 1::2, 0]])
+
+
+def cplanes_of(cu):
+    """upsampled c [B,T,mels] -> cplanes[2][B][T][mels/2] (fwn_upsample_stage output)."""
+    half = cu.shape[2] // 2
+    return np.stack([cu[:, :, :half], cu[:, :, half:]])
+
+
+def taps(h, ti, d):
+    """rows shifted by -d, 0, +d with zero padding at clip edges; h: [M,256] with M = B*ti."""
+    m = h.shape[0]
+    out = []
+    t = np.arange(m) % ti
+    for s in (-d, 0, d):
+        sh = np.zeros_like(h)
+        ok = (t + s >= 0) & (t + s < ti)
+        idx = np.arange(m)[ok]
+        sh[idx] = h[idx + s]
+        out.append(sh)
+    return np.concatenate(out, 1)
+
+
+def run_emulated_forward(params, hp, x, c):
+    """Whole forward on device layouts with packed weights (fp64)."""
+    b, t, _ = x.shape
+    half = hp.num_mels // 2
+    planes = to_planes(x)
+    cpl = cplanes_of(onp.upsample(params, c, hp))
+    fg, gch = P.gate_row_channel()
+    logdet_sum = 0.0
+    p = 0
+    for i in range(hp.n_block):
+        ch = 1 << i
+        ti = t // (2 * ch)
+        m = b * ti
+        cin = half * 2 * ch
+        br = P.bitrev_table(i).astype(np.int64)
+        for j in range(hp.n_flow):
+            fp = W.flow_prefix(i, j)
+            wp = fp + "/WaveNet"
+            xa = planes[p].reshape(m, ch)
+            xb = planes[1 - p].reshape(m, ch)
+            ca = cpl[p].reshape(m, cin)
+            b_ = np.asarray(params[fp + "/ActNorm/b"], np.float64).reshape(-1)
+            l3 = 3.0 * np.asarray(params[fp + "/ActNorm/logs"], np.float64).reshape(-1)
+            sh = [b_[r * ch + br] for r in range(2)]
+            sc = [np.exp(l3[r * ch + br]) for r in range(2)]
+            l3n = [l3[r * ch + br] for r in range(2)]
+            ya = (xa + sh[0]) * sc[0]
+            # front conv: K = tap*Ch + tau'
+            wf = wn_pack(params, wp + "/Conv_front", P.front_src_k(i), np.arange(256))
+            a_front = np.zeros((m, wf.shape[1]))
+            tt = np.arange(m) % ti
+            for tap in range(3):
+                ok = (tt + tap - 1 >= 0) & (tt + tap - 1 < ti)
+                idx = np.arange(m)[ok]
+                a_front[idx, tap * ch:(tap + 1) * ch] = ya[idx + tap - 1]
+            h = np.maximum(a_front @ wf.T + np.asarray(params[wp + "/Conv_front/bias"], np.float64), 0.0)
+            o_list = []
+            for l in range(hp.n_layer):
+                rp = "%s/ResBlock_%d" % (wp, l)
+                rows = [np.where(fg == s, gch, -1) for s in (0, 1)]
+                wd = wn_pack(params, rp + "/Conv_filter", np.arange(768), rows[0]) + \
+                    wn_pack(params, rp + "/Conv_gate", np.arange(768), rows[1])
+                wc = wn_pack(params, rp + "/filter_conv_c", P.cond_src_k(i, half), rows[0]) + \
+                    wn_pack(params, rp + "/gate_conv_c", P.cond_src_k(i, half), rows[1])
+                bsum = [np.asarray(params[rp + "/Conv_filter/bias"], np.float64) + np.asarray(params[rp + "/filter_conv_c/bias"], np.float64),
+                        np.asarray(params[rp + "/Conv_gate/bias"], np.float64) + np.asarray(params[rp + "/gate_conv_c/bias"], np.float64)]
+                bg = np.where(fg == 0, bsum[0][gch], bsum[1][gch])
+                ca_pad = np.zeros((m, wc.shape[1]))
+                ca_pad[:, :cin] = ca
+                pre = taps(h, ti, 3 ** l) @ wd.T + ca_pad @ wc.T + bg
+                o = np.zeros((m, 256))
+                f_rows = np.where(fg == 0)[0]
+                o[:, gch[f_rows]] = np.tanh(pre[:, f_rows]) * onp.sigmoid(pre[:, f_rows + 32])
+                o_list.append(o)
+                if l + 1 < hp.n_layer:
+                    wr = wn_pack(params, rp + "/res_conv", np.arange(256), np.arange(256))
+                    h = (h + o @ wr.T + np.asarray(params[rp + "/res_conv/bias"], np.float64)) * np.sqrt(0.5)
+            ws = np.concatenate([wn_pack(params, "%s/ResBlock_%d/skip_conv" % (wp, l), np.arange(256), np.arange(256))
+                                 for l in range(hp.n_layer)], 1)
+            bs = sum(np.asarray(params["%s/ResBlock_%d/skip_conv/bias" % (wp, l)], np.float64) for l in range(hp.n_layer))
+            s = np.maximum(np.concatenate(o_list, 1) @ ws.T + bs, 0.0)
+            wfin = wn_pack(params, wp + "/Conv_final", np.arange(256), np.arange(256))
+            u = np.maximum(s @ wfin.T + np.asarray(params[wp + "/Conv_final/bias"], np.float64), 0.0)
+            zsn = P.zero_src_n(i)
+            wz = wn_pack(params, wp + "/ZeroConv1d", np.arange(256), zsn, weight_norm=False)
+            zb = np.asarray(params[wp + "/ZeroConv1d/bias"], np.float64).reshape(-1)
+            zs = np.asarray(params[wp + "/ZeroConv1d/scale"], np.float64).reshape(-1)
+            net = u @ wz.T
+            yb = (xb + sh[1]) * sc[1]
+            new_b = np.empty_like(xb)
+            for tau in range(ch):
+                pt, jj = divmod(tau, 32)
+                nls, nt = pt * 64 + jj, pt * 64 + 32 + jj
+                ls = (net[:, nls] + zb[zsn[nls]]) * np.exp(3.0 * zs[zsn[nls]])
+                tv = (net[:, nt] + zb[zsn[nt]]) * np.exp(3.0 * zs[zsn[nt]])
+                new_b[:, tau] = (yb[:, tau] - tv) * np.exp(-ls)
+                logdet_sum += np.sum(l3n[0][tau] + l3n[1][tau] - ls)
+            planes[p] = ya.reshape(b, -1)
+            planes[1 - p] = new_b.reshape(b, -1)
+            p ^= 1
+    log_p = np.mean(0.5 * (-np.log(2 * np.pi) - planes ** 2))
+    return log_p, logdet_sum / (b * t), planes
+
+
+@pytest.mark.parametrize("cfg,b,t", [
+    (dict(n_block=2, n_flow=2), 2, 64),
+    (dict(n_block=3, n_flow=3, num_mels=16), 1, 128),
+    (dict(n_block=4, n_flow=2, n_layer=1, num_mels=16), 2, 128),
+])
+def test_packed_layout_emulation_matches_oracle(cfg, b, t):
+    hp = small_hparams(**cfg)
+    params = onp.to_f64(W.synthetic_params(hp, 7, actnorm="random"))
+    inp = W.synthetic_inputs(hp, b, t)
+    x, c = inp["x"].astype(np.float64), inp["c"].astype(np.float64)
+    lp0, ld0, z0 = onp.forward(params, x, c, hp)
+    lp, ld, planes = run_emulated_forward(params, hp, x, c)
+    assert abs(lp - lp0) < 1e-12 and abs(ld - ld0) < 1e-12
+    # planes -> canonical squeezed layout of the last block (q*Ch + bitrev(tau'))
+    n = hp.n_block
+    ch = 1 << (n - 1)
+    rows = t // (2 * ch)
+    br = P.bitrev_table(n - 1).astype(np.int64)
+    z = np.empty((b, rows, 2 * ch))
+    for q in range(2):
+        z[:, :, q * ch + br] = planes[q].reshape(b, rows, ch)
+    if (hp.n_block * hp.n_flow) % 2:   # odd number of swaps: logical = halves exchanged
+        z = np.concatenate([z[:, :, ch:], z[:, :, :ch]], 2)
+    np.testing.assert_allclose(z, z0, atol=1e-12)
+
+
+def test_actnorm_table_round_trip():
+    rng = np.random.default_rng(3)
+    for i in range(5):
+        c = 2 << i
+        b = rng.standard_normal((1, 1, c)).astype(np.float32)
+        logs = (0.1 * rng.standard_normal((1, 1, c))).astype(np.float32)
+        an = P.actnorm_table(b, logs, i)
+        assert an.shape == (2, 4, c // 2)
+        b2, l2 = P.actnorm_from_table(an, i)
+        np.testing.assert_allclose(b2, b, rtol=1e-6)
+        np.testing.assert_allclose(l2, logs, rtol=1e-5, atol=1e-7)
+
+
+def test_index_tables_are_permutations():
+    for i in range(8):
+        ch = 1 << i
+        f = P.front_src_k(i)
+        assert sorted(f[f >= 0]) == list(range(3 * ch)) and len(f) % 64 == 0
+        ck = P.cond_src_k(i, 40)
+        assert sorted(ck[ck >= 0]) == list(range(40 * 2 * ch)) and len(ck) % 64 == 0
+        z = P.zero_src_n(i)
+        assert sorted(z[z >= 0]) == list(range(2 * ch))
+    fg, gch = P.gate_row_channel()
+    assert sorted(gch[fg == 0]) == list(range(256)) and sorted(gch[fg == 1]) == list(range(256))
+    # filter row n' and gate row n'+32 address the same channel (the epilogue pairs them)
+    fr = np.where(fg == 0)[0]
+    assert np.all(gch[fr] == gch[fr + 32]) and np.all(fg[fr + 32] == 1)
+
+
+def test_hparams_surface():
+    hp = default_hparams()
+    # names / defaults of reference hparams.py:6-50
+    assert (hp.n_block, hp.n_flow, hp.n_layer, hp.num_mels, hp.hop_size, hp.sample_rate) == (8, 6, 2, 80, 256, 22050)
+    assert hp.upsample_scales == [16, 16] and hp.temp == 0.7 and hp.batch_size == 8 and hp.affine and not hp.causality
+    assert hp.gin_channels == -1 and hp.max_time_steps == 6400 and hp.tf_random_seed == 75 and hp.scale == 64.0
+    h8 = hparams8000()   # reference hparams8000.py
+    assert (h8.n_block, h8.hop_size, h8.sample_rate, h8.upsample_scales, h8.max_time_steps, h8.n_fft, h8.fmax) == \
+        (5, 96, 8000, [8, 12], 2320, 512, 4000)
+    with pytest.raises(AttributeError):
+        hp.replace(not_a_param=1)
+    with pytest.raises(AttributeError):
+        _ = hp.not_a_param
+    assert isinstance(hp, HParams) and "n_block" in hp.values()
+
+
+def test_synthetic_inputs_contract():
+    hp = default_hparams()
+    with pytest.raises(ValueError):
+        W.synthetic_inputs(hp, 1, 16000)        # not a multiple of hop 256
+    inp = W.synthetic_inputs(hp, 2, 512)
+    assert inp["x"].shape == (2, 512, 1) and inp["c"].shape == (2, 2, 80) and inp["z"].shape == (2, 512, 1)
+    assert np.abs(inp["x"]).max() <= 0.999 and inp["c"].min() >= 0 and inp["c"].max() < 1

@@ -152,6 +152,11 @@ int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float*
     return check_launch("fwn_tail");
 }
 
+int fwn_tail_partials(int M) {
+    const int rows = fwn_tail_rows(M);
+    return (M + rows - 1) / rows;
+}
+
 int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
                  void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
                  void* stream) {
@@ -256,7 +261,7 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
             const size_t need = (size_t)m->n_flow * m->n_layer * M * 512 * 4;
             if (need > pbytes) pbytes = need;
         }
-        npart += m->n_flow * (int)((M + 63) / 64);
+        npart += m->n_flow * fwn_tail_partials((int)M);
     }
     c.P = off; off = align_up(off + pbytes);
     c.partial = off; off = align_up(off + (size_t)npart * 4);
@@ -346,7 +351,7 @@ int fwn_model_forward(const fwn_model_desc* m, int64_t B, int64_t T, const float
             rc = fwn_flow_run(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
                               ws + c.h0, ws + c.h1, ws + c.o, P, partial + poff, 0, init, stream);
             if (rc) return rc;
-            poff += (int)((M + 63) / 64);
+            poff += fwn_tail_partials((int)M);
             p ^= 1;   // change_order (model.py:190)
         }
     }

@@ -1,6 +1,9 @@
 // Shared device helpers for the gfx950 (MI355X / CDNA4) FloWaveNet kernels.
-// wave = 64 lanes, MFMA = v_mfma_f32_32x32x16_bf16, LDS tiles are 64 bf16 (128 B)
-// wide and XOR-swizzled so that ds_read_b128 fragment reads are conflict-free.
+// wave = 64 lanes, MFMA = v_mfma_f32_32x32x16_bf16, LDS tiles are 64 bf16 (128 B) wide and
+// XOR-swizzled so that ds_read_b128 fragment reads are conflict-free.  Tiles are staged
+// HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no VGPR round trip, no branches;
+// rows that must read as zero (clip edges of the dilated taps, M / K padding) get an
+// out-of-range buffer offset, which the hardware range check turns into zeros.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,17 +11,36 @@
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __amdgpu_buffer_rsrc_t srd_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #define FWN_HID 256          // residual/gate/skip channels (reference model.py:217)
 #define FWN_BK 64            // K elements per staged chunk (128 B rows in LDS)
+#define FWN_OOB 0x80000000u  // buffer offset beyond every descriptor's range (buffers < 2 GiB)
 
 union Pack16 {               // 16 bytes = 8 bf16 = one MFMA A/B fragment
     uint4 u;
+    u32x4 w;
     bf16x8 v;
     bf16 e[8];
 };
 
 __device__ __forceinline__ uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// Raw buffer descriptor over [p, p + bytes): stride 0, hardware range check on the byte offset.
+__device__ __forceinline__ srd_t make_srd(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(srd_t s, uint32_t voff) {
+    Pack16 r;
+    r.w = __builtin_amdgcn_raw_buffer_load_b128(s, voff, 0, 0);
+    return r.u;
+}
+// 64 lanes x 16 B straight into LDS at (wave-uniform) dst + lane*16.
+__device__ __forceinline__ void buf_load16_lds(srd_t s, uint32_t voff, unsigned char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+}
 
 // Byte offset of 16-byte chunk `c8` (0..7) of row `row` in a [rows][64] bf16 LDS tile.
 // Two 128-B rows share one 256-B bank row; XOR with (row>>1)&7 spreads 16 rows over the
@@ -43,6 +65,15 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
     return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
 
+// tanh(f) * sigmoid(g) with two v_exp_f32 and one v_rcp_f32:
+//   a = e^-2f, b = e^-g  ->  (1 - a) / ((1 + a) (1 + b)).
+// f is clamped to +-15 (tanh is +-1 to fp32 beyond +-9.1) and g to >= -40 so a, b stay finite.
+__device__ __forceinline__ float gated_unit(float f, float g) {
+    const float a = __builtin_amdgcn_exp2f(-2.885390081777927f * fminf(fmaxf(f, -15.0f), 15.0f));
+    const float b = __builtin_amdgcn_exp2f(-1.4426950408889634f * fmaxf(g, -40.0f));
+    return (1.0f - a) * __builtin_amdgcn_rcpf((1.0f + a) * (1.0f + b));
+}
+
 __device__ __forceinline__ float fast_sigmoid(float x) {
     return __frcp_rn(1.0f + __expf(-x));
 }
@@ -61,48 +92,69 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ---------------------------------------------------------------------------
-// Generic bf16 MFMA GEMM core: block tile (32*MI*2) x 128, 256 threads = 4 waves
-// laid out 2 (M) x 2 (N); each wave owns MI x 2 tiles of 32x32.
-// `Prob` supplies the K-chunk sources (A may be a shifted / zero-padded / converted
-// view) and the fused epilogue.  Register-staged, LDS double-buffered, one barrier
-// per K-chunk.
+// Generic bf16 MFMA GEMM core: block tile (64*MI) x 128, 256 threads = 4 waves laid out
+// 2 (M) x 2 (N); each wave owns MI x 2 tiles of 32x32.
+// `Prob` supplies, per K-chunk, a buffer descriptor + per-lane byte offset for the A rows
+// (possibly a shifted / zero-padded view) and the B rows, and the fused epilogue.
+// A problem whose A operand needs arithmetic on the way in (front conv: fp32 -> ActNorm ->
+// bf16) sets A_DMA = false and returns the 16 packed bytes instead.
+// Pipeline: 2 LDS buffers, the DMA of chunk q+1 is in flight while chunk q is multiplied,
+// one barrier per chunk.
 // ---------------------------------------------------------------------------
 template <int MI, class Prob>
 __device__ __forceinline__ void gemm128_body(const Prob& p, int tile_m, int tile_n) {
     constexpr int BM = 64 * MI;
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = 128 * 128;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (A_BYTES + B_BYTES)];
+    constexpr int NA = BM / 32;      // A rows handled per lane per chunk
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * (A_BYTES + B_BYTES)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
-    const int c8 = tid & 7, r0 = tid >> 3;
     const int m0 = tile_m * BM, n0 = tile_n * 128;
 
-    typename Prob::RowCtx rc[2 * MI];
+    // DMA slot j of this wave covers tile rows [8*(wave + 4j), +8); lane -> (row, LDS slot);
+    // the global chunk it fetches is the slot XOR-ed back through the swizzle.
+    int trow[4], tc8[4];
 #pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) rc[i] = p.row_ctx(m0 + r0 + 32 * i);
+    for (int j = 0; j < 4; ++j) {
+        trow[j] = 8 * (wave + 4 * j) + (lane >> 3);
+        tc8[j] = (lane & 7) ^ ((trow[j] >> 1) & 7);
+    }
+    typename Prob::RowCtx rc[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) rc[j] = p.row_ctx(m0 + trow[j]);
 
-    uint4 ra[2 * MI], rb[4];
     const int nq = p.nchunks();
+    uint4 ra[NA];   // only used when !Prob::A_DMA
 
-    auto gload = [&](int q) {
+    auto stage = [&](int q, int buf) {
         typename Prob::ChunkCtx cc = p.chunk_ctx(q);
-#pragma unroll
-        for (int i = 0; i < 2 * MI; ++i) ra[i] = p.load_a(cc, rc[i], c8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = p.load_b(cc, n0 + r0 + 32 * i, c8);
-    };
-    auto lwrite = [&](int buf) {
         unsigned char* la = lds + buf * (A_BYTES + B_BYTES);
         unsigned char* lb = la + A_BYTES;
+        if constexpr (Prob::A_DMA) {
+            const srd_t sa = p.a_srd(cc);
 #pragma unroll
-        for (int i = 0; i < 2 * MI; ++i) *(uint4*)(la + lds_off64(r0 + 32 * i, c8)) = ra[i];
+            for (int j = 0; j < NA; ++j)
+                buf_load16_lds(sa, p.a_voff(cc, rc[j], tc8[j]), la + (wave + 4 * j) * 1024);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(uint4*)(lb + lds_off64(r0 + 32 * i, c8)) = rb[i];
+            for (int j = 0; j < NA; ++j) ra[j] = p.load_a(cc, rc[j], tc8[j]);
+        }
+        const srd_t sb = p.b_srd(cc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            buf_load16_lds(sb, p.b_voff(cc, n0 + trow[j], tc8[j]), lb + (wave + 4 * j) * 1024);
+    };
+    auto write_a = [&](int buf) {
+        if constexpr (!Prob::A_DMA) {
+            unsigned char* la = lds + buf * (A_BYTES + B_BYTES);
+#pragma unroll
+            for (int j = 0; j < NA; ++j) *(uint4*)(la + (wave + 4 * j) * 1024 + lane * 16) = ra[j];
+        }
     };
 
     f32x16 acc[MI][2];
@@ -113,12 +165,12 @@ __device__ __forceinline__ void gemm128_body(const Prob& p, int tile_m, int tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    gload(0);
-    lwrite(0);
+    stage(0, 0);
+    write_a(0);
     __syncthreads();
     for (int q = 0; q < nq; ++q) {
         const bool more = (q + 1 < nq);
-        if (more) gload(q + 1);
+        if (more) stage(q + 1, (q + 1) & 1);
         const unsigned char* la = lds + (q & 1) * (A_BYTES + B_BYTES);
         const unsigned char* lb = la + A_BYTES;
 #pragma unroll
@@ -135,8 +187,8 @@ __device__ __forceinline__ void gemm128_body(const Prob& p, int tile_m, int tile
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma32(af[mi], bfr[ni], acc[mi][ni]);
         }
-        if (more) lwrite((q + 1) & 1);
-        __syncthreads();
+        if (more) write_a((q + 1) & 1);
+        __syncthreads();   // drains the LDS-DMA of chunk q+1 (vmcnt) and fences the buffer swap
     }
     p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
 }

@@ -7,62 +7,79 @@
 // Data layout: flow state = two fp32 planes [M][Ch] (even / odd samples),
 // hidden activations bf16 [M][256], conditioning = two bf16 planes [M][cin].
 #include "common.h"
+#include "gemm_ring.h"
 #include "fwn_internal.h"
 
 // ---------------------------------------------------------------------------
 // Problem descriptors for gemm128_body
 // ---------------------------------------------------------------------------
 struct RowCtxT {
-    int row;   // flattened row index b*Ti + t
+    int row;   // flattened row index b*Ti + t (may be >= M in the last tile)
     int t;     // position inside the clip (row % Ti), for zero padding at clip edges
 };
 
 // ---- front conv: h0 = ReLU(conv_k3(actnorm(x_a)) + bias), modules.py:164-165 -------------
+// The fp32 flow state enters the bf16 MFMA as a hi/lo pair (x = hi + lo, both bf16) so the
+// network input carries ~16 mantissa bits: K is traversed twice, once per half, against the
+// same weights.  K index inside a half: k = tap*Ch + tau.
 struct FrontProb {
+    static constexpr bool A_DMA = false;
     const float* xa;      // plane [M][Ch] fp32
     const float* an;      // [4][Ch] (shift, scale, iscale, logs3) of the a-plane, natural order
-    const bf16* W;        // [256][kpad], k = tap*Ch + tau
+    const bf16* W;        // [256][kpad]
     const float* bias;    // [256]
     bf16* hout;           // [M][256]
     int M, Ti, Ch, chlog, kpad, apply_an;
     typedef RowCtxT RowCtx;
-    struct ChunkCtx { int k0; const bf16* b; };
-    __device__ int nchunks() const { return kpad / FWN_BK; }
+    struct ChunkCtx { int k0; int lo; };
+    __device__ int nchunks() const { return 2 * (kpad / FWN_BK); }
     __device__ RowCtx row_ctx(int row) const { return RowCtx{row, row % Ti}; }
-    __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{q * FWN_BK, W + q * FWN_BK}; }
-    __device__ float norm(float x, int tau) const {
-        return apply_an ? (x + an[tau]) * an[Ch + tau] : x;
+    __device__ ChunkCtx chunk_ctx(int q) const {
+        const int nk = kpad / FWN_BK;
+        const int lo = q >= nk;
+        return ChunkCtx{(q - lo * nk) * FWN_BK, lo};
+    }
+    __device__ float fetch(const RowCtx& rc, int k) const {
+        // branch-free: clamp the address, select the value
+        const int tap = k >> chlog, tau = k & (Ch - 1);
+        const int tt = rc.t + tap - 1;
+        const bool ok = rc.row < M && k < 3 * Ch && (unsigned)tt < (unsigned)Ti;
+        const int srow = ok ? rc.row + tap - 1 : 0;
+        float v = xa[(size_t)srow * Ch + tau];
+        if (apply_an) v = (v + an[tau]) * an[Ch + tau];
+        return ok ? v : 0.0f;
     }
     __device__ uint4 load_a(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
         const int k8 = cc.k0 + c8 * 8;
-        Pack16 out;
-        out.u = zero16();
-        if (rc.row >= M || k8 >= 3 * Ch) return out.u;
+        float f[8];
         if (Ch >= 8) {
             const int tap = k8 >> chlog, tau0 = k8 & (Ch - 1);
             const int tt = rc.t + tap - 1;
-            if ((unsigned)tt >= (unsigned)Ti) return out.u;
-            const float* src = xa + (size_t)(rc.row + tap - 1) * Ch + tau0;
+            const bool ok = rc.row < M && k8 < 3 * Ch && (unsigned)tt < (unsigned)Ti;
+            const float* src = xa + (size_t)(ok ? rc.row + tap - 1 : 0) * Ch + (ok ? tau0 : 0);
             const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
-            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) out.e[e] = (bf16)norm(f[e], tau0 + e);
-        } else {
+            const float g[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int k = k8 + e;
-                const int tap = k >> chlog, tau = k & (Ch - 1);
-                const int tt = rc.t + tap - 1;
-                float v = 0.0f;
-                if (k < 3 * Ch && (unsigned)tt < (unsigned)Ti)
-                    v = norm(xa[(size_t)(rc.row + tap - 1) * Ch + tau], tau);
-                out.e[e] = (bf16)v;
+                const int tau = ok ? tau0 + e : e;
+                const float v = apply_an ? (g[e] + an[tau]) * an[Ch + tau] : g[e];
+                f[e] = ok ? v : 0.0f;
             }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fetch(rc, k8 + e);
+        }
+        Pack16 out;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bf16 hi = (bf16)f[e];
+            out.e[e] = cc.lo ? (bf16)(f[e] - (float)hi) : hi;
         }
         return out.u;
     }
-    __device__ uint4 load_b(const ChunkCtx& cc, int n, int c8) const {
-        return *(const uint4*)(cc.b + (size_t)n * kpad + c8 * 8);
+    __device__ srd_t b_srd(const ChunkCtx&) const { return make_srd(W, (uint32_t)(256u * kpad * 2u)); }
+    __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
+        return (uint32_t)(n * kpad + cc.k0 + c8 * 8) * 2u;
     }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
@@ -86,6 +103,8 @@ struct FrontProb {
 // K segments: 3 dilated taps over h (K = 3*256) then the 1x1 conditioning conv over c_a
 // (K = cin), or a precomputed conditioning projection P added in the epilogue.
 struct GateProb {
+    static constexpr bool A_DMA = true;
+    static constexpr bool ALLOW_256 = true;
     const bf16* h;        // [M][256]
     const bf16* ca;       // [M][cin] or nullptr
     const float* P;       // [M][512] packed-N order, or nullptr
@@ -95,25 +114,33 @@ struct GateProb {
     bf16* o;              // [M][256]
     int M, Ti, dil, cin, kcpad;
     typedef RowCtxT RowCtx;
-    struct ChunkCtx { const bf16* a; const bf16* b; int lda, ldb, shift, kvalid; };
-    __device__ int nchunks() const { return 12 + (ca ? kcpad / FWN_BK : 0); }
+    struct ChunkCtx { int cond, acol, bcol, shift, kvalid; };
+    template <int BK> __device__ int nchunks() const { return (3 * FWN_HID + (ca ? kcpad : 0)) / BK; }
     __device__ RowCtx row_ctx(int row) const { return RowCtx{row, row % Ti}; }
-    __device__ ChunkCtx chunk_ctx(int q) const {
-        if (q < 12) {
-            const int tap = q >> 2, kc = q & 3;
-            return ChunkCtx{h + kc * FWN_BK, Wd + tap * FWN_HID + kc * FWN_BK, FWN_HID, 3 * FWN_HID,
-                            (tap - 1) * dil, FWN_BK};
+    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const {
+        constexpr int CPT = FWN_HID / BK;          // chunks per tap
+        if (q < 3 * CPT) {
+            const int tap = q / CPT, kc = q % CPT;
+            return ChunkCtx{0, kc * BK, tap * FWN_HID + kc * BK, (tap - 1) * dil, BK};
         }
-        const int qc = q - 12;
-        return ChunkCtx{ca + qc * FWN_BK, Wc + qc * FWN_BK, cin, kcpad, 0, cin - qc * FWN_BK};
+        const int qc = q - 3 * CPT;
+        return ChunkCtx{1, qc * BK, qc * BK, 0, cin - qc * BK};
     }
-    __device__ uint4 load_a(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
+    __device__ srd_t a_srd(const ChunkCtx& cc) const {
+        return cc.cond ? make_srd(ca, (uint32_t)((size_t)M * cin * 2)) : make_srd(h, (uint32_t)((size_t)M * FWN_HID * 2));
+    }
+    __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
         const bool ok = rc.row < M && (unsigned)(rc.t + cc.shift) < (unsigned)Ti && c8 * 8 < cc.kvalid;
-        if (!ok) return zero16();
-        return *(const uint4*)(cc.a + (size_t)(rc.row + cc.shift) * cc.lda + c8 * 8);
+        const int lda = cc.cond ? cin : FWN_HID;
+        const uint32_t off = (uint32_t)((rc.row + cc.shift) * lda + cc.acol + c8 * 8) * 2u;
+        return ok ? off : FWN_OOB;
     }
-    __device__ uint4 load_b(const ChunkCtx& cc, int n, int c8) const {
-        return *(const uint4*)(cc.b + (size_t)n * cc.ldb + c8 * 8);
+    __device__ srd_t b_srd(const ChunkCtx& cc) const {
+        return cc.cond ? make_srd(Wc, (uint32_t)(512u * kcpad * 2u)) : make_srd(Wd, 512u * 768u * 2u);
+    }
+    __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
+        const int ldb = cc.cond ? kcpad : 3 * FWN_HID;
+        return (uint32_t)(n * ldb + cc.bcol + c8 * 8) * 2u;
     }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
@@ -123,24 +150,28 @@ struct GateProb {
         const int ch = (ncol0 >> 7) * 64 + ((ncol0 >> 6) & 1) * 32 + lr;
         const float bfv = bias[ncol0 + lr], bgv = bias[ncol0 + 32 + lr];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi) {
+            float pf[16], pg[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {   // unconditional (clamped) loads: no branch per element
+                const int row = min(mrow0 + mi * 32 + acc_row(r, lane), M - 1);
+                pf[r] = P ? P[(size_t)row * 512 + ncol0 + lr] : 0.0f;
+                pg[r] = P ? P[(size_t)row * 512 + ncol0 + 32 + lr] : 0.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mrow0 + mi * 32 + acc_row(r, lane);
-                if (row < M) {
-                    float f = acc[mi][0][r] + bfv, g = acc[mi][1][r] + bgv;
-                    if (P) {
-                        f += P[(size_t)row * 512 + ncol0 + lr];
-                        g += P[(size_t)row * 512 + ncol0 + 32 + lr];
-                    }
-                    o[(size_t)row * FWN_HID + ch] = (bf16)(fast_tanh(f) * fast_sigmoid(g));
-                }
+                const float f = acc[mi][0][r] + bfv + pf[r], g = acc[mi][1][r] + bgv + pg[r];
+                if (row < M) o[(size_t)row * FWN_HID + ch] = (bf16)gated_unit(f, g);
             }
+        }
     }
 };
 
 // ---- residual 1x1: h' = (h + res_conv(o)) * sqrt(0.5), modules.py:126-128 ------------------
 struct ResProb {
+    static constexpr bool A_DMA = true;
+    static constexpr bool ALLOW_256 = false;   // 4 row tiles of residual reads would spill at 256 VGPRs
     const bf16* o;        // [M][256]
     const bf16* hin;      // [M][256]
     const bf16* W;        // [256][256]
@@ -149,15 +180,16 @@ struct ResProb {
     int M;
     struct RowCtx { int row; };
     struct ChunkCtx { int k0; };
-    __device__ int nchunks() const { return FWN_HID / FWN_BK; }
+    template <int BK> __device__ int nchunks() const { return FWN_HID / BK; }
     __device__ RowCtx row_ctx(int row) const { return RowCtx{row}; }
-    __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{q * FWN_BK}; }
-    __device__ uint4 load_a(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
-        if (rc.row >= M) return zero16();
-        return *(const uint4*)(o + (size_t)rc.row * FWN_HID + cc.k0 + c8 * 8);
+    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{q * BK}; }
+    __device__ srd_t a_srd(const ChunkCtx&) const { return make_srd(o, (uint32_t)((size_t)M * FWN_HID * 2)); }
+    __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
+        return rc.row < M ? (uint32_t)(rc.row * FWN_HID + cc.k0 + c8 * 8) * 2u : FWN_OOB;
     }
-    __device__ uint4 load_b(const ChunkCtx& cc, int n, int c8) const {
-        return *(const uint4*)(W + (size_t)n * FWN_HID + cc.k0 + c8 * 8);
+    __device__ srd_t b_srd(const ChunkCtx&) const { return make_srd(W, 256u * 256u * 2u); }
+    __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
+        return (uint32_t)(n * FWN_HID + cc.k0 + c8 * 8) * 2u;
     }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
@@ -167,36 +199,43 @@ struct ResProb {
             const int col = ncol0 + ni * 32 + lr;
             const float b = bias[col];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+                float hv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    hv[r] = (float)hin[(size_t)min(mrow0 + mi * 32 + acc_row(r, lane), M - 1) * FWN_HID + col];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mrow0 + mi * 32 + acc_row(r, lane);
-                    if (row < M) {
-                        const size_t idx = (size_t)row * FWN_HID + col;
-                        hout[idx] = (bf16)(((float)hin[idx] + acc[mi][ni][r] + b) * 0.70710678118654752f);
-                    }
+                    if (row < M)
+                        hout[(size_t)row * FWN_HID + col] = (bf16)((hv[r] + acc[mi][ni][r] + b) * 0.70710678118654752f);
                 }
+            }
         }
     }
 };
 
 // ---- conditioning projection hoisted out of the flow chain: P = c_a @ Wc -------------------
 struct CondProb {
+    static constexpr bool A_DMA = true;
+    static constexpr bool ALLOW_256 = false;
     const bf16* ca;       // [M][cin]
     const bf16* Wc;       // [512][kcpad]
     float* P;             // [M][512]
     int M, cin, kcpad;
     struct RowCtx { int row; };
     struct ChunkCtx { int k0; };
-    __device__ int nchunks() const { return kcpad / FWN_BK; }
+    template <int BK> __device__ int nchunks() const { return kcpad / BK; }
     __device__ RowCtx row_ctx(int row) const { return RowCtx{row}; }
-    __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{q * FWN_BK}; }
-    __device__ uint4 load_a(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
-        if (rc.row >= M || cc.k0 + c8 * 8 >= cin) return zero16();
-        return *(const uint4*)(ca + (size_t)rc.row * cin + cc.k0 + c8 * 8);
+    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{q * BK}; }
+    __device__ srd_t a_srd(const ChunkCtx&) const { return make_srd(ca, (uint32_t)((size_t)M * cin * 2)); }
+    __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
+        const bool ok = rc.row < M && cc.k0 + c8 * 8 < cin;
+        return ok ? (uint32_t)(rc.row * cin + cc.k0 + c8 * 8) * 2u : FWN_OOB;
     }
-    __device__ uint4 load_b(const ChunkCtx& cc, int n, int c8) const {
-        return *(const uint4*)(Wc + (size_t)n * kcpad + cc.k0 + c8 * 8);
+    __device__ srd_t b_srd(const ChunkCtx&) const { return make_srd(Wc, (uint32_t)(512u * kcpad * 2u)); }
+    __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
+        return (uint32_t)(n * kcpad + cc.k0 + c8 * 8) * 2u;
     }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
@@ -219,6 +258,13 @@ __global__ __launch_bounds__(256) void gemm128_kernel(Prob p, int ntn) {
     gemm128_body<MI, Prob>(p, wg / ntn, wg % ntn);
 }
 
+// Ring-pipelined GEMM: tile BM x BN, WM x WN waves, K-chunk BK, ring depth D.
+template <int BM, int BN, int WM, int WN, int BK, int D, class Prob>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(Prob p, int ntn) {
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    gemm_ring_body<BM, BN, WM, WN, BK, D, Prob>(p, wg / ntn, wg % ntn);
+}
+
 // Batched conditioning projections: blockIdx.y selects (flow, layer) of one parity group.
 struct CondBatch {
     const bf16* ca;
@@ -229,28 +275,36 @@ struct CondBatch {
     int flow0, flow_step, L;
     int M, cin, kcpad;
 };
-template <int MI>
-__global__ __launch_bounds__(256) void cond_batch_kernel(CondBatch cb) {
+template <int BM, int BN, int WM, int WN, int BK, int D>
+__global__ __launch_bounds__(64 * WM * WN) void cond_batch_kernel(CondBatch cb, int ntn) {
     const int z = blockIdx.y;
     const int zi = (cb.flow0 + (z / cb.L) * cb.flow_step) * cb.L + (z % cb.L);
     CondProb p{cb.ca, cb.Wc_base + (size_t)zi * cb.w_stride, cb.P_base + (size_t)zi * cb.p_stride,
                cb.M, cb.cin, cb.kcpad};
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    gemm128_body<MI, CondProb>(p, wg >> 2, wg & 3);
+    gemm_ring_body<BM, BN, WM, WN, BK, D, CondProb>(p, wg / ntn, wg % ntn);
 }
 
 // ---------------------------------------------------------------------------
-// Tail: skip-sum GEMM -> ReLU -> final 1x1 -> ReLU -> ZeroConv1d -> coupling.
-// One workgroup owns 64 rows and all 256 hidden channels, so the three GEMMs chain
-// through LDS without touching HBM.  modules.py:175-180,51-56; model.py:124-141,146-161.
+// Tail: skip-sum GEMM -> ReLU -> final 1x1 -> ReLU -> ZeroConv1d -> coupling + ActNorm.
+// modules.py:175-180,51-56; model.py:86-102,124-141,146-161.
+//
+// Weight-streaming, register-chained: each wave owns 32 time rows and ALL 256 hidden
+// channels.  The three GEMMs are computed transposed (channels on the accumulator
+// registers, time on the lanes), so the fp32 accumulator tile of one GEMM, after bias +
+// ReLU + bf16 packing, IS the B operand of the next MFMA chain: no LDS round trip.
+// Weights stream through a 2 x 32 KB LDS ring by LDS-DMA, shared by the NW waves of the
+// workgroup; the o_l rows are read once, straight into registers (no reuse across waves).
+// Wfinal / Wzero are packed with their K axis in accumulator-register order
+// (packing.acc_k_perm) so operand element j of lane half h meets the matching k.
 // ---------------------------------------------------------------------------
 struct TailArgs {
     const bf16* o;        // [L][M][256]
     const bf16* Ws;       // [256][L*256]
     const float* bs;      // [256]  (sum of the L skip biases)
-    const bf16* Wf;       // [256][256]
+    const bf16* Wf;       // [256][256]   K in acc order
     const float* bfin;    // [256]
-    const bf16* Wz;       // [npt*64][256], pair tiles: 32 log_s rows then 32 t rows
+    const bf16* Wz;       // [npt*64][256] K in acc order; pair tiles: 32 log_s rows then 32 t rows
     const float* bz;      // [npt*64]
     const float* ez;      // [npt*64]  exp(3*scale)
     const float* an;      // [2][4][Ch]: (a|b) x (shift, scale, iscale, logs3)
@@ -261,174 +315,242 @@ struct TailArgs {
     int L, M, Ch, npt, inverse;
 };
 
-__global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
-    constexpr int A_BYTES = 64 * 128, B_BYTES = 256 * 128, SU_BYTES = 64 * 512;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[A_BYTES + B_BYTES + SU_BYTES + 16];
-    unsigned char* la = lds;
-    unsigned char* lb = lds + A_BYTES;
-    unsigned char* su = lds + A_BYTES + B_BYTES;
-    float* red = (float*)(lds + A_BYTES + B_BYTES + SU_BYTES);
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
+    constexpr int W_BYTES = 256 * 128;               // weight chunk: [256 rows][64 k] bf16
+    constexpr int O_BYTES = 32 * NW * 128;           // o tile of a phase-1 chunk: [32*NW rows][64 k]
+    constexpr int SLOT = W_BYTES + O_BYTES;
+    constexpr int D = 3;                             // ring slots: two chunks in flight + one in use
+    constexpr int PWW = 32 / NW, PWO = 4;            // DMA pieces per wave per chunk: weights, o rows
+    constexpr int CST = 2560 + 1024;                 // floats: bs | bfin | bz | ez | an[2][4][Ch<=128]
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT + CST * 4 + 64];
+    float* cst = (float*)(lds + D * SLOT);           // bs[256] bfin[256] bz[512] ez[512] an[1024]
+    float* red = cst + CST;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
-    const int c8 = tid & 7, r0 = tid >> 3;
-    const int m0 = blockIdx.x * 64;
+    const int m0 = blockIdx.x * (32 * NW);
+    const int row = m0 + wave * 32 + lr;             // this lane's time row
     const int KS = a.L * FWN_HID;
+    const int nq1 = a.L * 4, NC = nq1 + 8;
+    const int Ch = a.Ch;
 
-    f32x16 acc[2][2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-    };
-    uint4 ra[2], rb[8];
+    // constants -> LDS (ordinary loads, all retired before the first DMA is issued)
+    for (int i = tid; i < 256; i += 64 * NW) { cst[i] = a.bs[i]; cst[256 + i] = a.bfin[i]; }
+    for (int i = tid; i < a.npt * 64; i += 64 * NW) { cst[512 + i] = a.bz[i]; cst[1024 + i] = a.ez[i]; }
+    for (int i = tid; i < 8 * Ch; i += 64 * NW) cst[1536 + i] = a.an[i];
 
-    // ---------------- phase 1: S = ReLU([o_0 | o_1 | ..] @ Ws + bs) ----------------
-    auto gload1 = [&](int q) {
-        const int l = q >> 2, kc = q & 3;
+    // ---- ring: chunk c (weights, and in phase 1 the o rows) goes to slot c % 3 ----
+    int wrow[PWW], wc8[PWW], orow[PWO], oc8[PWO];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = m0 + r0 + 32 * i;
-            ra[i] = (row < a.M)
-                        ? *(const uint4*)(a.o + (size_t)l * a.o_stride + (size_t)row * FWN_HID + kc * FWN_BK + c8 * 8)
-                        : zero16();
-        }
+    for (int j = 0; j < PWW; ++j) {
+        wrow[j] = 8 * (wave + NW * j) + (lane >> 3);
+        wc8[j] = (lane & 7) ^ ((wrow[j] >> 1) & 7);
+    }
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            rb[i] = *(const uint4*)(a.Ws + (size_t)(r0 + 32 * i) * KS + q * FWN_BK + c8 * 8);
+    for (int j = 0; j < PWO; ++j) {
+        orow[j] = 8 * (wave + NW * j) + (lane >> 3);
+        oc8[j] = (lane & 7) ^ ((orow[j] >> 1) & 7);
+    }
+    const srd_t srd_s = make_srd(a.Ws, (uint32_t)(256u * KS * 2u));
+    const srd_t srd_f = make_srd(a.Wf, 256u * 256u * 2u);
+    const srd_t srd_z = make_srd(a.Wz, (uint32_t)(a.npt * 64u * 256u * 2u));
+    const srd_t srd_o = make_srd(a.o, (uint32_t)((size_t)a.L * a.o_stride * 2));
+    // Each chunk's DMA pieces are issued in 4 parts (one per k-step of the chunk being multiplied)
+    // so the issue cost hides under MFMAs; part < 0 issues the whole chunk (prologue).
+    auto issue_w = [&](const srd_t s, int ld, int col, int c, int part) {
+        unsigned char* dst = lds + (c % D) * SLOT;
+        constexpr int PP = PWW / 4;
+#pragma unroll
+        for (int j = 0; j < PWW; ++j)
+            if (part < 0 || j / PP == part)
+                buf_load16_lds(s, (uint32_t)(wrow[j] * ld + col + wc8[j] * 8) * 2u, dst + (wave + NW * j) * 1024);
     };
-    auto lwrite = [&](bool with_a) {
-        if (with_a) {
+    auto issue1 = [&](int q, int part) {              // phase 1: Ws chunk q + o rows of (layer q/4, k (q%4)*64)
+        issue_w(srd_s, KS, q * FWN_BK, q, part);
+        unsigned char* dst = lds + (q % D) * SLOT + W_BYTES;
+        const uint32_t base = (uint32_t)((q >> 2) * a.o_stride + (q & 3) * FWN_BK);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) *(uint4*)(la + lds_off64(r0 + 32 * i, c8)) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *(uint4*)(lb + lds_off64(r0 + 32 * i, c8)) = rb[i];
+        for (int j = 0; j < PWO; ++j)
+            if (part < 0 || j == part) {
+                const int r = m0 + orow[j];
+                const uint32_t off = (base + (uint32_t)(r * FWN_HID + oc8[j] * 8)) * 2u;
+                buf_load16_lds(srd_o, r < a.M ? off : FWN_OOB, dst + (wave + NW * j) * 1024);
+            }
     };
-    zero_acc();
-    const int nq1 = a.L * 4;
-    gload1(0);
-    for (int q = 0; q < nq1; ++q) {
-        lwrite(true);
-        __syncthreads();
-        if (q + 1 < nq1) gload1(q + 1);
+    auto issue2 = [&](int kc, int part) { issue_w(srd_f, FWN_HID, kc * FWN_BK, nq1 + kc, part); };
+    auto issue3 = [&](int kc, int part) { issue_w(srd_z, FWN_HID, kc * FWN_BK, nq1 + 4 + kc, part); };
+    // refill part `part` of chunk c2 (the slot freed by the barrier of chunk c2 - 2)
+    auto refill = [&](int c2, int part) {
+        if (FWN_ABL >= 2) return;
+        if (c2 < nq1) issue1(c2, part);
+        else if (c2 < nq1 + 4) issue2(c2 - nq1, part);
+        else if (c2 < NC) issue3(c2 - nq1 - 4, part);
+    };
+    // wait for chunk c (leave chunk c+1 in flight) and cross the barrier
+    auto step = [&](int c) {
+        if (FWN_ABL >= 2) { if (c == 0) FWN_WAIT_VMCNT(0); __builtin_amdgcn_s_barrier(); return; }
+        if (c + 1 >= NC) FWN_WAIT_VMCNT(0);
+        else if (c + 1 < nq1) FWN_WAIT_VMCNT(PWW + PWO);
+        else FWN_WAIT_VMCNT(PWW);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // Fragment of 32-row tile `t`, k-step kk of a 64-wide chunk: the swizzle depends on the row only
+    // through lr, so tile t is an immediate offset t*4096.
+    int wfrag[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wfrag[kk] = lr * 128 + (((kk * 2 + lh) ^ ((lr >> 1) & 7)) << 4);
+#define WFRAG(wb, t, kk) (*(const bf16x8*)((wb) + wfrag[kk] + (t) * 4096))
+
+    f32x16 acc[8];
+    auto init_acc = [&](const float* bias) {         // acc[ct][r] = bias[ct*32 + acc_row(r)]
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = *(const float4*)(bias + ct * 32 + 8 * g + 4 * lh);
+                acc[ct][4 * g + 0] = v.x; acc[ct][4 * g + 1] = v.y; acc[ct][4 * g + 2] = v.z; acc[ct][4 * g + 3] = v.w;
+            }
+    };
+    bf16x8 pk[8][2];                                  // packed activations: B operands of the next chain
+    auto pack_relu = [&]() {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                Pack16 t;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t.e[j] = (bf16)fmaxf(acc[ct][8 * s + j], 0.0f);
+                pk[ct][s] = t.v;
+            }
+    };
+    // One k-step: acc[t] += W-tile(t) x B for t < NT, with the weight fragments read one step ahead.
+    bf16x8 wf[2][8];
+    auto ldw = [&](const unsigned char* wb, int kk, int s) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) wf[s][t] = WFRAG(wb, t, kk);
+    };
+
+    issue1(0, -1);
+    issue1(1, -1);
+    step(0);
+    init_acc(cst);
+
+    // ---------------- phase 1: S^T = Ws @ [o_0 | o_1 | ..]^T + bs ----------------
+    for (int c = 0; c < nq1; ++c) {
+        if (c > 0) step(c);
+        if (FWN_ABL == 1) { refill(c + 2, -1); continue; }
+        const unsigned char* wb = lds + (c % D) * SLOT;
+        const unsigned char* ob = wb + W_BYTES + wave * 4096;
+        ldw(wb, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[2], bfr[2];
+            const bf16x8 b = *(const bf16x8*)(ob + wfrag[kk]);
+            if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);       // keep the next step's reads ahead of these MFMAs
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = *(const bf16x8*)(la + lds_off64(mi * 32 + lr, kk * 2 + lh));
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                bfr[ni] = *(const bf16x8*)(lb + lds_off64(wave * 64 + ni * 32 + lr, kk * 2 + lh));
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma32(af[mi], bfr[ni], acc[mi][ni]);
+            for (int ct = 0; ct < 8; ++ct) {
+                acc[ct] = mfma32(wf[kk & 1][ct], b, acc[ct]);
+                if (ct == 0) refill(c + 2, kk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
     }
-    auto store_su = [&](const float* bias) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = wave * 64 + ni * 32 + lr;
-            const float b = bias[col];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mi * 32 + acc_row(r, lane);
-                    *(bf16*)(su + lds_off256(row, col >> 3) + (col & 7) * 2) =
-                        (bf16)fmaxf(acc[mi][ni][r] + b, 0.0f);
-                }
-        }
-    };
-    store_su(a.bs);
+    pack_relu();
+    init_acc(cst + 256);
 
-    // ---------------- phase 2: U = ReLU(S @ Wf + bfin) ----------------
-    auto gload2 = [&](int q) {
+    // ---------------- phase 2: U^T = Wf @ S^T + bfin ----------------
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            rb[i] = *(const uint4*)(a.Wf + (size_t)(r0 + 32 * i) * FWN_HID + q * FWN_BK + c8 * 8);
-    };
-    zero_acc();
-    gload2(0);
-    for (int q = 0; q < 4; ++q) {
-        lwrite(false);
-        __syncthreads();   // also orders the S stores above before the first fragment read
-        if (q + 1 < 4) gload2(q + 1);
+    for (int kc = 0; kc < 4; ++kc) {
+        step(nq1 + kc);
+        if (FWN_ABL == 1) { refill(nq1 + kc + 2, -1); continue; }
+        const unsigned char* wb = lds + ((nq1 + kc) % D) * SLOT;
+        ldw(wb, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[2], bfr[2];
+            if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                af[mi] = *(const bf16x8*)(su + lds_off256(mi * 32 + lr, q * 8 + kk * 2 + lh));
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                bfr[ni] = *(const bf16x8*)(lb + lds_off64(wave * 64 + ni * 32 + lr, kk * 2 + lh));
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma32(af[mi], bfr[ni], acc[mi][ni]);
+            for (int ot = 0; ot < 8; ++ot) {
+                acc[ot] = mfma32(wf[kk & 1][ot], pk[2 * kc + (kk >> 1)][kk & 1], acc[ot]);
+                if (ot == 0) refill(nq1 + kc + 2, kk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();   // after the last chunk: every wave is done reading S
     }
-    store_su(a.bfin);
-    __syncthreads();
+    pack_relu();
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
 
-    // ---------------- phase 3: ZeroConv1d + affine coupling ----------------
-    const float* an_a = a.an;
-    const float* an_b = a.an + 4 * a.Ch;
+    // ---------------- phase 3: [log_s | t]^T = Wz @ U^T ----------------
+    const int ntz = 2 * a.npt;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        step(nq1 + 4 + kc);
+        refill(nq1 + 4 + kc + 2, -1);
+        if (FWN_ABL == 1) continue;
+        const unsigned char* wb = lds + ((nq1 + 4 + kc) % D) * SLOT;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int tz = 0; tz < 8; ++tz)
+                if (tz < ntz) acc[tz] = mfma32(WFRAG(wb, tz, kk), pk[2 * kc + (kk >> 1)][kk & 1], acc[tz]);
+    }
+
+    // ---------------- affine coupling + ActNorm on the b plane (branch-free loads) ----------------
+    const float* bzl = cst + 512;
+    const float* ezl = cst + 1024;
+    const float* an_a = cst + 1536;
+    const float* an_b = an_a + 4 * Ch;
     float lsum = 0.0f;
-    for (int job = wave; job < 2 * a.npt; job += 4) {
-        const int mt = job & 1, pt = job >> 1;
-        f32x16 als, at;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { als[r] = 0.0f; at[r] = 0.0f; }
-        const bf16* wls = a.Wz + (size_t)(pt * 64 + lr) * FWN_HID + lh * 8;
-        const bf16* wt = wls + 32 * FWN_HID;
-#pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const bf16x8 af = *(const bf16x8*)(su + lds_off256(mt * 32 + lr, ks * 2 + lh));
-            Pack16 b0, b1;
-            b0.u = *(const uint4*)(wls + ks * 16);
-            b1.u = *(const uint4*)(wt + ks * 16);
-            als = mfma32(af, b0.v, als);
-            at = mfma32(af, b1.v, at);
-        }
-        const int tau = pt * 32 + lr;
-        if (tau < a.Ch) {
-            const int nls = pt * 64 + lr, nt = nls + 32;
-            const float bls = a.bz[nls], els = a.ez[nls], bt = a.bz[nt], et = a.ez[nt];
-            const float shb = an_b[tau], scb = an_b[a.Ch + tau], iscb = an_b[2 * a.Ch + tau];
-            const float l3 = an_a[3 * a.Ch + tau] + an_b[3 * a.Ch + tau];
+    for (int pt = 0; pt < 4; ++pt) {
+        if (pt < a.npt) {
+            float xv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + mt * 32 + acc_row(r, lane);
-                if (row < a.M) {
-                    const float ls = (als[r] + bls) * els;
-                    const float t = (at[r] + bt) * et;
-                    float* px = a.xb + (size_t)row * a.Ch + tau;
-                    if (!a.inverse) {
-                        const float yb = (*px + shb) * scb;           // ActNorm (model.py:86-94)
-                        *px = (yb - t) * expf(-ls);                   // model.py:134
-                        lsum += l3 - ls;                              // model.py:135 + :80
-                    } else {
-                        const float yb = *px * expf(ls) + t;          // model.py:156
-                        *px = yb * iscb - shb;                        // ActNorm^-1 (model.py:97-102)
-                    }
+                const int tau = pt * 32 + acc_row(r, lane);
+                const bool ok = tau < Ch && row < a.M;
+                xv[r] = a.xb[ok ? (size_t)row * Ch + tau : 0];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = acc_row(r, lane);
+                const int tau = pt * 32 + j;
+                const bool ok = tau < Ch && row < a.M;
+                const int tc = ok ? tau : 0;
+                const int nls = pt * 64 + j, nt = nls + 32;
+                const float ls = (acc[2 * pt][r] + bzl[nls]) * ezl[nls];
+                const float t = (acc[2 * pt + 1][r] + bzl[nt]) * ezl[nt];
+                float outv;
+                if (!a.inverse) {
+                    const float yb = (xv[r] + an_b[tc]) * an_b[Ch + tc];              // ActNorm (model.py:86-94)
+                    outv = (yb - t) * expf(-ls);                                      // model.py:134
+                    lsum += ok ? (an_a[3 * Ch + tc] + an_b[3 * Ch + tc] - ls) : 0.0f;  // model.py:135 + :80
+                } else {
+                    const float yb = xv[r] * expf(ls) + t;                            // model.py:156
+                    outv = yb * an_b[2 * Ch + tc] - an_b[tc];                          // ActNorm^-1 (model.py:97-102)
                 }
+                if (ok) a.xb[(size_t)row * Ch + tau] = outv;
             }
         }
     }
     // a-plane: ActNorm only (the coupling passes in_a through unchanged).
-    for (int idx = tid; idx < 64 * a.Ch; idx += 256) {
-        const int row = m0 + idx / a.Ch, tau = idx % a.Ch;
-        if (row < a.M) {
-            float* px = a.xa + (size_t)row * a.Ch + tau;
-            *px = a.inverse ? (*px * an_a[2 * a.Ch + tau] - an_a[tau]) : ((*px + an_a[tau]) * an_a[a.Ch + tau]);
+    {
+        const int total = 32 * NW * Ch;
+        const int chmask = Ch - 1;
+#pragma unroll 4
+        for (int idx = tid; idx < total; idx += 64 * NW) {
+            const int tau = idx & chmask;
+            const size_t off = (size_t)m0 * Ch + idx;
+            const bool ok = off < (size_t)a.M * Ch;
+            const float v = a.xa[ok ? off : 0];
+            const float w = a.inverse ? (v * an_a[2 * Ch + tau] - an_a[tau]) : ((v + an_a[tau]) * an_a[Ch + tau]);
+            if (ok) a.xa[off] = w;
         }
     }
     if (a.partial) {
@@ -436,13 +558,19 @@ __global__ __launch_bounds__(256) void tail_kernel(TailArgs a) {
         for (int s = 32; s > 0; s >>= 1) lsum += __shfl_xor(lsum, s);
         if (lane == 0) red[wave] = lsum;
         __syncthreads();
-        if (tid == 0) a.partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) {
+            float t = 0.0f;
+            for (int w = 0; w < NW; ++w) t += red[w];
+            a.partial[blockIdx.x] = t;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
 // Host-side launchers (called from the C-ABI in api.hip)
 // ---------------------------------------------------------------------------
+int fwn_tail_rows(int M) { (void)M; return 128; }   // rows per tail workgroup (4 waves x 32 rows)
+
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 template <class Prob>
@@ -457,6 +585,28 @@ static void launch_gemm128(const Prob& p, int M, int ntn, hipStream_t st) {
     }
 }
 
+// Tile choice for the ring GEMMs: the largest tile that still yields about one workgroup per CU
+// (the chain of K-chunks inside a workgroup is serial, so fewer, fatter workgroups only pay while
+// every CU has one).  N = 64 * ncol64 output columns.
+#define RING_LAUNCH(BM, BN, WM, WN, BK, D)                                                          \
+    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, WM, WN, BK, D, Prob>),                             \
+                       dim3(((M + BM - 1) / BM) * (N / BN)), dim3(64 * WM * WN), 0, st, p, N / BN)
+template <class Prob>
+static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
+    const int CU = 256;
+    if (Prob::ALLOW_256 && N % 256 == 0 && ((M + 255) / 256) * (N / 256) >= CU * 3 / 4) {
+        RING_LAUNCH(256, 256, 2, 4, 64, 2);
+    } else if (N % 256 == 0 && ((M + 127) / 128) * (N / 256) >= CU * 3 / 4) {
+        RING_LAUNCH(128, 256, 2, 4, 64, 3);
+    } else if (((M + 127) / 128) * (N / 128) >= CU * 3 / 4) {
+        RING_LAUNCH(128, 128, 2, 2, 64, 3);
+    } else if (((M + 63) / 64) * (N / 128) >= CU * 3 / 4) {
+        RING_LAUNCH(64, 128, 2, 2, 64, 4);
+    } else {
+        RING_LAUNCH(64, 64, 2, 1, 64, 4);
+    }
+}
+
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const float* bias, void* hout,
                       int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st) {
     FrontProb p{xa, an_a, (const bf16*)W, bias, (bf16*)hout, M, Ti, Ch, ilog2(Ch), kpad, apply_an};
@@ -467,24 +617,26 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, hipStream_t st) {
     GateProb p{(const bf16*)h, (const bf16*)ca, P, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o,
                M, Ti, dil, cin, kcpad};
-    launch_gemm128(p, M, 4, st);
+    launch_ring(p, M, 512, st);
 }
 
 void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M,
                     hipStream_t st) {
     ResProb p{(const bf16*)o, (const bf16*)hin, (const bf16*)W, bias, (bf16*)hout, M};
-    launch_gemm128(p, M, 2, st);
+    launch_ring(p, M, 256, st);
 }
 
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
                      int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, hipStream_t st) {
     CondBatch cb{(const bf16*)ca, (const bf16*)Wc_base, P_base, w_stride, p_stride, flow0, flow_step, L,
                  M, cin, kcpad};
-    const int t128 = (M + 127) / 128 * 4;
-    if (t128 * nflow * L >= 512) {
-        hipLaunchKernelGGL((cond_batch_kernel<2>), dim3(t128, nflow * L), dim3(256), 0, st, cb);
+    const int nz = nflow * L;
+    if (((M + 127) / 128) * 4 * nz >= 192) {
+        hipLaunchKernelGGL((cond_batch_kernel<128, 128, 2, 2, 64, 3>), dim3(((M + 127) / 128) * 4, nz), dim3(256), 0,
+                           st, cb, 4);
     } else {
-        hipLaunchKernelGGL((cond_batch_kernel<1>), dim3((M + 63) / 64 * 4, nflow * L), dim3(256), 0, st, cb);
+        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nz), dim3(256), 0,
+                           st, cb, 4);
     }
 }
 
@@ -494,5 +646,5 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
                      hipStream_t st) {
     TailArgs a{(const bf16*)o, (const bf16*)Ws, bs, (const bf16*)Wf, bfin, (const bf16*)Wz, bz, ez, an,
                xa, xb, partial, o_stride, L, M, Ch, npt, inverse};
-    hipLaunchKernelGGL(tail_kernel, dim3((M + 63) / 64), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((tail_kernel<4>), dim3((M + 127) / 128), dim3(256), 0, st, a);
 }

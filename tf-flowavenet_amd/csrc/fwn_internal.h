@@ -15,6 +15,8 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
                      float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse,
                      hipStream_t st);
 
+int fwn_tail_rows(int M);   // rows per tail workgroup (sizes the log-det partial buffer)
+
 void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st);
 void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,
                      int k_dst, int n_dst, long ld_dst, void* out, hipStream_t st);

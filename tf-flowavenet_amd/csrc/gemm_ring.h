@@ -1,0 +1,178 @@
+// Deep-pipelined bf16 MFMA GEMM core for gfx950: LDS-DMA ring with counted vmcnt waits.
+//
+// Why a ring: on MI355X an LDS-DMA piece lands ~1.1-1.5 us after issue, and one CU only reaches
+// its L2->LDS rate (~66 GB/s) with ~100 KB in flight.  A workgroup that waits for its single
+// outstanding K-chunk every iteration (vmcnt(0) + barrier) therefore runs at one chunk per DMA
+// latency whatever the tile.  Here D ring slots hold D-1 chunks in flight; iteration q waits only
+// for chunk q (s_waitcnt vmcnt((D-2)*PW), PW = DMA pieces per wave per chunk), crosses ONE raw
+// s_barrier (which also proves every wave is done with slot (q-1)%D), re-issues chunk q+D-1 into
+// that slot and multiplies chunk q.  No ordinary VGPR-destination loads appear inside the loop
+// (hipcc would drain the DMA queue at their first use), and all LDS lives in one array.
+//
+// Tile: BM x BN, waves laid out WM x WN, wave tile (32*MI) x 64 with MI = BM/(32*WM); BN = 64*WN.
+// K-chunk BK = 32 or 64 bf16 (64- or 128-byte LDS rows, XOR-swizzled on the DMA source side).
+#pragma once
+#include "common.h"
+
+template <int BK>
+struct RingGeom {
+    static constexpr int RB = BK * 2;            // row bytes
+    static constexpr int PR = 1024 / RB;         // rows per 1-KiB DMA piece
+    static constexpr int CPR = RB / 16;          // 16-byte pieces per row
+    static constexpr int KS = BK / 16;           // MFMA k-steps per chunk
+    // byte offset of 16-byte piece c of row `row` in a [rows][BK] tile
+    static __device__ __forceinline__ int off(int row, int c) {
+        if constexpr (BK == 64) return row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        else return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+    }
+    // lane -> (row within piece, global 16-byte piece index it must fetch for its linear LDS slot)
+    static __device__ __forceinline__ int piece_row(int lane) { return lane / CPR; }
+    static __device__ __forceinline__ int piece_c(int lane, int row) {
+        if constexpr (BK == 64) return (lane & 7) ^ ((row >> 1) & 7);
+        else return (lane & 3) ^ ((row >> 2) & 3);
+    }
+};
+
+// Developer ablation switch (tools/bench_gemm.hip builds with -DFWN_ABL=n; the product is 0):
+//   1 = no MFMA/ds_read (DMA + waits + barriers only), 2 = DMA issued only in the prologue
+//   (MFMA on stale LDS), 3 = no DMA at all and no waits.
+#ifndef FWN_ABL
+#define FWN_ABL 0
+#endif
+#ifndef FWN_SETPRIO
+#define FWN_SETPRIO 0
+#endif
+
+#define FWN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le(int pending_chunks) {
+    // pending_chunks (wave-uniform) in {0, 1, .., MAXC}: wait until at most pending*N DMAs remain
+    if (pending_chunks >= 3) FWN_WAIT_VMCNT(3 * N);
+    else if (pending_chunks == 2) FWN_WAIT_VMCNT(2 * N);
+    else if (pending_chunks == 1) FWN_WAIT_VMCNT(N);
+    else FWN_WAIT_VMCNT(0);
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int D, class Prob>
+__device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int tile_n) {
+    using G = RingGeom<BK>;
+    constexpr int NWV = WM * WN;
+    constexpr int MI = BM / (32 * WM);
+    static_assert(BN == 64 * WN, "wave tile is 64 columns wide");
+    static_assert(MI >= 1 && BM == 32 * MI * WM, "bad BM");
+    constexpr int A_BYTES = BM * G::RB, B_BYTES = BN * G::RB, SLOT = A_BYTES + B_BYTES;
+    constexpr int PA = BM / (G::PR * NWV);       // A pieces per wave per chunk
+    constexpr int PB = BN / (G::PR * NWV);       // B pieces per wave per chunk
+    static_assert(PA * G::PR * NWV == BM && PB * G::PR * NWV == BN, "pieces must divide evenly over waves");
+    constexpr int PW = PA + PB;
+    static_assert(D >= 2 && D <= 5, "ring depth");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // DMA piece j of this wave: tile rows [PR*(wave + NWV*j), +PR)
+    int arow[PA], ac[PA], brow[PB], bc[PB];
+    typename Prob::RowCtx rc[PA];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        arow[j] = G::PR * (wave + NWV * j) + G::piece_row(lane);
+        ac[j] = G::piece_c(lane, arow[j]);
+        rc[j] = p.row_ctx(m0 + arow[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        brow[j] = G::PR * (wave + NWV * j) + G::piece_row(lane);
+        bc[j] = G::piece_c(lane, brow[j]);
+    }
+    const int nq = p.template nchunks<BK>();
+
+    // piece j (0..PW-1) of chunk q: A pieces first, then B pieces
+    auto issue_piece = [&](const typename Prob::ChunkCtx& cc, int q, int j) {
+        unsigned char* la = lds + (q % D) * SLOT;
+        if (j < PA) {
+            buf_load16_lds(p.a_srd(cc), p.a_voff(cc, rc[j < PA ? j : 0], ac[j < PA ? j : 0]),
+                           la + (wave + NWV * j) * 1024);
+        } else {
+            const int jb = j - PA;
+            buf_load16_lds(p.b_srd(cc), p.b_voff(cc, n0 + brow[jb < PB ? jb : 0], bc[jb < PB ? jb : 0]),
+                           la + A_BYTES + (wave + NWV * jb) * 1024);
+        }
+    };
+    auto issue = [&](int q) {
+        typename Prob::ChunkCtx cc = p.template chunk_ctx<BK>(q);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) issue_piece(cc, q, j);
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    // fragment addresses: the swizzle sees only lr (32-row tiles preserve the low row bits)
+    int afr[G::KS], bfr_[G::KS];
+#pragma unroll
+    for (int kk = 0; kk < G::KS; ++kk) {
+        afr[kk] = G::off(wm * 32 * MI + lr, kk * 2 + lh);
+        bfr_[kk] = G::off(wn * 64 + lr, kk * 2 + lh);
+    }
+
+#pragma unroll
+    for (int q = 0; q < D - 1; ++q)
+        if (q < nq) issue(q);
+
+    for (int q = 0; q < nq; ++q) {
+        // chunks issued so far: min(nq, q + D - 1); those after q may stay in flight
+        const int pending = min(nq, q + D - 1) - (q + 1);
+        if (FWN_ABL < 2) wait_vmcnt_le<PW>(pending);
+        else if (q == 0) FWN_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        // The refill of the slot freed by this barrier (chunk q+D-1) is spread over the k-steps,
+        // so every DMA issue (~100 cycles of this wave's issue time) hides under MFMAs in flight.
+        const bool refill = FWN_ABL < 2 && q + D - 1 < nq;
+        typename Prob::ChunkCtx ccn = p.template chunk_ctx<BK>(refill ? q + D - 1 : 0);
+        if (FWN_ABL == 1) {
+            if (refill) issue(q + D - 1);
+            continue;
+        }
+        const unsigned char* la = lds + (q % D) * SLOT;
+        const unsigned char* lb = la + A_BYTES;
+        // k-steps with explicitly double-buffered fragments: the ds_reads of step kk+1 are in
+        // flight while the MFMAs of step kk issue.
+        bf16x8 af[2][MI], bf_[2][2];
+        auto ldfrag = [&](int kk, int s) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[s][mi] = *(const bf16x8*)(la + afr[kk] + mi * 32 * G::RB);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bf_[s][ni] = *(const bf16x8*)(lb + bfr_[kk] + ni * 32 * G::RB);
+        };
+        constexpr int PPK = (PW + G::KS - 1) / G::KS;     // DMA pieces issued per k-step
+        ldfrag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < G::KS; ++kk) {
+            if (kk + 1 < G::KS) ldfrag(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);       // keep the next step's reads ahead of these MFMAs
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = mfma32(af[kk & 1][mi], bf_[kk & 1][ni], acc[mi][ni]);
+                    if (mi == 0 && ni == 0 && refill) {
+#pragma unroll
+                        for (int j = kk * PPK; j < (kk + 1) * PPK && j < PW; ++j) issue_piece(ccn, q + D - 1, j);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+}

@@ -169,9 +169,10 @@ class FloWaveNet:
     __call__ = forward
 
 
-def z_planes_to_squeezed(zp, n_block):
+def z_planes_to_squeezed(zp, n_block, n_flow=2):
     """planes[2][B][T/2] (device layout) -> the reference's final ``out`` [B, T/2^n, 2^n]
-    (canonical squeezed channel order), for comparisons against the oracle."""
+    (logical squeezed channel order after n_block*n_flow change_orders), for comparisons
+    against the oracle."""
     import torch
     two, b, ht = zp.shape
     n = n_block
@@ -180,6 +181,7 @@ def z_planes_to_squeezed(zp, n_block):
     v = zp.reshape(2, b, rows, ch)                       # [q][b][t][tau']
     br = torch.as_tensor(packing.bitrev_table(n - 1).astype(np.int64), device=zp.device)
     out = torch.empty(b, rows, 2 * ch, dtype=zp.dtype, device=zp.device)
+    swapped = (n_block * n_flow) & 1                     # odd number of swaps: halves exchanged
     for q in range(2):
-        out[:, :, q * ch + br] = v[q]
+        out[:, :, (q ^ swapped) * ch + br] = v[q]
     return out

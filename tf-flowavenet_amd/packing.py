@@ -88,6 +88,17 @@ def zero_src_n(block: int) -> np.ndarray:
     return out
 
 
+def acc_k_perm(k: int = FILTER) -> np.ndarray:
+    """K order of the weights whose activation operand comes straight out of an MFMA
+    accumulator (tail kernel, phases 2 and 3).  A 32x32 fp32 accumulator tile converted to
+    bf16 serves as the B operand of the next v_mfma_f32_32x32x16_bf16 with element j of lane
+    half h of k-step s holding tile row 16s + 8(j>>2) + 4h + (j&3); the matching A-operand
+    fragment is 8 contiguous packed columns k' = tile*32 + s*16 + h*8 + j."""
+    kp = np.arange(k)
+    s, h, j = (kp >> 4) & 1, (kp >> 3) & 1, kp & 7
+    return ((kp & ~31) + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)).astype(np.int32)
+
+
 def actnorm_table(b: np.ndarray, logs: np.ndarray, block: int) -> np.ndarray:
     """ActNorm (b, logs) in logical channel order -> an[2][4][Ch] (shift, scale, 1/scale, 3*logs)."""
     ch = 1 << block
@@ -172,6 +183,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
 
     ident256 = dev_i32("id256", lambda: np.arange(FILTER))
     ident768 = dev_i32("id768", lambda: np.arange(3 * FILTER))
+    accperm = dev_i32("accperm", lambda: acc_k_perm(FILTER))
     fg, gch = gate_row_channel()
     gate_rows = [dev_i32("gate_rows%d" % s, lambda s=s: np.where(fg == s, gch, -1)) for s in (0, 1)]
     scale_buf = torch.empty(FILTER, dtype=torch.float32, device=dev)
@@ -248,12 +260,12 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             d.bskip = dev_f32(bskip).data_ptr()
 
             wfin = bf16_zeros(FILTER, FILTER)
-            pack(wp + "/Conv_final", ident256, ident256, FILTER, FILTER, wfin, FILTER)
+            pack(wp + "/Conv_final", accperm, ident256, FILTER, FILTER, wfin, FILTER)
             d.Wfinal = wfin.data_ptr()
             d.bfinal = dev_f32(params[wp + "/Conv_final/bias"]).data_ptr()
 
             wz = bf16_zeros(npt * 64, FILTER)
-            pack(wp + "/ZeroConv1d", ident256, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
+            pack(wp + "/ZeroConv1d", accperm, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
             zb = np.asarray(params[wp + "/ZeroConv1d/bias"], np.float64).reshape(-1)
             zs = np.asarray(params[wp + "/ZeroConv1d/scale"], np.float64).reshape(-1)
             valid = zsn_host >= 0

@@ -1,0 +1,87 @@
+"""``synthesize`` CLI - same flags and file contract as the reference's synthesize.py:51-63:
+
+    python -m tf_flowavenet_amd.synthesize --saved_dir logs/pretrained/ --mels_dir mels/ --output_dir output/
+
+``mels_dir/*.npy`` float32 [F, num_mels] in [0,1]  ->  ``output_dir/<name>.wav`` (16-bit mono PCM at
+``hparams.sample_rate``).  Differences: the checkpoint is this package's own format (``*.npz`` /
+``*.safetensors`` holding the parameter names of ``weights.param_shapes``; TF checkpoints are out of
+scope), the wav writer is the stdlib ``wave`` module (librosa is not a dependency), ``z`` is
+seedable (``--seed``; TF's Philox stream cannot be reproduced), and mels of equal length are
+batched into one launch.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import os
+import wave
+
+import numpy as np
+
+
+def load_checkpoint(saved_dir):
+    """Newest ``*.npz`` / ``*.safetensors`` in ``saved_dir`` -> dict name -> ndarray."""
+    files = sorted(glob.glob(os.path.join(saved_dir, "*.npz")) + glob.glob(os.path.join(saved_dir, "*.safetensors")),
+                   key=os.path.getmtime)
+    if not files:
+        raise FileNotFoundError("no *.npz / *.safetensors checkpoint in %r" % saved_dir)
+    path = files[-1]
+    print("Loading checkpoint {}".format(path))
+    if path.endswith(".npz"):
+        with np.load(path) as f:
+            return {k: f[k] for k in f.files}
+    from safetensors.numpy import load_file
+    return load_file(path)
+
+
+def write_wav(path, audio, sample_rate):
+    pcm = np.clip(np.asarray(audio, dtype=np.float64), -1.0, 1.0)
+    pcm = (pcm * 32767.0).round().astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(int(sample_rate))
+        w.writeframes(pcm.tobytes())
+
+
+def synthesize(args, hparams, model=None):
+    import torch
+    from .model import FloWaveNet
+    if model is None:
+        model = FloWaveNet(hparams).load_params(load_checkpoint(args.saved_dir))
+    os.makedirs(args.output_dir, exist_ok=True)
+    names = sorted(f for f in os.listdir(args.mels_dir) if f.endswith(".npy"))
+    mels = {n: np.load(os.path.join(args.mels_dir, n)).astype(np.float32) for n in names}
+    by_len = {}
+    for n in names:
+        by_len.setdefault(mels[n].shape[0], []).append(n)
+    gen = torch.Generator(device="cpu").manual_seed(int(args.seed))
+    hop = hparams.hop_size
+    align = max(1, (1 << hparams.n_block) // np.gcd(1 << hparams.n_block, hop))
+    for frames, group in sorted(by_len.items()):
+        pad = (-frames) % align                      # T must divide by 2^n_block (model.py:226)
+        for i in range(0, len(group), args.batch):
+            chunk = group[i:i + args.batch]
+            c = np.stack([np.pad(mels[n], ((0, pad), (0, 0)), mode="edge") for n in chunk])
+            t = (frames + pad) * hop
+            z = torch.randn(len(chunk), t, 1, generator=gen) * hparams.temp     # synthesize.py:14
+            wav = model.reverse(z.cuda(), torch.from_numpy(c).cuda()).squeeze(-1).cpu().numpy()
+            for n, w in zip(chunk, wav):
+                write_wav(os.path.join(args.output_dir, n[:-4] + ".wav"), w[:frames * hop], hparams.sample_rate)
+    return names
+
+
+def main(argv=None):
+    from .hparams import hparams
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--saved_dir", default="logs/pretrained/", help="Folder with model checkpoint")
+    parser.add_argument("--mels_dir", default="mels/", help="folder to contain mels to synthesize audio from using the model")
+    parser.add_argument("--output_dir", default="output/", help="folder to contain synthesized audio files")
+    parser.add_argument("--seed", type=int, default=hparams.tf_random_seed, help="seed of the latent z")
+    parser.add_argument("--batch", type=int, default=8, help="equal-length mels per launch")
+    args = parser.parse_args(argv)
+    synthesize(args, hparams)
+
+
+if __name__ == "__main__":
+    main()
