@@ -99,6 +99,59 @@ struct FrontProb {
     }
 };
 
+// ---- front conv for the early blocks (Ch <= 16, K = 3*Ch <= 48): fp32 VALU -------------------
+// With so few input channels the conv is HBM-bound on writing h0 ([M][256] bf16), and an MFMA
+// tile would be > 90 % zero padding.  One workgroup = 4*R rows x 256 channels; a wave owns R rows
+// and each lane 4 channels; x (ActNorm applied, zero padded per clip) and the weights sit in LDS
+// as fp32, so the flow state enters the network at full precision.
+template <int R>
+__global__ __launch_bounds__(256) void front_valu_kernel(FrontProb p) {
+    constexpr int ROWS = 4 * R;
+    __shared__ __attribute__((aligned(16))) float wt[48 * 256];     // [k][256]
+    __shared__ __attribute__((aligned(16))) float yt[48 * ROWS];    // [k][row]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = 3 * p.Ch;
+    const int m0 = blockIdx.x * ROWS;
+    for (int i = tid; i < K * 256; i += 256) {
+        const int n = i & 255, k = i >> 8;
+        wt[k * 256 + n] = (float)p.W[(size_t)n * p.kpad + k];
+    }
+    for (int i = tid; i < K * ROWS; i += 256) {
+        const int r = i % ROWS, k = i / ROWS;
+        const int row = m0 + r;
+        yt[k * ROWS + r] = p.fetch(RowCtxT{row, row % p.Ti}, k);
+    }
+    __syncthreads();
+    float acc[R][4];
+    const float4 b4 = *(const float4*)(p.bias + 4 * lane);
+#pragma unroll
+    for (int r = 0; r < R; ++r) { acc[r][0] = b4.x; acc[r][1] = b4.y; acc[r][2] = b4.z; acc[r][3] = b4.w; }
+    for (int k = 0; k < K; ++k) {
+        const float4 w = *(const float4*)(wt + k * 256 + 4 * lane);
+#pragma unroll
+        for (int r4 = 0; r4 < R / 4; ++r4) {
+            const float4 y = *(const float4*)(yt + k * ROWS + wave * R + 4 * r4);    // wave-uniform: broadcast
+            const float yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[4 * r4 + j][0] += yy[j] * w.x; acc[4 * r4 + j][1] += yy[j] * w.y;
+                acc[4 * r4 + j][2] += yy[j] * w.z; acc[4 * r4 + j][3] += yy[j] * w.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = m0 + wave * R + r;
+        if (row < p.M) {
+            union { bf16 e[4]; uint2 u; } o;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o.e[c] = (bf16)fmaxf(acc[r][c], 0.0f);
+            *(uint2*)(p.hout + (size_t)row * FWN_HID + 4 * lane) = o.u;
+        }
+    }
+}
+
 // ---- gated dilated layer: o = tanh(f) * sigmoid(g), modules.py:113-124 ---------------------
 // K segments: 3 dilated taps over h (K = 3*256) then the 1x1 conditioning conv over c_a
 // (K = cin), or a precomputed conditioning projection P added in the epilogue.
@@ -593,14 +646,16 @@ static void launch_gemm128(const Prob& p, int M, int ntn, hipStream_t st) {
                        dim3(((M + BM - 1) / BM) * (N / BN)), dim3(64 * WM * WN), 0, st, p, N / BN)
 template <class Prob>
 static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
-    const int CU = 256;
-    if (Prob::ALLOW_256 && N % 256 == 0 && ((M + 255) / 256) * (N / 256) >= CU * 3 / 4) {
-        RING_LAUNCH(256, 256, 2, 4, 64, 2);
-    } else if (N % 256 == 0 && ((M + 127) / 128) * (N / 256) >= CU * 3 / 4) {
-        RING_LAUNCH(128, 256, 2, 4, 64, 3);
-    } else if (((M + 127) / 128) * (N / 128) >= CU * 3 / 4) {
-        RING_LAUNCH(128, 128, 2, 2, 64, 3);
-    } else if (((M + 63) / 64) * (N / 128) >= CU * 3 / 4) {
+    // 16-wave workgroups (4 waves per SIMD) hide the barrier / LDS latency of the K loop best
+    // (tools/bench_gemm.hip): 256x256 reaches ~0.8 PF on the block-1 gate, 8-wave tiles ~0.7.
+    const int FILL = 192;    // workgroups needed before a fatter tile pays (256 CUs)
+    if (Prob::ALLOW_256 && N % 256 == 0 && ((M + 255) / 256) * (N / 256) >= FILL) {
+        RING_LAUNCH(256, 256, 4, 4, 64, 2);
+    } else if (((M + 255) / 256) * (N / 128) >= FILL) {
+        RING_LAUNCH(256, 128, 8, 2, 64, 3);
+    } else if (((M + 127) / 128) * (N / 128) >= FILL) {
+        RING_LAUNCH(128, 128, 4, 2, 64, 3);
+    } else if (((M + 63) / 64) * (N / 128) >= FILL) {
         RING_LAUNCH(64, 128, 2, 2, 64, 4);
     } else {
         RING_LAUNCH(64, 64, 2, 1, 64, 4);
@@ -610,6 +665,11 @@ static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const float* bias, void* hout,
                       int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st) {
     FrontProb p{xa, an_a, (const bf16*)W, bias, (bf16*)hout, M, Ti, Ch, ilog2(Ch), kpad, apply_an};
+    if (Ch <= 16) {
+        if (M >= 64 * 512) hipLaunchKernelGGL((front_valu_kernel<16>), dim3((M + 63) / 64), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((front_valu_kernel<4>), dim3((M + 15) / 16), dim3(256), 0, st, p);
+        return;
+    }
     launch_gemm128(p, M, 2, st);
 }
 

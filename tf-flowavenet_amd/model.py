@@ -102,14 +102,17 @@ class FloWaveNet:
         return b, t, x32, c32
 
     def _workspace(self, b, t):
+        """Scratch for one pass.  One workspace per (B, T, HIP stream): passes issued on different
+        streams (e.g. a forward and an inverse overlapping on the chip) never share scratch."""
         import torch
-        key = (b, t)
+        key = (b, t, self._stream())
         ws = self._ws.get(key)
         if ws is None:
             n = self._lib.fwn_workspace_bytes(C.byref(self._packed.model_desc), b, t)
             if n == 0:
                 _lib.check(-1, "fwn_workspace_bytes")
-            self._ws.clear()     # one live workspace; sized for 288 GB parts, not hoarded
+            for k in [k for k in self._ws if k[:2] != (b, t)]:
+                del self._ws[k]   # keep only the current shape's workspaces
             ws = torch.empty(n + 256, dtype=torch.uint8, device=self._device)
             self._ws[key] = ws
         off = (-ws.data_ptr()) % 256

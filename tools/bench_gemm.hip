@@ -50,15 +50,19 @@ int main(int argc, char** argv) {
         const double flops = 2.0 * M * (768.0 + (hoist ? 0 : cin)) * 512;
         printf("block %d  M=%d K=%d\n", blk, M, 768 + (hoist ? 0 : cin));
         if (M >= 16128) {
-            GATE_CFG(256, 256, 2, 4, 32, 4);
             GATE_CFG(256, 256, 2, 4, 64, 2);
+            GATE_CFG(256, 256, 4, 4, 64, 2);
+            GATE_CFG(256, 256, 4, 4, 32, 4);
             GATE_CFG(256, 128, 4, 2, 64, 3);
+            GATE_CFG(256, 128, 8, 2, 64, 3);
             GATE_CFG(128, 256, 2, 4, 64, 3);
-            GATE_CFG(128, 256, 2, 4, 32, 4);
+            GATE_CFG(128, 256, 4, 4, 64, 3);
         }
-        GATE_CFG(128, 128, 2, 2, 64, 3);
         GATE_CFG(128, 128, 2, 2, 64, 2);
+        GATE_CFG(128, 128, 4, 2, 64, 3);
+        GATE_CFG(128, 128, 4, 2, 64, 2);
         GATE_CFG(64, 128, 2, 2, 64, 4);
+        GATE_CFG(64, 256, 2, 4, 64, 3);
         if (M <= 4096) GATE_CFG(64, 64, 2, 1, 64, 4);
         {
             void* Ws = dalloc(256ull * 512 * 2, 1);
