@@ -122,6 +122,18 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
 int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_partial, float* out2,
                    void* stream);
 
+/* ---- data-parallel optimiser step (replaces average_gradients + un-scale + clip_by_global_norm
+ * + AdamOptimizer.apply_gradients, utils.py:34-60, train.py:27-32,75-81).  g is the flat fp32
+ * gradient buffer AFTER the RCCL all-reduce (a sum over ranks); gscale = 1/(world * loss_scale)
+ * turns it into the reference's averaged, un-scaled gradient.
+ * fwn_grad_norm: gnorm_out[0] = ||g * gscale||_2 (deterministic; partial holds
+ * fwn_grad_norm_partials(n) doubles).  fwn_clip_adam: g' = g*gscale * clip / max(gnorm, clip),
+ * then TF-form Adam (lr_t = lr*sqrt(1-b2^t)/(1-b1^t), eps outside the sqrt) on fp32 masters. */
+int fwn_grad_norm_partials(int64_t n);
+int fwn_grad_norm(const float* g, int64_t n, float gscale, double* partial, float* gnorm_out, void* stream);
+int fwn_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* gnorm, float gscale,
+                  float clip, float lr, int64_t step, float beta1, float beta2, float eps, void* stream);
+
 /* ---- whole model (replaces FloWaveNet.forward / .reverse, model.py:317-396) ---- */
 typedef struct fwn_model_desc {
     int32_t n_block, n_flow, n_layer, num_mels;

@@ -218,3 +218,18 @@ def test_synthetic_inputs_contract():
     inp = W.synthetic_inputs(hp, 2, 512)
     assert inp["x"].shape == (2, 512, 1) and inp["c"].shape == (2, 2, 80) and inp["z"].shape == (2, 512, 1)
     assert np.abs(inp["x"]).max() <= 0.999 and inp["c"].min() >= 0 and inp["c"].max() < 1
+
+
+def test_wav_writer_and_checkpoint_loader(tmp_path):
+    import wave
+    from tf_flowavenet_amd import synthesize as S
+    audio = np.array([0.0, 0.5, -0.5, 1.5, -1.5, 0.25])
+    S.write_wav(str(tmp_path / "x.wav"), audio, 8000)
+    with wave.open(str(tmp_path / "x.wav")) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 8000, 6)
+        pcm = np.frombuffer(w.readframes(6), dtype="<i2")
+    np.testing.assert_array_equal(pcm, [0, 16384, -16384, 32767, -32767, 8192])   # clipped to +-1
+    with pytest.raises(FileNotFoundError):
+        S.load_checkpoint(str(tmp_path))
+    np.savez(tmp_path / "m.npz", a=np.arange(3))
+    assert list(S.load_checkpoint(str(tmp_path))) == ["a"]

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 
 #include "../../include/fwn.h"
 #include "fwn_internal.h"
@@ -194,6 +195,26 @@ int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_p
     REQUIRE(planes && out2 && n > 0 && n_partial >= 0 && (partial || n_partial == 0), "fwn_prior_logp: bad argument");
     fwn_launch_prior(planes, (long)n, partial, n_partial, 1.0 / (double)n, out2, (hipStream_t)stream);
     return check_launch("fwn_prior_logp");
+}
+
+// ---- data-parallel optimiser step -------------------------------------------------------------
+int fwn_grad_norm_partials(int64_t n) { return fwn_sqnorm_blocks((long)n); }
+
+int fwn_grad_norm(const float* g, int64_t n, float gscale, double* partial, float* gnorm_out, void* stream) {
+    REQUIRE(g && partial && gnorm_out && n > 0, "fwn_grad_norm: bad argument");
+    REQUIRE(ALIGNED16(g), "fwn_grad_norm: gradient buffer must be 16-byte aligned");
+    fwn_launch_grad_norm(g, (long)n, gscale, partial, gnorm_out, (hipStream_t)stream);
+    return check_launch("fwn_grad_norm");
+}
+
+int fwn_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* gnorm, float gscale,
+                  float clip, float lr, int64_t step, float beta1, float beta2, float eps, void* stream) {
+    REQUIRE(w && g && m && v && gnorm && n > 0, "fwn_clip_adam: bad argument");
+    REQUIRE(ALIGNED16(w) && ALIGNED16(g) && ALIGNED16(m) && ALIGNED16(v), "fwn_clip_adam: buffers must be 16-byte aligned");
+    REQUIRE(step >= 1 && clip > 0.0f && lr > 0.0f, "fwn_clip_adam: step must be >= 1, clip and lr positive");
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+    fwn_launch_adam(w, g, m, v, (long)n, gnorm, gscale, clip, (float)lr_t, beta1, beta2, eps, (hipStream_t)stream);
+    return check_launch("fwn_clip_adam");
 }
 
 // ---------------------------------------------------------------------------------------------

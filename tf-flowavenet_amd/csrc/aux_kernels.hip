@@ -167,6 +167,75 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ z
     }
 }
 
+// ---- data-parallel optimiser step (train.py:15-32,75-81, utils.py:34-60) --------------------
+// Gradients live in ONE flat fp32 buffer (what the RCCL all-reduce sums); the reference's
+// average_gradients / un-scale / clip_by_global_norm / Adam chain becomes two HBM-bound passes:
+//   (1) per-workgroup partial sums of g^2 (fixed order -> deterministic global norm),
+//   (2) fused  g' = g * gscale / max(||g * gscale||, clip);  TF-form Adam on fp32 master weights.
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, long n,
+                                                             double* __restrict__ partial) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const float4 v = *(const float4*)(g + i);
+            s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        } else {
+            for (long j = i; j < n; ++j) s += (double)g[j] * g[j];
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// out[0] = sqrt(sum partial) * gscale  (= global norm of the averaged, un-scaled gradient)
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const double* __restrict__ partial, int np,
+                                                           float gscale, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)(sqrt(red[0]) * (double)gscale);
+}
+// tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v updates; w -= lr_t*m/(sqrt(v)+eps)
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long n,
+                                                        const float* __restrict__ gnorm, float gscale, float clip,
+                                                        float lr_t, float b1, float b2, float eps) {
+    const float sc = gscale / fmaxf(gnorm[0], clip);     // tf.clip_by_global_norm: g / max(gn, clip)*clip, clip=1
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 3 < n) {
+            const float4 gv = *(const float4*)(g + i);
+            float4 mv = *(float4*)(m + i), vv = *(float4*)(v + i), wv = *(float4*)(w + i);
+            const float gg[4] = {gv.x * sc * clip, gv.y * sc * clip, gv.z * sc * clip, gv.w * sc * clip};
+            float* mm = &mv.x; float* v2 = &vv.x; float* ww = &wv.x;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mm[k] = b1 * mm[k] + (1.0f - b1) * gg[k];
+                v2[k] = b2 * v2[k] + (1.0f - b2) * gg[k] * gg[k];
+                ww[k] -= lr_t * mm[k] / (sqrtf(v2[k]) + eps);
+            }
+            *(float4*)(m + i) = mv; *(float4*)(v + i) = vv; *(float4*)(w + i) = wv;
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gj = g[j] * sc * clip;
+                m[j] = b1 * m[j] + (1.0f - b1) * gj;
+                v[j] = b2 * v[j] + (1.0f - b2) * gj * gj;
+                w[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
+            }
+        }
+    }
+}
+
 // ---- launchers -------------------------------------------------------------------------------
 static inline int grid_for(long total) {
     long g = (total + 255) / 256;
@@ -199,4 +268,16 @@ void fwn_launch_ddi(const float* xa, const float* xb, int M, int Ch, float* an, 
 void fwn_launch_prior(const float* planes, long n, const float* partial, int n_partial, double inv_bt,
                       float* out2, hipStream_t st) {
     hipLaunchKernelGGL(prior_kernel, dim3(1), dim3(1024), 0, st, planes, n, partial, n_partial, inv_bt, out2);
+}
+
+int fwn_sqnorm_blocks(long n) { long b = (n + 1023) / 1024; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+void fwn_launch_grad_norm(const float* g, long n, float gscale, double* partial, float* out, hipStream_t st) {
+    const int nb = fwn_sqnorm_blocks(n);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, st, g, n, partial);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, gscale, out);
+}
+void fwn_launch_adam(float* w, const float* g, float* m, float* v, long n, const float* gnorm, float gscale,
+                     float clip, float lr_t, float b1, float b2, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(adam_clip_kernel, dim3(fwn_sqnorm_blocks(n)), dim3(256), 0, st, w, g, m, v, n, gnorm, gscale,
+                       clip, lr_t, b1, b2, eps);
 }

@@ -312,10 +312,10 @@ __global__ __launch_bounds__(256) void gemm128_kernel(Prob p, int ntn) {
 }
 
 // Ring-pipelined GEMM: tile BM x BN, WM x WN waves, K-chunk BK, ring depth D.
-template <int BM, int BN, int WM, int WN, int BK, int D, class Prob>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(Prob p, int ntn) {
+template <int BM, int BN, int WM, int WN, int BK, int D, class Prob, int KSP = 1>
+__global__ __launch_bounds__(64 * WM * WN * KSP) void gemm_ring_kernel(Prob p, int ntn) {
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    gemm_ring_body<BM, BN, WM, WN, BK, D, Prob>(p, wg / ntn, wg % ntn);
+    gemm_ring_body<BM, BN, WM, WN, BK, D, Prob, KSP>(p, wg / ntn, wg % ntn);
 }
 
 // Batched conditioning projections: blockIdx.y selects (flow, layer) of one parity group.
@@ -641,9 +641,10 @@ static void launch_gemm128(const Prob& p, int M, int ntn, hipStream_t st) {
 // Tile choice for the ring GEMMs: the largest tile that still yields about one workgroup per CU
 // (the chain of K-chunks inside a workgroup is serial, so fewer, fatter workgroups only pay while
 // every CU has one).  N = 64 * ncol64 output columns.
-#define RING_LAUNCH(BM, BN, WM, WN, BK, D)                                                          \
-    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, WM, WN, BK, D, Prob>),                             \
-                       dim3(((M + BM - 1) / BM) * (N / BN)), dim3(64 * WM * WN), 0, st, p, N / BN)
+#define RING_LAUNCH(BM, BN, WM, WN, BK, D) RING_LAUNCHK(BM, BN, WM, WN, BK, D, 1)
+#define RING_LAUNCHK(BM, BN, WM, WN, BK, D, KSP)                                                    \
+    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, WM, WN, BK, D, Prob, KSP>),                        \
+                       dim3(((M + BM - 1) / BM) * (N / BN)), dim3(64 * WM * WN * KSP), 0, st, p, N / BN)
 template <class Prob>
 static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
     // 16-wave workgroups (4 waves per SIMD) hide the barrier / LDS latency of the K loop best
@@ -654,11 +655,11 @@ static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
     } else if (((M + 255) / 256) * (N / 128) >= FILL) {
         RING_LAUNCH(256, 128, 8, 2, 64, 3);
     } else if (((M + 127) / 128) * (N / 128) >= FILL) {
-        RING_LAUNCH(128, 128, 4, 2, 64, 3);
+        RING_LAUNCH(128, 128, 4, 2, 64, 2);
     } else if (((M + 63) / 64) * (N / 128) >= FILL) {
         RING_LAUNCH(64, 128, 2, 2, 64, 4);
     } else {
-        RING_LAUNCH(64, 64, 2, 1, 64, 4);
+        RING_LAUNCHK(64, 64, 2, 1, 64, 4, 2);   // 2-way intra-workgroup split-K: 4 waves per tile
     }
 }
 

@@ -27,3 +27,8 @@ void fwn_launch_merge(const float* planes, long B, long T, float* x, hipStream_t
 void fwn_launch_ddi(const float* xa, const float* xb, int M, int Ch, float* an, hipStream_t st);
 void fwn_launch_prior(const float* planes, long n, const float* partial, int n_partial, double inv_bt,
                       float* out2, hipStream_t st);
+
+int fwn_sqnorm_blocks(long n);
+void fwn_launch_grad_norm(const float* g, long n, float gscale, double* partial, float* out, hipStream_t st);
+void fwn_launch_adam(float* w, const float* g, float* m, float* v, long n, const float* gnorm, float gscale,
+                     float clip, float lr_t, float b1, float b2, float eps, hipStream_t st);

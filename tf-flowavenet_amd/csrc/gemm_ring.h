@@ -54,10 +54,14 @@ __device__ __forceinline__ void wait_vmcnt_le(int pending_chunks) {
     else FWN_WAIT_VMCNT(0);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int D, class Prob>
+// KSP > 1: intra-workgroup split-K for small tiles - KSP wave groups take alternate k-steps of
+// every chunk (more waves per CU to hide LDS latency on an otherwise 2-wave tile) and their
+// partial accumulators are summed through LDS before the epilogue.
+template <int BM, int BN, int WM, int WN, int BK, int D, class Prob, int KSP = 1>
 __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int tile_n) {
     using G = RingGeom<BK>;
-    constexpr int NWV = WM * WN;
+    constexpr int NWV = WM * WN * KSP;
+    static_assert(G::KS % KSP == 0, "k-steps must divide over the split");
     constexpr int MI = BM / (32 * WM);
     static_assert(BN == 64 * WN, "wave tile is 64 columns wide");
     static_assert(MI >= 1 && BM == 32 * MI * WM, "bad BM");
@@ -72,7 +76,8 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int wk = wave / (WM * WN), wmn = wave % (WM * WN);
+    const int wm = wmn / WN, wn = wmn % WN;
     const int lr = lane & 31, lh = lane >> 5;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -119,11 +124,13 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
     // fragment addresses: the swizzle sees only lr (32-row tiles preserve the low row bits)
-    int afr[G::KS], bfr_[G::KS];
+    // (indexed by this wave's own k-step counter ki: k-step wk + ki*KSP of the chunk)
+    constexpr int KSW = G::KS / KSP;
+    int afr[KSW], bfr_[KSW];
 #pragma unroll
-    for (int kk = 0; kk < G::KS; ++kk) {
-        afr[kk] = G::off(wm * 32 * MI + lr, kk * 2 + lh);
-        bfr_[kk] = G::off(wn * 64 + lr, kk * 2 + lh);
+    for (int ki = 0; ki < KSW; ++ki) {
+        afr[ki] = G::off(wm * 32 * MI + lr, (wk + ki * KSP) * 2 + lh);
+        bfr_[ki] = G::off(wn * 64 + lr, (wk + ki * KSP) * 2 + lh);
     }
 
 #pragma unroll
@@ -149,29 +156,57 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         // k-steps with explicitly double-buffered fragments: the ds_reads of step kk+1 are in
         // flight while the MFMAs of step kk issue.
         bf16x8 af[2][MI], bf_[2][2];
-        auto ldfrag = [&](int kk, int s) {
+        auto ldfrag = [&](int ki, int s) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[s][mi] = *(const bf16x8*)(la + afr[kk] + mi * 32 * G::RB);
+            for (int mi = 0; mi < MI; ++mi) af[s][mi] = *(const bf16x8*)(la + afr[ki] + mi * 32 * G::RB);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bf_[s][ni] = *(const bf16x8*)(lb + bfr_[kk] + ni * 32 * G::RB);
+            for (int ni = 0; ni < 2; ++ni) bf_[s][ni] = *(const bf16x8*)(lb + bfr_[ki] + ni * 32 * G::RB);
         };
-        constexpr int PPK = (PW + G::KS - 1) / G::KS;     // DMA pieces issued per k-step
+        constexpr int PPK = (PW + KSW - 1) / KSW;          // DMA pieces issued per k-step
         ldfrag(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < G::KS; ++kk) {
-            if (kk + 1 < G::KS) ldfrag(kk + 1, (kk + 1) & 1);
+        for (int ki = 0; ki < KSW; ++ki) {
+            if (ki + 1 < KSW) ldfrag(ki + 1, (ki + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);       // keep the next step's reads ahead of these MFMAs
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    acc[mi][ni] = mfma32(af[kk & 1][mi], bf_[kk & 1][ni], acc[mi][ni]);
+                    acc[mi][ni] = mfma32(af[ki & 1][mi], bf_[ki & 1][ni], acc[mi][ni]);
                     if (mi == 0 && ni == 0 && refill) {
 #pragma unroll
-                        for (int j = kk * PPK; j < (kk + 1) * PPK && j < PW; ++j) issue_piece(ccn, q + D - 1, j);
+                        for (int j = ki * PPK; j < (ki + 1) * PPK && j < PW; ++j) issue_piece(ccn, q + D - 1, j);
                     }
                 }
             __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (KSP > 1) {
+        // sum the KSP partial accumulators: groups 1.. park theirs in LDS (the ring is drained)
+        constexpr int TILE_F = MI * 2 * 16 * 64;           // floats per wave
+        static_assert((KSP - 1) * WM * WN * TILE_F * 4 <= D * SLOT, "reduction scratch must fit the ring");
+        float* red = (float*)lds;
+        __builtin_amdgcn_s_barrier();
+        if (wk > 0) {
+            float* dst = red + ((wk - 1) * WM * WN + wmn) * TILE_F + lane;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((mi * 2 + ni) * 16 + r) * 64] = acc[mi][ni][r];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int g = 1; g < KSP; ++g) {
+            const float* src = red + ((g - 1) * WM * WN + wmn) * TILE_F + lane;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += src[((mi * 2 + ni) * 16 + r) * 64];
         }
     }
     p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);

@@ -52,9 +52,9 @@ class FloWaveNet:
         for name, shape in shapes.items():
             if name not in params:
                 raise KeyError("missing parameter %r" % name)
-            if tuple(np.shape(params[name])) != tuple(shape):
-                raise ValueError("parameter %r has shape %r, expected %r"
-                                 % (name, tuple(np.shape(params[name])), tuple(shape)))
+            got = tuple(getattr(params[name], "shape", None) or np.shape(params[name]))
+            if got != tuple(shape):
+                raise ValueError("parameter %r has shape %r, expected %r" % (name, got, tuple(shape)))
         self._packed = packing.pack_model(params, self._hparams, self._device, self._cond_mode)
         return self
 

@@ -1,0 +1,125 @@
+"""Data-parallel optimiser step for the flow model.
+
+Replaces, for one process per GPU:
+  * ``average_gradients`` (utils.py:34-60: gather every tower's gradient on one device and
+    ``reduce_mean``)  ->  ONE bucketed RCCL all-reduce (sum) of a flat fp32 gradient buffer over
+    xGMI; the 1/world factor is folded into the optimiser kernel;
+  * ``tf.scalar_mul(1/scale)`` + ``clip_by_global_norm(., 1)`` + ``AdamOptimizer`` (train.py:15-32,
+    75-81)  ->  ``fwn_grad_norm`` + ``fwn_clip_adam`` (two HBM-bound passes, deterministic norm);
+  * ``fp16_dtype_getter`` (utils.py:3-31: fp32 master variable + cached low-precision cast)  ->
+    fp32 master weights in one flat buffer, re-packed to bf16 MFMA layouts after the update
+    (``packing.pack_model`` reading device views; bf16 needs no loss scale, ``scale`` is kept only
+    to consume gradients of a scaled loss).
+
+The backward kernels that would fill ``grad`` are not part of this round;
+tests drive the step with known gradients.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib, weights
+
+
+def learning_rate(step: int) -> float:
+    """Step-wise schedule of train.py:17-20 (global_step before the update)."""
+    if step >= 600000:
+        return 0.001 / 6
+    if step >= 400000:
+        return 0.001 / 4
+    if step >= 200000:
+        return 0.001 / 2
+    return 0.001
+
+
+class FlatLayout:
+    """name -> (offset, shape) of every trainable tensor inside one flat fp32 vector, in
+    ``weights.param_shapes`` order, each tensor start aligned to 4 elements (16 bytes)."""
+
+    def __init__(self, hp):
+        self.slots = {}
+        off = 0
+        for name, shape in weights.param_shapes(hp).items():
+            n = int(np.prod(shape))
+            self.slots[name] = (off, tuple(shape), n)
+            off += (n + 3) // 4 * 4
+        self.size = off
+
+    def flatten(self, params):
+        out = np.zeros(self.size, dtype=np.float32)
+        for name, (off, shape, n) in self.slots.items():
+            out[off:off + n] = np.asarray(params[name], dtype=np.float32).reshape(-1)
+        return out
+
+    def views(self, flat):
+        """dict name -> view (torch or numpy) into ``flat`` with the reference's shapes."""
+        return {name: flat[off:off + n].reshape(shape) for name, (off, shape, n) in self.slots.items()}
+
+
+def bucket_bounds(n: int, bucket_elems: int):
+    """[lo, hi) element ranges of the all-reduce buckets (last one may be short)."""
+    if bucket_elems <= 0:
+        raise ValueError("bucket size must be positive")
+    return [(lo, min(n, lo + bucket_elems)) for lo in range(0, n, bucket_elems)]
+
+
+def allreduce_flat(grad, group=None, bucket_elems=64 << 20, async_op=True):
+    """Sum ``grad`` (flat tensor, any device) over ranks bucket by bucket.  Buckets are issued
+    back to back (asynchronously) so a caller can interleave them with backward compute; xGMI is
+    point-to-point, so fewer, larger buckets (256 MB of fp32 each by default) keep every link busy.
+    Returns the list of work handles (already waited when async_op=False)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return []
+    works = [dist.all_reduce(grad[lo:hi], group=group, async_op=True) for lo, hi in bucket_bounds(grad.numel(), bucket_elems)]
+    if not async_op:
+        for w in works:
+            w.wait()
+    return works
+
+
+class DataParallelAdam:
+    """fp32 master weights + Adam slots in flat device buffers; ``step()`` = all-reduce -> global
+    norm -> clip -> Adam, returning the (device) global gradient norm."""
+
+    def __init__(self, hp, params, device="cuda", clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8, group=None,
+                 bucket_elems=64 << 20):
+        import torch
+        self.layout = FlatLayout(hp)
+        self.device = device
+        self.group = group
+        self.bucket_elems = bucket_elems
+        self.clip, self.b1, self.b2, self.eps = clip, beta1, beta2, eps
+        self.w = torch.from_numpy(self.layout.flatten(params)).to(device)
+        self.g = torch.zeros_like(self.w)
+        self.m = torch.zeros_like(self.w)
+        self.v = torch.zeros_like(self.w)
+        self.global_step = 0
+        self._lib = _lib.load()
+        self._partial = torch.empty(self._lib.fwn_grad_norm_partials(self.w.numel()), dtype=torch.float64, device=device)
+        self._gnorm = torch.empty(1, dtype=torch.float32, device=device)
+
+    def master_views(self):
+        return self.layout.views(self.w)
+
+    def grad_views(self):
+        return self.layout.views(self.g)
+
+    def step(self, loss_scale=1.0):
+        """``self.g`` holds this rank's gradient of (loss_scale * loss)."""
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        for w in allreduce_flat(self.g, self.group, self.bucket_elems):
+            w.wait()
+        gscale = 1.0 / (world * float(loss_scale))
+        st = torch.cuda.current_stream(torch.device(self.device)).cuda_stream
+        n = self.w.numel()
+        _lib.check(self._lib.fwn_grad_norm(self.g.data_ptr(), n, gscale, self._partial.data_ptr(),
+                                           self._gnorm.data_ptr(), st), "fwn_grad_norm")
+        lr = learning_rate(self.global_step)
+        self.global_step += 1
+        _lib.check(self._lib.fwn_clip_adam(self.w.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                           n, self._gnorm.data_ptr(), gscale, self.clip, lr, self.global_step,
+                                           self.b1, self.b2, self.eps, st), "fwn_clip_adam")
+        return self._gnorm

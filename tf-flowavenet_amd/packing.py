@@ -181,6 +181,15 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
     def dev_f32(a):
         return pm.keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev))
 
+    class _HostView(dict):
+        """params may hold device tensors (fp32 masters of optim.DataParallelAdam): the few
+        host-side reductions (bias sums, ActNorm / ZeroConv scale tables) read them through here."""
+        def __getitem__(self, k):
+            v = params[k]
+            return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v
+
+    hostp = _HostView()
+
     ident256 = dev_i32("id256", lambda: np.arange(FILTER))
     ident768 = dev_i32("id768", lambda: np.arange(3 * FILTER))
     accperm = dev_i32("accperm", lambda: acc_k_perm(FILTER))
@@ -190,12 +199,17 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
 
     def pack(name, src_k, src_n, k_dst, n_dst, out, ld_dst, col_off=0, weight_norm=True):
         """Pack params[name + '/kernel'] into out[:, col_off: col_off + k_dst]."""
-        v = torch.from_numpy(np.ascontiguousarray(params[name + "/kernel"], dtype=np.float32)).to(dev)
+        def up(x):
+            if isinstance(x, torch.Tensor):
+                return x.to(device=dev, dtype=torch.float32).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+
+        v = up(params[name + "/kernel"])
         k_src = v.shape[0] * v.shape[1]
         n_src = v.shape[2]
         sc = None
         if weight_norm:
-            g = torch.from_numpy(np.ascontiguousarray(params[name + "/g"], dtype=np.float32)).to(dev)
+            g = up(params[name + "/g"])
             _lib.check(lib.fwn_wn_scale(v.data_ptr(), g.data_ptr(), k_src, n_src, scale_buf.data_ptr(), stream),
                        "fwn_wn_scale")
             sc = scale_buf.data_ptr()
@@ -229,7 +243,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             wfront = bf16_zeros(FILTER, kfpad)
             pack(wp + "/Conv_front", f_src_k, ident256, kfpad, FILTER, wfront, kfpad)
             d.Wfront = wfront.data_ptr()
-            d.bfront = dev_f32(params[wp + "/Conv_front/bias"]).data_ptr()
+            d.bfront = dev_f32(hostp[wp + "/Conv_front/bias"]).data_ptr()
 
             wskip = bf16_zeros(FILTER, L * FILTER)
             bskip = np.zeros(FILTER, dtype=np.float64)
@@ -241,10 +255,10 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
                 wc = wc_blk[j, l]
                 pack(rp + "/filter_conv_c", c_src_k, gate_rows[0], kcpad, GATE_N, wc, kcpad)
                 pack(rp + "/gate_conv_c", c_src_k, gate_rows[1], kcpad, GATE_N, wc, kcpad)
-                bsum = [np.asarray(params[rp + "/Conv_filter/bias"], np.float32)
-                        + np.asarray(params[rp + "/filter_conv_c/bias"], np.float32),
-                        np.asarray(params[rp + "/Conv_gate/bias"], np.float32)
-                        + np.asarray(params[rp + "/gate_conv_c/bias"], np.float32)]
+                bsum = [np.asarray(hostp[rp + "/Conv_filter/bias"], np.float32)
+                        + np.asarray(hostp[rp + "/filter_conv_c/bias"], np.float32),
+                        np.asarray(hostp[rp + "/Conv_gate/bias"], np.float32)
+                        + np.asarray(hostp[rp + "/gate_conv_c/bias"], np.float32)]
                 bg = np.where(fg == 0, bsum[0][gch], bsum[1][gch])
                 d.Wd[l] = wd.data_ptr()
                 d.Wc[l] = wc.data_ptr()
@@ -253,21 +267,21 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
                     wr = bf16_zeros(FILTER, FILTER)
                     pack(rp + "/res_conv", ident256, ident256, FILTER, FILTER, wr, FILTER)
                     d.Wres[l] = wr.data_ptr()
-                    d.bres[l] = dev_f32(params[rp + "/res_conv/bias"]).data_ptr()
+                    d.bres[l] = dev_f32(hostp[rp + "/res_conv/bias"]).data_ptr()
                 pack(rp + "/skip_conv", ident256, ident256, FILTER, FILTER, wskip, L * FILTER, col_off=l * FILTER)
-                bskip += np.asarray(params[rp + "/skip_conv/bias"], np.float64)
+                bskip += np.asarray(hostp[rp + "/skip_conv/bias"], np.float64)
             d.Wskip = wskip.data_ptr()
             d.bskip = dev_f32(bskip).data_ptr()
 
             wfin = bf16_zeros(FILTER, FILTER)
             pack(wp + "/Conv_final", accperm, ident256, FILTER, FILTER, wfin, FILTER)
             d.Wfinal = wfin.data_ptr()
-            d.bfinal = dev_f32(params[wp + "/Conv_final/bias"]).data_ptr()
+            d.bfinal = dev_f32(hostp[wp + "/Conv_final/bias"]).data_ptr()
 
             wz = bf16_zeros(npt * 64, FILTER)
             pack(wp + "/ZeroConv1d", accperm, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
-            zb = np.asarray(params[wp + "/ZeroConv1d/bias"], np.float64).reshape(-1)
-            zs = np.asarray(params[wp + "/ZeroConv1d/scale"], np.float64).reshape(-1)
+            zb = np.asarray(hostp[wp + "/ZeroConv1d/bias"], np.float64).reshape(-1)
+            zs = np.asarray(hostp[wp + "/ZeroConv1d/scale"], np.float64).reshape(-1)
             valid = zsn_host >= 0
             bz = np.zeros(npt * 64)
             ez = np.ones(npt * 64)
@@ -277,7 +291,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             d.bzero = dev_f32(bz).data_ptr()
             d.ezero = dev_f32(ez).data_ptr()
 
-            an = dev_f32(actnorm_table(params[fp + "/ActNorm/b"], params[fp + "/ActNorm/logs"], i))
+            an = dev_f32(actnorm_table(hostp[fp + "/ActNorm/b"], hostp[fp + "/ActNorm/logs"], i))
             pm.an[(i, j)] = an
             d.an = an.data_ptr()
 
@@ -287,7 +301,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
     if md.n_up > _lib.FWN_MAX_UPSAMPLE:
         raise ValueError("too many upsample stages")
     for n, s in enumerate(hp.upsample_scales):
-        wk, bias = upsample_kernel(params, n)
+        wk, bias = upsample_kernel(hostp, n)
         md.up_scale[n] = int(s)
         md.up_w[n] = dev_f32(wk).data_ptr()
         md.up_bias[n] = bias

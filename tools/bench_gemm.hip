@@ -32,6 +32,12 @@ template <class F> static void timeit(const char* name, double flops, F fn) {
                            dim3(((M + BM - 1) / BM) * (512 / BN)), dim3(64 * WM * WN), 0, 0, p, 512 / BN); \
     })
 
+#define GATE_CFGK(BM, BN, WM, WN, BK, D, KSP)                                                              \
+    timeit("gate " #BM "x" #BN " w" #WM "x" #WN " k" #BK " d" #D " ksp" #KSP, flops, [&] {                 \
+        hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, WM, WN, BK, D, GateProb, KSP>),                       \
+                           dim3(((M + BM - 1) / BM) * (512 / BN)), dim3(64 * WM * WN * KSP), 0, 0, p, 512 / BN); \
+    })
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8;
     const int T = 16128;
@@ -52,7 +58,7 @@ int main(int argc, char** argv) {
         if (M >= 16128) {
             GATE_CFG(256, 256, 2, 4, 64, 2);
             GATE_CFG(256, 256, 4, 4, 64, 2);
-            GATE_CFG(256, 256, 4, 4, 32, 4);
+            GATE_CFG(128, 128, 4, 2, 64, 2);
             GATE_CFG(256, 128, 4, 2, 64, 3);
             GATE_CFG(256, 128, 8, 2, 64, 3);
             GATE_CFG(128, 256, 2, 4, 64, 3);
@@ -63,7 +69,13 @@ int main(int argc, char** argv) {
         GATE_CFG(128, 128, 4, 2, 64, 2);
         GATE_CFG(64, 128, 2, 2, 64, 4);
         GATE_CFG(64, 256, 2, 4, 64, 3);
-        if (M <= 4096) GATE_CFG(64, 64, 2, 1, 64, 4);
+        if (M <= 4096) {
+            GATE_CFG(64, 64, 2, 1, 64, 4);
+            GATE_CFGK(64, 64, 2, 1, 64, 4, 2);
+            GATE_CFGK(64, 64, 2, 1, 64, 4, 4);
+            GATE_CFGK(64, 128, 2, 2, 64, 4, 2);
+            GATE_CFGK(128, 128, 4, 2, 64, 3, 2);
+        }
         {
             void* Ws = dalloc(256ull * 512 * 2, 1);
             void* Wf = dalloc(256ull * 256 * 2, 1);
