@@ -67,10 +67,11 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
 
 // tanh(f) * sigmoid(g) with two v_exp_f32 and one v_rcp_f32:
 //   a = e^-2f, b = e^-g  ->  (1 - a) / ((1 + a) (1 + b)).
-// f is clamped to +-15 (tanh is +-1 to fp32 beyond +-9.1) and g to >= -40 so a, b stay finite.
+// The exponents are capped at 2^40 so a, b stay finite (tanh is -1 to fp32 long before that);
+// large positive f, g underflow a, b to 0, which is the right limit.
 __device__ __forceinline__ float gated_unit(float f, float g) {
-    const float a = __builtin_amdgcn_exp2f(-2.885390081777927f * fminf(fmaxf(f, -15.0f), 15.0f));
-    const float b = __builtin_amdgcn_exp2f(-1.4426950408889634f * fmaxf(g, -40.0f));
+    const float a = __builtin_amdgcn_exp2f(fminf(-2.885390081777927f * f, 40.0f));
+    const float b = __builtin_amdgcn_exp2f(fminf(-1.4426950408889634f * g, 40.0f));
     return (1.0f - a) * __builtin_amdgcn_rcpf((1.0f + a) * (1.0f + b));
 }
 

@@ -368,12 +368,14 @@ struct TailArgs {
     int L, M, Ch, npt, inverse;
 };
 
-template <int NW>
+// NW waves x 32 rows per workgroup, D ring slots (D-1 chunks in flight), WDB = double-buffered
+// weight fragments (worth it at one wave per SIMD; at two per SIMD the partner wave covers the
+// LDS latency and the registers are needed to stay under 256).
+template <int NW, int D, bool WDB>
 __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     constexpr int W_BYTES = 256 * 128;               // weight chunk: [256 rows][64 k] bf16
     constexpr int O_BYTES = 32 * NW * 128;           // o tile of a phase-1 chunk: [32*NW rows][64 k]
     constexpr int SLOT = W_BYTES + O_BYTES;
-    constexpr int D = 3;                             // ring slots: two chunks in flight + one in use
     constexpr int PWW = 32 / NW, PWO = 4;            // DMA pieces per wave per chunk: weights, o rows
     constexpr int CST = 2560 + 1024;                 // floats: bs | bfin | bz | ez | an[2][4][Ch<=128]
     __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT + CST * 4 + 64];
@@ -441,14 +443,16 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         else if (c2 < nq1 + 4) issue2(c2 - nq1, part);
         else if (c2 < NC) issue3(c2 - nq1 - 4, part);
     };
-    // wait for chunk c (leave chunk c+1 in flight) and cross the barrier
+    // wait for chunk c (chunks c+1 .. c+D-2 may stay in flight) and cross the barrier
     auto step = [&](int c) {
         if (FWN_ABL >= 2) { if (c == 0) FWN_WAIT_VMCNT(0); __builtin_amdgcn_s_barrier(); return; }
-        if (c + 1 >= NC) FWN_WAIT_VMCNT(0);
+        if (D == 2 || c + 1 >= NC) FWN_WAIT_VMCNT(0);
         else if (c + 1 < nq1) FWN_WAIT_VMCNT(PWW + PWO);
         else FWN_WAIT_VMCNT(PWW);
         __builtin_amdgcn_s_barrier();
     };
+    static_assert(D == 2 || D == 3, "ring depth");
+    constexpr int LA = D - 1;                         // refill distance
 
     // Fragment of 32-row tile `t`, k-step kk of a 64-wide chunk: the swizzle depends on the row only
     // through lr, so tile t is an immediate offset t*4096.
@@ -487,28 +491,30 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     };
 
     issue1(0, -1);
-    issue1(1, -1);
+    if (D == 3) issue1(1, -1);
     step(0);
     init_acc(cst);
 
     // ---------------- phase 1: S^T = Ws @ [o_0 | o_1 | ..]^T + bs ----------------
     for (int c = 0; c < nq1; ++c) {
         if (c > 0) step(c);
-        if (FWN_ABL == 1) { refill(c + 2, -1); continue; }
+        if (FWN_ABL == 1) { refill(c + LA, -1); continue; }
         const unsigned char* wb = lds + (c % D) * SLOT;
         const unsigned char* ob = wb + W_BYTES + wave * 4096;
-        ldw(wb, 0, 0);
+        if (WDB) ldw(wb, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const bf16x8 b = *(const bf16x8*)(ob + wfrag[kk]);
-            if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);       // keep the next step's reads ahead of these MFMAs
+            if (WDB) {
+                if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of these MFMAs
+            }
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
-                acc[ct] = mfma32(wf[kk & 1][ct], b, acc[ct]);
-                if (ct == 0) refill(c + 2, kk);
+                acc[ct] = mfma32(WDB ? wf[kk & 1][ct] : WFRAG(wb, ct, kk), b, acc[ct]);
+                if (ct == 0) refill(c + LA, kk);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (WDB) __builtin_amdgcn_sched_barrier(0);
         }
     }
     pack_relu();
@@ -518,19 +524,21 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
         step(nq1 + kc);
-        if (FWN_ABL == 1) { refill(nq1 + kc + 2, -1); continue; }
+        if (FWN_ABL == 1) { refill(nq1 + kc + LA, -1); continue; }
         const unsigned char* wb = lds + ((nq1 + kc) % D) * SLOT;
-        ldw(wb, 0, 0);
+        if (WDB) ldw(wb, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (WDB) {
+                if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int ot = 0; ot < 8; ++ot) {
-                acc[ot] = mfma32(wf[kk & 1][ot], pk[2 * kc + (kk >> 1)][kk & 1], acc[ot]);
-                if (ot == 0) refill(nq1 + kc + 2, kk);
+                acc[ot] = mfma32(WDB ? wf[kk & 1][ot] : WFRAG(wb, ot, kk), pk[2 * kc + (kk >> 1)][kk & 1], acc[ot]);
+                if (ot == 0) refill(nq1 + kc + LA, kk);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (WDB) __builtin_amdgcn_sched_barrier(0);
         }
     }
     pack_relu();
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
         step(nq1 + 4 + kc);
-        refill(nq1 + 4 + kc + 2, -1);
+        refill(nq1 + 4 + kc + LA, -1);
         if (FWN_ABL == 1) continue;
         const unsigned char* wb = lds + ((nq1 + 4 + kc) % D) * SLOT;
 #pragma unroll
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 // ---------------------------------------------------------------------------
 // Host-side launchers (called from the C-ABI in api.hip)
 // ---------------------------------------------------------------------------
-int fwn_tail_rows(int M) { (void)M; return 128; }   // rows per tail workgroup (4 waves x 32 rows)
+int fwn_tail_rows(int M) { return (M + 255) / 256 >= 192 ? 256 : 128; }   // rows per tail workgroup
 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -655,7 +663,7 @@ static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
     } else if (((M + 255) / 256) * (N / 128) >= FILL) {
         RING_LAUNCH(256, 128, 8, 2, 64, 3);
     } else if (((M + 127) / 128) * (N / 128) >= FILL) {
-        RING_LAUNCH(128, 128, 4, 2, 64, 2);
+        RING_LAUNCH(128, 128, 4, 2, 64, 3);
     } else if (((M + 63) / 64) * (N / 128) >= FILL) {
         RING_LAUNCH(64, 128, 2, 2, 64, 4);
     } else {
@@ -707,5 +715,8 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
                      hipStream_t st) {
     TailArgs a{(const bf16*)o, (const bf16*)Ws, bs, (const bf16*)Wf, bfin, (const bf16*)Wz, bz, ez, an,
                xa, xb, partial, o_stride, L, M, Ch, npt, inverse};
-    hipLaunchKernelGGL((tail_kernel<4>), dim3((M + 127) / 128), dim3(256), 0, st, a);
+    if (fwn_tail_rows(M) == 256)
+        hipLaunchKernelGGL((tail_kernel<8, 2, false>), dim3((M + 255) / 256), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((tail_kernel<4, 3, true>), dim3((M + 127) / 128), dim3(256), 0, st, a);
 }

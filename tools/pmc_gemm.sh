@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 R=$PWD
 abl=${1:-0}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFWN_ABL=$abl tools/bench_gemm.hip tf-flowavenet_amd/csrc/flow_kernels.hip -o /tmp/bench_gemm_$abl 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFWN_ABL=$abl tools/bench_gemm.hip -o /tmp/bench_gemm_$abl 2>/dev/null
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/pmc_out
@@ -20,6 +20,7 @@ for r in rows:
     k = (r["Kernel_Name"].split("(")[0].replace("void ", "")[:60], r["Grid_Size"])
     d = agg.setdefault(k, collections.defaultdict(float)); d[r["Counter_Name"]] += float(r["Counter_Value"]); d["_n_" + r["Counter_Name"]] += 1
 for k, d in agg.items():
-    if "Gate" not in k[0] and "tail" not in k[0]: continue
+    import os
+    if os.environ.get("PMC_FILTER", "Gate") not in k[0]: continue
     print(k, {c: round(v / d["_n_" + c]) for c, v in d.items() if not c.startswith("_n_")})
 PY
