@@ -107,9 +107,16 @@ def gate_roofline(model, hp, b, t, iters=30):
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * m * (768 + d.cin) * 512
     ach = flops / sec / 1e12
+    traffic = None      # HBM bytes per launch from the committed PMC profile of this exact launch shape
+    tj = os.path.join(ROOT, "profiles", "r01_gate_traffic.json")
+    if os.path.exists(tj):
+        with open(tj) as f:
+            rec = json.load(f)
+        if rec.get("rows") == m:
+            traffic = rec["traffic_bytes"]
     return {"bound": "mfma", "kernel": "gemm_ring_kernel<256,256,4,4,64,2,GateProb> (block 0 gated dilated layer, fwn_gate)",
             "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-            "traffic": None, "launch_us": sec * 1e6, "flop_per_launch": flops, "rows": m}
+            "traffic": traffic, "launch_us": sec * 1e6, "flop_per_launch": flops, "rows": m}
 
 
 def main():
