@@ -630,7 +630,10 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 // ---------------------------------------------------------------------------
 // Host-side launchers (called from the C-ABI in api.hip)
 // ---------------------------------------------------------------------------
-int fwn_tail_rows(int M) { return (M + 255) / 256 >= 192 ? 256 : 128; }   // rows per tail workgroup
+#ifndef FWN_TAIL256_MIN
+#define FWN_TAIL256_MIN (192 * 256)
+#endif
+int fwn_tail_rows(int M) { return M >= FWN_TAIL256_MIN ? 256 : 128; }   // rows per tail workgroup
 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 

@@ -58,6 +58,9 @@ int main(int argc, char** argv) {
         if (M >= 16128) {
             GATE_CFG(256, 256, 2, 4, 64, 2);
             GATE_CFG(256, 256, 4, 4, 64, 2);
+            GATE_CFG(256, 256, 4, 4, 32, 2);
+            GATE_CFG(256, 256, 4, 4, 32, 3);
+            GATE_CFG(256, 128, 4, 2, 32, 3);
             GATE_CFG(128, 128, 4, 2, 64, 2);
             GATE_CFG(256, 128, 4, 2, 64, 3);
             GATE_CFG(256, 128, 8, 2, 64, 3);
