@@ -42,6 +42,25 @@ __device__ __forceinline__ void buf_load16_lds(srd_t s, uint32_t voff, unsigned 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
 }
 
+// Epilogue stores / loads through a buffer descriptor: rows past the end of the matrix (last
+// tile) fall outside the descriptor and are dropped / read as zero by the hardware range check,
+// so no per-element branch; the per-register row offset rides in the SGPR soffset operand.
+__device__ __forceinline__ void buf_store_bf16(srd_t s, uint32_t voff, uint32_t soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)v), s, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_store_f32(srd_t s, uint32_t voff, uint32_t soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), s, voff, soff, 0);
+}
+__device__ __forceinline__ float buf_load_f32(srd_t s, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load_bf16(srd_t s, uint32_t voff, uint32_t soff) {
+    const unsigned int u = (unsigned int)__builtin_amdgcn_raw_buffer_load_b16(s, voff, soff, 0) << 16;
+    return __builtin_bit_cast(float, u);
+}
+// row offset (in rows) of accumulator register r, without the lane-dependent 4*(lane>>5) part
+__device__ __forceinline__ constexpr int acc_row_c(int r) { return (r & 3) + 8 * (r >> 2); }
+
 // Byte offset of 16-byte chunk `c8` (0..7) of row `row` in a [rows][64] bf16 LDS tile.
 // Two 128-B rows share one 256-B bank row; XOR with (row>>1)&7 spreads 16 rows over the
 // 16 slots of a bank row ("LDS image").

@@ -84,17 +84,18 @@ struct FrontProb {
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         const int lr = lane & 31;
+        const srd_t so = make_srd(hout, (uint32_t)((size_t)M * FWN_HID * 2));
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = ncol0 + ni * 32 + lr;
             const float b = bias[col];
+            const uint32_t voff = (uint32_t)((mrow0 + 4 * (lane >> 5)) * FWN_HID + col) * 2u;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mrow0 + mi * 32 + acc_row(r, lane);
-                    if (row < M) hout[(size_t)row * FWN_HID + col] = (bf16)fmaxf(acc[mi][ni][r] + b, 0.0f);
-                }
+                for (int r = 0; r < 16; ++r)
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
+                                   fmaxf(acc[mi][ni][r] + b, 0.0f));
         }
     }
 };
@@ -202,21 +203,33 @@ struct GateProb {
         const int lr = lane & 31;
         const int ch = (ncol0 >> 7) * 64 + ((ncol0 >> 6) & 1) * 32 + lr;
         const float bfv = bias[ncol0 + lr], bgv = bias[ncol0 + 32 + lr];
+        const srd_t so = make_srd(o, (uint32_t)((size_t)M * FWN_HID * 2));
+        const int rbase = mrow0 + 4 * (lane >> 5);
+        const uint32_t voff = (uint32_t)(rbase * FWN_HID + ch) * 2u;
+        if (P) {    // hoisted conditioning projection (fp32 [M][512], packed-N columns)
+            const srd_t sp = make_srd(P, (uint32_t)((size_t)M * 512 * 4));
+            const uint32_t vp = (uint32_t)(rbase * 512 + ncol0 + lr) * 4u;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            float pf[16], pg[16];
+            for (int mi = 0; mi < MI; ++mi) {
+                float pf[16], pg[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {   // unconditional (clamped) loads: no branch per element
-                const int row = min(mrow0 + mi * 32 + acc_row(r, lane), M - 1);
-                pf[r] = P ? P[(size_t)row * 512 + ncol0 + lr] : 0.0f;
-                pg[r] = P ? P[(size_t)row * 512 + ncol0 + 32 + lr] : 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t sro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 4);
+                    pf[r] = buf_load_f32(sp, vp, sro);
+                    pg[r] = buf_load_f32(sp, vp, sro + 128);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
+                                   gated_unit(acc[mi][0][r] + bfv + pf[r], acc[mi][1][r] + bgv + pg[r]));
             }
+        } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + mi * 32 + acc_row(r, lane);
-                const float f = acc[mi][0][r] + bfv + pf[r], g = acc[mi][1][r] + bgv + pg[r];
-                if (row < M) o[(size_t)row * FWN_HID + ch] = (bf16)gated_unit(f, g);
-            }
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
+                                   gated_unit(acc[mi][0][r] + bfv, acc[mi][1][r] + bgv));
         }
     }
 };
@@ -247,22 +260,23 @@ struct ResProb {
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         const int lr = lane & 31;
+        const uint32_t bytes = (uint32_t)((size_t)M * FWN_HID * 2);
+        const srd_t si = make_srd(hin, bytes), so = make_srd(hout, bytes);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = ncol0 + ni * 32 + lr;
             const float b = bias[col];
+            const uint32_t voff = (uint32_t)((mrow0 + 4 * (lane >> 5)) * FWN_HID + col) * 2u;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 float hv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    hv[r] = (float)hin[(size_t)min(mrow0 + mi * 32 + acc_row(r, lane), M - 1) * FWN_HID + col];
+                    hv[r] = buf_load_bf16(si, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mrow0 + mi * 32 + acc_row(r, lane);
-                    if (row < M)
-                        hout[(size_t)row * FWN_HID + col] = (bf16)((hv[r] + acc[mi][ni][r] + b) * 0.70710678118654752f);
-                }
+                for (int r = 0; r < 16; ++r)
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
+                                   (hv[r] + acc[mi][ni][r] + b) * 0.70710678118654752f);
             }
         }
     }
@@ -293,15 +307,16 @@ struct CondProb {
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         const int lr = lane & 31;
+        const srd_t sp = make_srd(P, (uint32_t)((size_t)M * 512 * 4));
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 2; ++ni) {
+            const uint32_t voff = (uint32_t)((mrow0 + 4 * (lane >> 5)) * 512 + ncol0 + ni * 32 + lr) * 4u;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = mrow0 + mi * 32 + acc_row(r, lane);
-                    if (row < M) P[(size_t)row * 512 + ncol0 + ni * 32 + lr] = acc[mi][ni][r];
-                }
+                for (int r = 0; r < 16; ++r)
+                    buf_store_f32(sp, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 4), acc[mi][ni][r]);
+        }
     }
 };
 
