@@ -32,11 +32,8 @@ __device__ __forceinline__ uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
 __device__ __forceinline__ srd_t make_srd(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ uint4 buf_load16(srd_t s, uint32_t voff) {
-    Pack16 r;
-    r.w = __builtin_amdgcn_raw_buffer_load_b128(s, voff, 0, 0);
-    return r.u;
-}
+// (No VGPR-destination 16-byte buffer load helper on purpose: hipcc / ROCm 7.2 miscompiles element
+// extraction from __builtin_amdgcn_raw_buffer_load_b128 - see DESIGN.md "Toolchain pitfalls".)
 // 64 lanes x 16 B straight into LDS at (wave-uniform) dst + lane*16.
 __device__ __forceinline__ void buf_load16_lds(srd_t s, uint32_t voff, unsigned char* dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s, (lds_ptr_t)dst, 16, voff, 0, 0, 0);

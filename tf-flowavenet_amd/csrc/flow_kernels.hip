@@ -366,6 +366,9 @@ __global__ __launch_bounds__(64 * WM * WN) void cond_batch_kernel(CondBatch cb, 
 // Wfinal / Wzero are packed with their K axis in accumulator-register order
 // (packing.acc_k_perm) so operand element j of lane half h meets the matching k.
 // ---------------------------------------------------------------------------
+#ifndef FWN_DEBUG_SCALAR_APLANE
+#define FWN_DEBUG_SCALAR_APLANE 0
+#endif
 struct TailArgs {
     const bf16* o;        // [L][M][256]
     const bf16* Ws;       // [256][L*256]
@@ -570,29 +573,61 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         refill(nq1 + 4 + kc + LA, -1);
         if (FWN_ABL == 1) continue;
         const unsigned char* wb = lds + ((nq1 + 4 + kc) % D) * SLOT;
+        if (WDB && ntz > 2) {           // wide ZeroConv (Ch > 32): fragments read one k-step ahead
+            ldw(wb, 0, 0);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int tz = 0; tz < 8; ++tz)
-                if (tz < ntz) acc[tz] = mfma32(WFRAG(wb, tz, kk), pk[2 * kc + (kk >> 1)][kk & 1], acc[tz]);
+                for (int tz = 0; tz < 8; ++tz)
+                    if (tz < ntz) acc[tz] = mfma32(wf[kk & 1][tz], pk[2 * kc + (kk >> 1)][kk & 1], acc[tz]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int tz = 0; tz < 8; ++tz)
+                    if (tz < ntz) acc[tz] = mfma32(WFRAG(wb, tz, kk), pk[2 * kc + (kk >> 1)][kk & 1], acc[tz]);
+        }
     }
 
-    // ---------------- affine coupling + ActNorm on the b plane (branch-free loads) ----------------
+    // ---------------- affine coupling + ActNorm on the b plane ----------------
+    // Buffer loads / stores: elements outside the plane (tau >= Ch, rows past M) get an
+    // out-of-range offset, read as 0 and are dropped on store - no branches.
     const float* bzl = cst + 512;
     const float* ezl = cst + 1024;
     const float* an_a = cst + 1536;
     const float* an_b = an_a + 4 * Ch;
+    const uint32_t plane_bytes = (uint32_t)((size_t)a.M * Ch * 4);
+    const srd_t sxb = make_srd(a.xb, plane_bytes), sxa = make_srd(a.xa, plane_bytes);
     float lsum = 0.0f;
+    const bool vec4 = Ch >= 4;          // 4 consecutive channels per accumulator register group
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
         if (pt < a.npt) {
             float xv[16];
+            uint32_t voff[16];
+            if (vec4) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tau = pt * 32 + acc_row(r, lane);
-                const bool ok = tau < Ch && row < a.M;
-                xv[r] = a.xb[ok ? (size_t)row * Ch + tau : 0];
+                for (int g = 0; g < 4; ++g) {
+                    const int tau0 = pt * 32 + 8 * g + 4 * lh;
+                    const bool ok = tau0 < Ch && row < a.M;
+                    const float4 q = *(const float4*)(a.xb + (ok ? (size_t)row * Ch + tau0 : 0));   // clamped
+                    xv[4 * g + 0] = q.x; xv[4 * g + 1] = q.y; xv[4 * g + 2] = q.z; xv[4 * g + 3] = q.w;
+                    voff[4 * g] = ok ? (uint32_t)(row * Ch + tau0) * 4u : FWN_OOB;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tau = pt * 32 + acc_row(r, lane);
+                    const bool ok = tau < Ch && row < a.M;
+                    voff[r] = ok ? (uint32_t)(row * Ch + tau) * 4u : FWN_OOB;
+                    xv[r] = buf_load_f32(sxb, voff[r], 0);
+                }
             }
+            float ov[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = acc_row(r, lane);
@@ -602,31 +637,61 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
                 const int nls = pt * 64 + j, nt = nls + 32;
                 const float ls = (acc[2 * pt][r] + bzl[nls]) * ezl[nls];
                 const float t = (acc[2 * pt + 1][r] + bzl[nt]) * ezl[nt];
-                float outv;
                 if (!a.inverse) {
                     const float yb = (xv[r] + an_b[tc]) * an_b[Ch + tc];              // ActNorm (model.py:86-94)
-                    outv = (yb - t) * expf(-ls);                                      // model.py:134
+                    ov[r] = (yb - t) * __expf(-ls);                                     // model.py:134
                     lsum += ok ? (an_a[3 * Ch + tc] + an_b[3 * Ch + tc] - ls) : 0.0f;  // model.py:135 + :80
                 } else {
-                    const float yb = xv[r] * expf(ls) + t;                            // model.py:156
-                    outv = yb * an_b[2 * Ch + tc] - an_b[tc];                          // ActNorm^-1 (model.py:97-102)
+                    const float yb = xv[r] * __expf(ls) + t;                            // model.py:156
+                    ov[r] = yb * an_b[2 * Ch + tc] - an_b[tc];                         // ActNorm^-1 (model.py:97-102)
                 }
-                if (ok) a.xb[(size_t)row * Ch + tau] = outv;
+            }
+            if (vec4) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4 o4 = {__builtin_bit_cast(unsigned int, ov[4 * g]), __builtin_bit_cast(unsigned int, ov[4 * g + 1]),
+                                      __builtin_bit_cast(unsigned int, ov[4 * g + 2]), __builtin_bit_cast(unsigned int, ov[4 * g + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(o4, sxb, voff[4 * g], 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) buf_store_f32(sxb, voff[r], 0, ov[r]);
             }
         }
     }
-    // a-plane: ActNorm only (the coupling passes in_a through unchanged).
+    // a-plane: ActNorm only (the coupling passes in_a through unchanged); 4 elements per lane per
+    // step when the plane rows allow 16-byte pieces.
     {
-        const int total = 32 * NW * Ch;
+        const int total = 32 * NW * Ch;                  // elements of this workgroup's rows
+        const uint32_t base = (uint32_t)(m0 * Ch) * 4u;
         const int chmask = Ch - 1;
+        if (Ch >= 4 && !FWN_DEBUG_SCALAR_APLANE) {
+            // NOTE: the 16-byte load is a plain (clamped) float4 load, not raw_buffer_load_b128:
+            // hipcc (ROCm 7.2) lowers element extracts of that builtin's result to ONE
+            // buffer_load_dword reused for all four lanes (minimal repro in DESIGN.md).
+            const size_t plane_elems = (size_t)a.M * Ch;
 #pragma unroll 4
-        for (int idx = tid; idx < total; idx += 64 * NW) {
-            const int tau = idx & chmask;
-            const size_t off = (size_t)m0 * Ch + idx;
-            const bool ok = off < (size_t)a.M * Ch;
-            const float v = a.xa[ok ? off : 0];
-            const float w = a.inverse ? (v * an_a[2 * Ch + tau] - an_a[tau]) : ((v + an_a[tau]) * an_a[Ch + tau]);
-            if (ok) a.xa[off] = w;
+            for (int idx = tid * 4; idx < total; idx += 64 * NW * 4) {
+                const size_t e0 = (size_t)m0 * Ch + idx;
+                const bool ok = e0 + 3 < plane_elems;
+                const float4 q = *(const float4*)(a.xa + (ok ? e0 : 0));
+                float f[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tau = (idx + e) & chmask;
+                    f[e] = a.inverse ? (f[e] * an_a[2 * Ch + tau] - an_a[tau]) : ((f[e] + an_a[tau]) * an_a[Ch + tau]);
+                }
+                const u32x4 o4 = {__builtin_bit_cast(unsigned int, f[0]), __builtin_bit_cast(unsigned int, f[1]),
+                                  __builtin_bit_cast(unsigned int, f[2]), __builtin_bit_cast(unsigned int, f[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o4, sxa, base + (uint32_t)idx * 4u, 0, 0);   // past the plane: dropped
+            }
+        } else {
+            for (int idx = tid; idx < total; idx += 64 * NW) {
+                const int tau = idx & chmask;
+                const uint32_t off = base + (uint32_t)idx * 4u;
+                const float v = buf_load_f32(sxa, off, 0);
+                buf_store_f32(sxa, off, 0, a.inverse ? (v * an_a[2 * Ch + tau] - an_a[tau]) : ((v + an_a[tau]) * an_a[Ch + tau]));
+            }
         }
     }
     if (a.partial) {
