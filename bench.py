@@ -141,13 +141,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FWN_BENCH_SHARE_GPU=1 is a plumbing test for boxes with one GPU: every rank uses cuda:0 and the
+    # scalar exchanges go over gloo.  The measured configuration is always one GPU per rank + RCCL.
+    share_gpu = os.environ.get("FWN_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    def allreduce(tensor, op=dist.ReduceOp.SUM):
+        if share_gpu:
+            host = tensor.cpu()
+            dist.all_reduce(host, op=op)
+            tensor.copy_(host)
+        else:
+            dist.all_reduce(tensor, op=op)
 
     hp = default_hparams()
     b, t = args.batch, args.samples
@@ -193,8 +209,9 @@ def main():
                 cur.wait_stream(s_)
             nll = torch.stack(nlls).mean(0)          # equal-size sub-batches: mean of means
             wav = torch.cat(wavs, 0)
-        if world > 1:
-            dist.all_reduce(nll)             # global-batch NLL: the path's only exchange
+        if world > 1:                        # global-batch NLL: the path's only exchange
+            allreduce(nll)                   # (every rank holds the same number of clips)
+            nll = nll / world
         return nll, wav
 
     for _ in range(args.warmup):
@@ -213,7 +230,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        allreduce(tmax, dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(nll).all()) and bool(torch.isfinite(wav).all())
 
