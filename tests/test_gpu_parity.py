@@ -298,3 +298,12 @@ def test_synthesize_cli_file_contract(tmp_path):
     args.output_dir = str(tmp_path / "out2")
     S.synthesize(args, hp)
     assert (tmp_path / "out" / "a.wav").read_bytes() == (tmp_path / "out2" / "a.wav").read_bytes()
+
+
+def test_oversized_call_is_rejected_with_a_message(full_model):
+    """Activation buffers are addressed with 32-bit offsets below 2 GiB: larger calls must fail loudly."""
+    hp, model, x, c, z = full_model
+    big_x = torch.zeros(40, 220672, 1, device="cuda")
+    big_c = torch.zeros(40, 862, 80, device="cuda")
+    with pytest.raises(_lib.FwnError, match="2 GiB"):
+        model.forward(big_x, big_c)

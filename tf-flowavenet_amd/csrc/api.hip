@@ -165,7 +165,8 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
     if (rc) return rc;
     REQUIRE(B > 0 && T > 0 && T % (2 * (int64_t)d->Ch) == 0, "fwn_flow_run: T=%lld not divisible by 2*Ch=%d",
             (long long)T, 2 * d->Ch);
-    REQUIRE(B * T < ((int64_t)1 << 31), "fwn_flow_run: B*T too large");
+    REQUIRE(B * T < ((int64_t)1 << 31) && (int64_t)d->L * (B * T / 2) * 512 < ((int64_t)1 << 31),
+            "fwn_flow_run: B*T too large (2 GiB per activation buffer)");
     REQUIRE(xa && xb && h0 && h1 && o, "fwn_flow_run: null buffer");
     REQUIRE((ca != nullptr) != (P != nullptr), "fwn_flow_run: exactly one of ca / P");
     REQUIRE(!(ddi && inverse), "fwn_flow_run: data-dependent init runs in the forward direction only");
@@ -249,6 +250,11 @@ static int check_model(const fwn_model_desc* m, int64_t B, int64_t T) {
     REQUIRE(T % ((int64_t)1 << m->n_block) == 0, "T=%lld must be a multiple of 2^n_block (model.py:226)",
             (long long)T);
     REQUIRE(B * T < ((int64_t)1 << 31), "B*T too large");
+    // every activation matrix is addressed through a raw buffer descriptor with 32-bit offsets and
+    // an out-of-range sentinel at 2 GiB: the largest one is o = [n_layer][B*T/2][256] bf16.
+    REQUIRE((int64_t)m->n_layer * (B * T / 2) * 512 < ((int64_t)1 << 31) &&
+                B * T * (int64_t)(m->num_mels / 2) * 2 < ((int64_t)1 << 31),
+            "B*T=%lld samples per call exceeds the 2 GiB-per-buffer limit (split the batch)", (long long)(B * T));
     for (int i = 0; i < m->n_block; ++i)
         for (int j = 0; j < m->n_flow; ++j) {
             const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
