@@ -129,7 +129,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cond-mode", type=int, default=0)
     ap.add_argument("--serial", action="store_true", help="forward and inverse on one stream (no overlap)")
-    ap.add_argument("--split", type=int, default=1, help="sub-batches per direction, each on its own stream")
     args = ap.parse_args()
 
     import torch
@@ -178,51 +177,48 @@ def main():
     model.forward(x, c)          # ActNorm data-dependent init on the first batch
     torch.cuda.synchronize()
 
-    # The forward (NLL) and inverse (synthesis) passes of a step are independent, so they are
-    # issued on two HIP streams: the small-M kernels of one pass (late blocks leave most CUs idle)
-    # overlap the MFMA-bound kernels of the other.  --serial puts both on one stream.
-    nsplit = max(1, args.split)
-    assert b % nsplit == 0
-    sb = b // nsplit
-    streams = [torch.cuda.Stream(dev) for _ in range(2 * nsplit)]
-    xs = [x[i * sb:(i + 1) * sb].contiguous() for i in range(nsplit)]
-    cs = [c[i * sb:(i + 1) * sb].contiguous() for i in range(nsplit)]
-    zs = [z[i * sb:(i + 1) * sb].contiguous() for i in range(nsplit)]
+    # The forward (NLL) and inverse (synthesis) passes of a step are independent, and so are
+    # successive steps: each direction gets its own HIP stream and the K steps are enqueued back to
+    # back (joined once, before the clock stops).  The small-M kernels of one pass (late blocks
+    # leave most CUs idle) then overlap the MFMA-bound kernels of the other.  --serial puts
+    # everything on one stream.
+    s_fwd, s_inv = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 
-    def step():
-        cur = torch.cuda.current_stream(dev)
+    def enqueue_step():
         if args.serial:
             log_p, logdet = model.forward(x, c)
-            wav = model.reverse(z, c)
             nll = torch.stack([log_p, logdet])
-        else:
-            for s_ in streams:
-                s_.wait_stream(cur)
-            nlls, wavs = [], []
-            for i in range(nsplit):
-                with torch.cuda.stream(streams[2 * i]):
-                    lp, ld = model.forward(xs[i], cs[i])
-                    nlls.append(torch.stack([lp, ld]))
-                with torch.cuda.stream(streams[2 * i + 1]):
-                    wavs.append(model.reverse(zs[i], cs[i]))
-            for s_ in streams:
-                cur.wait_stream(s_)
-            nll = torch.stack(nlls).mean(0)          # equal-size sub-batches: mean of means
-            wav = torch.cat(wavs, 0)
-        if world > 1:                        # global-batch NLL: the path's only exchange
-            allreduce(nll)                   # (every rank holds the same number of clips)
-            nll = nll / world
+            if world > 1:
+                allreduce(nll)
+                nll = nll / world
+            return nll, model.reverse(z, c)
+        with torch.cuda.stream(s_fwd):
+            log_p, logdet = model.forward(x, c)
+            nll = torch.stack([log_p, logdet])
+            if world > 1:                    # global-batch NLL: the path's only exchange
+                allreduce(nll)               # (every rank holds the same number of clips)
+                nll = nll / world
+        with torch.cuda.stream(s_inv):
+            wav = model.reverse(z, c)
         return nll, wav
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n):
+        cur = torch.cuda.current_stream(dev)
+        s_fwd.wait_stream(cur)
+        s_inv.wait_stream(cur)
+        for _ in range(n):
+            nll, wav = enqueue_step()
+        cur.wait_stream(s_fwd)
+        cur.wait_stream(s_inv)
+        return nll, wav
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nll, wav = step()
+    nll, wav = run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
