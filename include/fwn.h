@@ -76,6 +76,7 @@ typedef struct fwn_flow_desc {
     int32_t npt;         /* ZeroConv pair tiles = max(1, ceil(Ch/32)) */
     int32_t L;           /* n_layer */
     const void* Wfront;  const float* bfront;               /* [256][kfpad], [256]            */
+    const void* Wfront2;                                    /* Ch >= 32 only, else NULL: [256][6*Ch], K = tap*2Ch + (hi|lo)*Ch + tau */
     const void* Wd[FWN_MAX_LAYERS];                         /* [512][768] gate-packed rows     */
     const void* Wc[FWN_MAX_LAYERS];                         /* [512][kcpad]                    */
     const float* bgate[FWN_MAX_LAYERS];                     /* [512] conv bias + cond bias     */
@@ -88,8 +89,11 @@ typedef struct fwn_flow_desc {
 } fwn_flow_desc;
 
 /* ---- stage entry points (K4..K8), exposed so each kernel can be parity-tested alone ---- */
-/* K4 front conv k=3 + ReLU over in_a (modules.py:144,164-165); apply_an: ActNorm on load. */
-int fwn_front(const fwn_flow_desc* d, const float* xa, void* h_out, int M, int Ti, int apply_an, void* stream);
+/* K4 front conv k=3 + ReLU over in_a (modules.py:144,164-165); apply_an: ActNorm on load.
+ * scratch: NULL or [M][256] bf16 (for Ch >= 32 the fp32 state is first laid out as a hi|lo bf16
+ * matrix there so the conv runs on the LDS-DMA ring GEMM; fwn_flow_run lends its second h buffer). */
+int fwn_front(const fwn_flow_desc* d, const float* xa, void* h_out, void* scratch, int M, int Ti, int apply_an,
+              void* stream);
 /* K5 gated dilated layer `layer` (modules.py:113-124).  ca==NULL uses P (precomputed c_a@Wc). */
 int fwn_gate(const fwn_flow_desc* d, int layer, const void* h, const void* ca, const float* P, void* o,
              int M, int Ti, void* stream);

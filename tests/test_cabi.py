@@ -40,7 +40,7 @@ def test_version(lib):
 
 def test_struct_layout_matches_header():
     # 6 int32 + (2 + 5*8 + 7 + 1) pointers
-    assert C.sizeof(_lib.FlowDesc) == 24 + 8 * (2 + 5 * _lib.FWN_MAX_LAYERS + 7 + 1)
+    assert C.sizeof(_lib.FlowDesc) == 24 + 8 * (2 + 5 * _lib.FWN_MAX_LAYERS + 8 + 1)
     assert _lib.ModelDesc.flows.offset % 8 == 0 and _lib.ModelDesc.up_w.offset == 40
 
 
@@ -52,7 +52,7 @@ def test_argument_validation_reports_errors(lib):
     assert b"even" in lib.fwn_last_error()
     assert lib.fwn_pack_bf16(None, None, None, None, 1, 1, 1, 1, None, None) == -1
     d = _lib.FlowDesc()
-    assert lib.fwn_front(C.byref(d), 1 << 20, 1 << 20, 64, 64, 1, None) == -1
+    assert lib.fwn_front(C.byref(d), 1 << 20, 1 << 20, None, 64, 64, 1, None) == -1
     assert b"power of two" in lib.fwn_last_error() or b"flow desc" in lib.fwn_last_error()
     m = _lib.ModelDesc()
     assert lib.fwn_workspace_bytes(C.byref(m), 1, 256) == 0

@@ -23,7 +23,7 @@ class FlowDesc(C.Structure):
     """Mirror of ``fwn_flow_desc`` (include/fwn.h)."""
     _fields_ = [
         ("Ch", i32), ("cin", i32), ("kcpad", i32), ("kfpad", i32), ("npt", i32), ("L", i32),
-        ("Wfront", vp), ("bfront", vp),
+        ("Wfront", vp), ("bfront", vp), ("Wfront2", vp),
         ("Wd", vp * FWN_MAX_LAYERS), ("Wc", vp * FWN_MAX_LAYERS), ("bgate", vp * FWN_MAX_LAYERS),
         ("Wres", vp * FWN_MAX_LAYERS), ("bres", vp * FWN_MAX_LAYERS),
         ("Wskip", vp), ("bskip", vp), ("Wfinal", vp), ("bfinal", vp),
@@ -55,7 +55,7 @@ SIGNATURES = {
     "fwn_split_planes": (C.c_int, [vp, i64, i64, vp, vp]),
     "fwn_merge_planes": (C.c_int, [vp, i64, i64, vp, vp]),
     "fwn_actnorm_ddi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
-    "fwn_front": (C.c_int, [C.POINTER(FlowDesc), vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "fwn_front": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "fwn_gate": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "fwn_res": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, vp]),
     "fwn_cond": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -93,12 +93,14 @@ static int check_desc(const fwn_flow_desc* d) {
     return FWN_OK;
 }
 
-int fwn_front(const fwn_flow_desc* d, const float* xa, void* h_out, int M, int Ti, int apply_an, void* stream) {
+int fwn_front(const fwn_flow_desc* d, const float* xa, void* h_out, void* scratch, int M, int Ti, int apply_an,
+              void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(xa && h_out && M > 0 && Ti > 0 && M % Ti == 0, "fwn_front: bad argument");
     REQUIRE(ALIGNED16(xa) && ALIGNED16(h_out), "fwn_front: buffers must be 16-byte aligned");
-    fwn_launch_front(xa, d->an, d->Wfront, d->bfront, h_out, M, Ti, d->Ch, d->kfpad, apply_an,
+    REQUIRE(!scratch || ALIGNED16(scratch), "fwn_front: scratch must be 16-byte aligned");
+    fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h_out, scratch, M, Ti, d->Ch, d->kfpad, apply_an,
                      (hipStream_t)stream);
     return check_launch("fwn_front");
 }
@@ -174,7 +176,7 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
     const int Ti = (int)(T / (2 * d->Ch));
     const int M = (int)(B * Ti);
     if (ddi) fwn_launch_ddi(xa, xb, M, d->Ch, d->an, st);
-    fwn_launch_front(xa, d->an, d->Wfront, d->bfront, h0, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1, st);
+    fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h0, h1, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1, st);
     void* hc = h0;
     void* hn = h1;
     for (int l = 0; l < d->L; ++l) {

@@ -153,6 +153,69 @@ __global__ __launch_bounds__(256) void front_valu_kernel(FrontProb p) {
     }
 }
 
+// ---- front conv for the late blocks (Ch >= 32) on the ring GEMM -----------------------------------
+// The fp32 plane is first rewritten as a bf16 matrix [M][2*Ch] = (hi | lo) with ActNorm applied
+// (xprep_kernel, HBM-bound, tiny), so the conv becomes three shifted DMA-able K segments like the
+// dilated taps of the gate: K = tap*2Ch + half*Ch + tau against Wfront2.
+__global__ __launch_bounds__(256) void xprep_kernel(const float* __restrict__ xa, const float* __restrict__ an,
+                                                    int M, int Ch, int apply_an, bf16* __restrict__ xhl) {
+    const long total = (long)M * Ch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int tau = (int)(i & (Ch - 1));
+        const long row = i / Ch;
+        float v = xa[i];
+        if (apply_an) v = (v + an[tau]) * an[Ch + tau];
+        const bf16 hi = (bf16)v;
+        xhl[row * 2 * Ch + tau] = hi;
+        xhl[row * 2 * Ch + Ch + tau] = (bf16)(v - (float)hi);
+    }
+}
+
+struct FrontRingProb {
+    static constexpr bool A_DMA = true;
+    static constexpr bool ALLOW_256 = false;
+    const bf16* xhl;      // [M][2*Ch]
+    const bf16* W;        // [256][6*Ch]
+    const float* bias;    // [256]
+    bf16* hout;           // [M][256]
+    int M, Ti, Ch;
+    typedef RowCtxT RowCtx;
+    struct ChunkCtx { int acol, bcol, shift; };
+    template <int BK> __device__ int nchunks() const { return 6 * Ch / BK; }
+    __device__ RowCtx row_ctx(int row) const { return RowCtx{row, row % Ti}; }
+    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const {
+        const int cpt = 2 * Ch / BK;               // chunks per tap
+        const int tap = q / cpt, kc = q % cpt;
+        return ChunkCtx{kc * BK, tap * 2 * Ch + kc * BK, tap - 1};
+    }
+    __device__ srd_t a_srd(const ChunkCtx&) const { return make_srd(xhl, (uint32_t)((size_t)M * 2 * Ch * 2)); }
+    __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
+        const bool ok = rc.row < M && (unsigned)(rc.t + cc.shift) < (unsigned)Ti;
+        return ok ? (uint32_t)((rc.row + cc.shift) * 2 * Ch + cc.acol + c8 * 8) * 2u : FWN_OOB;
+    }
+    __device__ srd_t b_srd(const ChunkCtx&) const { return make_srd(W, (uint32_t)(256u * 6u * Ch * 2u)); }
+    __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
+        return (uint32_t)(n * 6 * Ch + cc.bcol + c8 * 8) * 2u;
+    }
+    template <int MI>
+    __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
+        const int lr = lane & 31;
+        const srd_t so = make_srd(hout, (uint32_t)((size_t)M * FWN_HID * 2));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = ncol0 + ni * 32 + lr;
+            const float b = bias[col];
+            const uint32_t voff = (uint32_t)((mrow0 + 4 * (lane >> 5)) * FWN_HID + col) * 2u;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
+                                   fmaxf(acc[mi][ni][r] + b, 0.0f));
+        }
+    }
+};
+
 // ---- gated dilated layer: o = tanh(f) * sigmoid(g), modules.py:113-124 ---------------------
 // K segments: 3 dilated taps over h (K = 3*256) then the 1x1 conditioning conv over c_a
 // (K = cin), or a precomputed conditioning projection P added in the epilogue.
@@ -754,8 +817,16 @@ static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
     }
 }
 
-void fwn_launch_front(const float* xa, const float* an_a, const void* W, const float* bias, void* hout,
-                      int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st) {
+void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,
+                      void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st) {
+    if (Ch >= 32 && W2 && scratch) {
+        const long total = (long)M * Ch;
+        const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(xprep_kernel, dim3(grid), dim3(256), 0, st, xa, an_a, M, Ch, apply_an, (bf16*)scratch);
+        FrontRingProb rp{(const bf16*)scratch, (const bf16*)W2, bias, (bf16*)hout, M, Ti, Ch};
+        launch_ring(rp, M, 256, st);
+        return;
+    }
     FrontProb p{xa, an_a, (const bf16*)W, bias, (bf16*)hout, M, Ti, Ch, ilog2(Ch), kpad, apply_an};
     if (Ch <= 16) {
         if (M >= 64 * 512) hipLaunchKernelGGL((front_valu_kernel<16>), dim3((M + 63) / 64), dim3(256), 0, st, p);

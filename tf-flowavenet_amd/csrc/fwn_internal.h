@@ -2,8 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-void fwn_launch_front(const float* xa, const float* an_a, const void* W, const float* bias, void* hout,
-                      int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st);
+void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,
+                      void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st);
 void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc,
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, hipStream_t st);
 void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M,

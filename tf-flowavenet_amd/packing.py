@@ -58,6 +58,18 @@ def front_src_k(block: int) -> np.ndarray:
     return out
 
 
+def front2_src_k(block: int) -> np.ndarray:
+    """[6*Ch] -> source row of the (3*Ch, 256) front kernel for the hi|lo layout used when Ch >= 32:
+    K = tap*2Ch + half*Ch + tau (the same weight serves the hi and the lo bf16 half of x)."""
+    ch = 1 << block
+    br = bitrev_table(block)
+    out = np.empty(6 * ch, dtype=np.int32)
+    for tap in range(3):
+        for half in range(2):
+            out[tap * 2 * ch + half * ch: tap * 2 * ch + (half + 1) * ch] = tap * ch + br
+    return out
+
+
 def cond_src_k(block: int, half: int) -> np.ndarray:
     """[kcpad] -> source row of the (cin, 256) conditioning kernel for natural K = tau*half + m'."""
     n = block + 1
@@ -243,6 +255,11 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             wfront = bf16_zeros(FILTER, kfpad)
             pack(wp + "/Conv_front", f_src_k, ident256, kfpad, FILTER, wfront, kfpad)
             d.Wfront = wfront.data_ptr()
+            if ch >= 32:
+                f2 = dev_i32(("front2", i), lambda: front2_src_k(i))
+                wfront2 = bf16_zeros(FILTER, 6 * ch)
+                pack(wp + "/Conv_front", f2, ident256, 6 * ch, FILTER, wfront2, 6 * ch)
+                d.Wfront2 = wfront2.data_ptr()
             d.bfront = dev_f32(hostp[wp + "/Conv_front/bias"]).data_ptr()
 
             wskip = bf16_zeros(FILTER, L * FILTER)
