@@ -83,12 +83,24 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
 
 // tanh(f) * sigmoid(g) with two v_exp_f32 and one v_rcp_f32:
 //   a = e^-2f, b = e^-g  ->  (1 - a) / ((1 + a) (1 + b)).
-// The exponents are capped at 2^40 so a, b stay finite (tanh is -1 to fp32 long before that);
+// a is capped at 2^40 so it stays finite (tanh is -1 to fp32 long before that);
 // large positive f, g underflow a, b to 0, which is the right limit.
-__device__ __forceinline__ float gated_unit(float f, float g) {
-    const float a = __builtin_amdgcn_exp2f(fminf(-2.885390081777927f * f, 40.0f));
-    const float b = __builtin_amdgcn_exp2f(fminf(-1.4426950408889634f * g, 40.0f));
-    return (1.0f - a) * __builtin_amdgcn_rcpf((1.0f + a) * (1.0f + b));
+// The gate weights and biases arrive pre-multiplied (packing.py) so the accumulators already hold
+// the exponents: u = -2 log2(e) f, v = -log2(e) g.  Two outputs per call so the adds and
+// multiplies pair up into v_pk_*_f32 (the epilogue is VALU-bound: 3 quarter-rate ops per output).
+// b may overflow to +inf (-> rcp 0 -> 0, the right limit while a is finite), so only u is capped.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gated_unit2(f32x2 u, f32x2 v) {
+    f32x2 a, b;
+    a.x = __builtin_amdgcn_exp2f(fminf(u.x, 40.0f));
+    a.y = __builtin_amdgcn_exp2f(fminf(u.y, 40.0f));
+    b.x = __builtin_amdgcn_exp2f(v.x);
+    b.y = __builtin_amdgcn_exp2f(v.y);
+    const f32x2 den = (1.0f + a) * (1.0f + b);
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(den.x);
+    r.y = __builtin_amdgcn_rcpf(den.y);
+    return (1.0f - a) * r;
 }
 
 __device__ __forceinline__ float fast_sigmoid(float x) {

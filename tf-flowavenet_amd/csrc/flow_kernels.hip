@@ -197,6 +197,7 @@ struct FrontRingProb {
     __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
         return (uint32_t)(n * 6 * Ch + cc.bcol + c8 * 8) * 2u;
     }
+    __device__ float acc_init(int) const { return 0.0f; }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         const int lr = lane & 31;
@@ -259,13 +260,13 @@ struct GateProb {
         const int ldb = cc.cond ? kcpad : 3 * FWN_HID;
         return (uint32_t)(n * ldb + cc.bcol + c8 * 8) * 2u;
     }
+    __device__ float acc_init(int col) const { return bias[col]; }   // packed-N order, like the columns
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         // packed-N: ncol0 = nb*128 + wn*64; columns [ncol0, +32) = filter, [+32, +64) = gate of
         // channels nb*64 + wn*32 + lr.
         const int lr = lane & 31;
         const int ch = (ncol0 >> 7) * 64 + ((ncol0 >> 6) & 1) * 32 + lr;
-        const float bfv = bias[ncol0 + lr], bgv = bias[ncol0 + 32 + lr];
         const srd_t so = make_srd(o, (uint32_t)((size_t)M * FWN_HID * 2));
         const int rbase = mrow0 + 4 * (lane >> 5);
         const uint32_t voff = (uint32_t)(rbase * FWN_HID + ch) * 2u;
@@ -282,17 +283,24 @@ struct GateProb {
                     pg[r] = buf_load_f32(sp, vp, sro + 128);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
-                                   gated_unit(acc[mi][0][r] + bfv + pf[r], acc[mi][1][r] + bgv + pg[r]));
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 y = gated_unit2(
+                        f32x2{acc[mi][0][r], acc[mi][0][r + 1]} + f32x2{pf[r], pf[r + 1]},
+                        f32x2{acc[mi][1][r], acc[mi][1][r + 1]} + f32x2{pg[r], pg[r + 1]});
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2), y.x);
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r + 1)) * FWN_HID * 2), y.y);
+                }
             }
         } else {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
-                                   gated_unit(acc[mi][0][r] + bfv, acc[mi][1][r] + bgv));
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 y = gated_unit2(f32x2{acc[mi][0][r], acc[mi][0][r + 1]},
+                                                f32x2{acc[mi][1][r], acc[mi][1][r + 1]});
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2), y.x);
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r + 1)) * FWN_HID * 2), y.y);
+                }
         }
     }
 };
@@ -320,6 +328,7 @@ struct ResProb {
     __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
         return (uint32_t)(n * FWN_HID + cc.k0 + c8 * 8) * 2u;
     }
+    __device__ float acc_init(int) const { return 0.0f; }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         const int lr = lane & 31;
@@ -367,6 +376,7 @@ struct CondProb {
     __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
         return (uint32_t)(n * kcpad + cc.k0 + c8 * 8) * 2u;
     }
+    __device__ float acc_init(int) const { return 0.0f; }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         const int lr = lane & 31;

@@ -35,7 +35,8 @@ struct RingGeom {
 
 // Developer ablation switch (tools/bench_gemm.hip builds with -DFWN_ABL=n; the product is 0):
 //   1 = no MFMA/ds_read (DMA + waits + barriers only), 2 = DMA issued only in the prologue
-//   (MFMA on stale LDS), 3 = no DMA at all and no waits.
+//   (MFMA on stale LDS), 3 = no DMA at all and no waits, 4 = 3 without the epilogue,
+//   5 = 4 without the per-chunk barrier.
 #ifndef FWN_ABL
 #define FWN_ABL 0
 #endif
@@ -115,13 +116,17 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         for (int j = 0; j < PW; ++j) issue_piece(cc, q, j);
     };
 
+    // accumulators start from the problem's per-column constant (the bias, where the epilogue would
+    // otherwise add it per element); with split-K only the first wave group carries it
     f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int ni = 0; ni < 2; ++ni) {
+        const float c0 = wk == 0 ? p.acc_init(n0 + wn * 64 + ni * 32 + lr) : 0.0f;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = c0;
+    }
 
     // fragment addresses: the swizzle sees only lr (32-row tiles preserve the low row bits)
     // (indexed by this wave's own k-step counter ki: k-step wk + ki*KSP of the chunk)
@@ -142,7 +147,7 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         const int pending = min(nq, q + D - 1) - (q + 1);
         if (FWN_ABL < 2) wait_vmcnt_le<PW>(pending);
         else if (q == 0) FWN_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
+        if (FWN_ABL != 5) __builtin_amdgcn_s_barrier();
         // The refill of the slot freed by this barrier (chunk q+D-1) is spread over the k-steps,
         // so every DMA issue (~100 cycles of this wave's issue time) hides under MFMAs in flight.
         const bool refill = FWN_ABL < 2 && q + D - 1 < nq;
@@ -208,6 +213,17 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] += src[((mi * 2 + ni) * 16 + r) * 64];
         }
+    }
+    if (FWN_ABL >= 4) {     // ablation: keep the accumulators live without the epilogue
+        float sacc = 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[mi][ni][r];
+        if (sacc == 12345.678f) p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+        return;
     }
     p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
 }

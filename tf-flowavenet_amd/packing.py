@@ -23,6 +23,9 @@ from . import _lib
 from .weights import FILTER, flow_prefix
 
 GATE_N = 2 * FILTER  # filter + gate output channels
+# tanh(f) * sigmoid(g) = (1 - a) / ((1 + a)(1 + b)), a = 2^(-2 log2(e) f), b = 2^(-log2(e) g):
+# the packed filter / gate rows and biases are pre-multiplied by these (csrc/common.h gated_unit2).
+GATE_MUL = (-2.0 * 1.4426950408889634, -1.4426950408889634)
 
 
 def bitrev(v: int, nbits: int) -> int:
@@ -209,8 +212,9 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
     gate_rows = [dev_i32("gate_rows%d" % s, lambda s=s: np.where(fg == s, gch, -1)) for s in (0, 1)]
     scale_buf = torch.empty(FILTER, dtype=torch.float32, device=dev)
 
-    def pack(name, src_k, src_n, k_dst, n_dst, out, ld_dst, col_off=0, weight_norm=True):
-        """Pack params[name + '/kernel'] into out[:, col_off: col_off + k_dst]."""
+    def pack(name, src_k, src_n, k_dst, n_dst, out, ld_dst, col_off=0, weight_norm=True, mul=None):
+        """Pack params[name + '/kernel'] into out[:, col_off: col_off + k_dst]; ``mul`` scales every
+        output channel (folded into the weight-norm scale before the bf16 rounding)."""
         def up(x):
             if isinstance(x, torch.Tensor):
                 return x.to(device=dev, dtype=torch.float32).contiguous()
@@ -224,7 +228,11 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             g = up(params[name + "/g"])
             _lib.check(lib.fwn_wn_scale(v.data_ptr(), g.data_ptr(), k_src, n_src, scale_buf.data_ptr(), stream),
                        "fwn_wn_scale")
+            if mul is not None:
+                scale_buf.mul_(mul)
             sc = scale_buf.data_ptr()
+        elif mul is not None:
+            raise ValueError("mul needs weight_norm")
         _lib.check(lib.fwn_pack_bf16(v.data_ptr(), sc, src_k.data_ptr(), src_n.data_ptr(), n_src, k_dst, n_dst,
                                      ld_dst, out.data_ptr() + 2 * col_off, stream), "fwn_pack_bf16")
         # v / g are freed by the caching allocator only after the stream passes this point
@@ -267,15 +275,17 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             for l in range(L):
                 rp = "%s/ResBlock_%d" % (wp, l)
                 wd = bf16_zeros(GATE_N, 3 * FILTER)
-                pack(rp + "/Conv_filter", ident768, gate_rows[0], 3 * FILTER, GATE_N, wd, 3 * FILTER)
-                pack(rp + "/Conv_gate", ident768, gate_rows[1], 3 * FILTER, GATE_N, wd, 3 * FILTER)
+                # filter / gate rows carry the exponent scales of tanh / sigmoid (GATE_MUL) so the
+                # gate epilogue feeds its accumulators straight into exp2
+                pack(rp + "/Conv_filter", ident768, gate_rows[0], 3 * FILTER, GATE_N, wd, 3 * FILTER, mul=GATE_MUL[0])
+                pack(rp + "/Conv_gate", ident768, gate_rows[1], 3 * FILTER, GATE_N, wd, 3 * FILTER, mul=GATE_MUL[1])
                 wc = wc_blk[j, l]
-                pack(rp + "/filter_conv_c", c_src_k, gate_rows[0], kcpad, GATE_N, wc, kcpad)
-                pack(rp + "/gate_conv_c", c_src_k, gate_rows[1], kcpad, GATE_N, wc, kcpad)
-                bsum = [np.asarray(hostp[rp + "/Conv_filter/bias"], np.float32)
-                        + np.asarray(hostp[rp + "/filter_conv_c/bias"], np.float32),
-                        np.asarray(hostp[rp + "/Conv_gate/bias"], np.float32)
-                        + np.asarray(hostp[rp + "/gate_conv_c/bias"], np.float32)]
+                pack(rp + "/filter_conv_c", c_src_k, gate_rows[0], kcpad, GATE_N, wc, kcpad, mul=GATE_MUL[0])
+                pack(rp + "/gate_conv_c", c_src_k, gate_rows[1], kcpad, GATE_N, wc, kcpad, mul=GATE_MUL[1])
+                bsum = [GATE_MUL[0] * (np.asarray(hostp[rp + "/Conv_filter/bias"], np.float64)
+                                       + np.asarray(hostp[rp + "/filter_conv_c/bias"], np.float64)),
+                        GATE_MUL[1] * (np.asarray(hostp[rp + "/Conv_gate/bias"], np.float64)
+                                       + np.asarray(hostp[rp + "/gate_conv_c/bias"], np.float64))]
                 bg = np.where(fg == 0, bsum[0][gch], bsum[1][gch])
                 d.Wd[l] = wd.data_ptr()
                 d.Wc[l] = wc.data_ptr()

@@ -60,6 +60,8 @@ int main(int argc, char** argv) {
             GATE_CFG(256, 256, 4, 4, 64, 2);
             GATE_CFG(256, 256, 4, 4, 32, 2);
             GATE_CFG(256, 256, 4, 4, 32, 3);
+            GATE_CFG(256, 256, 4, 4, 32, 4);
+            GATE_CFG(256, 256, 4, 4, 32, 5);
             GATE_CFG(256, 128, 4, 2, 32, 3);
             GATE_CFG(128, 128, 4, 2, 64, 2);
             GATE_CFG(256, 128, 4, 2, 64, 3);
