@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cond-mode", type=int, default=0)
     ap.add_argument("--serial", action="store_true", help="forward and inverse on one stream (no overlap)")
+    ap.add_argument("--lanes", type=int, default=1, help="HIP streams per direction (successive steps alternate)")
     args = ap.parse_args()
 
     import torch
@@ -182,9 +183,13 @@ def main():
     # back (joined once, before the clock stops).  The small-M kernels of one pass (late blocks
     # leave most CUs idle) then overlap the MFMA-bound kernels of the other.  --serial puts
     # everything on one stream.
-    s_fwd, s_inv = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    lanes_f = [torch.cuda.Stream(dev) for _ in range(args.lanes)]
+    lanes_i = [torch.cuda.Stream(dev) for _ in range(args.lanes)]
+    step_no = [0]
 
     def enqueue_step():
+        s_fwd, s_inv = lanes_f[step_no[0] % args.lanes], lanes_i[step_no[0] % args.lanes]
+        step_no[0] += 1
         if args.serial:
             log_p, logdet = model.forward(x, c)
             nll = torch.stack([log_p, logdet])
@@ -204,12 +209,12 @@ def main():
 
     def run_steps(n):
         cur = torch.cuda.current_stream(dev)
-        s_fwd.wait_stream(cur)
-        s_inv.wait_stream(cur)
+        for st in lanes_f + lanes_i:
+            st.wait_stream(cur)
         for _ in range(n):
             nll, wav = enqueue_step()
-        cur.wait_stream(s_fwd)
-        cur.wait_stream(s_inv)
+        for st in lanes_f + lanes_i:
+            cur.wait_stream(st)
         return nll, wav
 
     run_steps(args.warmup)

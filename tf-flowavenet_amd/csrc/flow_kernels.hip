@@ -305,6 +305,8 @@ struct GateProb {
     }
 };
 
+#include "gate_halo.h"
+
 // ---- residual 1x1: h' = (h + res_conv(o)) * sqrt(0.5), modules.py:126-128 ------------------
 struct ResProb {
     static constexpr bool A_DMA = true;
@@ -850,6 +852,10 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, hipStream_t st) {
     GateProb p{(const bf16*)h, (const bf16*)ca, P, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o,
                M, Ti, dil, cin, kcpad};
+    if (dil <= FWN_HALO_MAXDIL && ((M + 255) / 256) * 2 >= 192) {   // same fill rule as launch_ring's 256 tile
+        hipLaunchKernelGGL((gate_halo_kernel<GateProb>), dim3(((M + 255) / 256) * 2), dim3(1024), 0, st, p, 2);
+        return;
+    }
     launch_ring(p, M, 512, st);
 }
 

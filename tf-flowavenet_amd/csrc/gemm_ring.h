@@ -40,6 +40,8 @@ struct RingGeom {
 #ifndef FWN_ABL
 #define FWN_ABL 0
 #endif
+// 6 = everything but the epilogue
+#define FWN_ABL_DMA (FWN_ABL < 2 || FWN_ABL == 6)
 #ifndef FWN_SETPRIO
 #define FWN_SETPRIO 0
 #endif
@@ -145,12 +147,12 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
     for (int q = 0; q < nq; ++q) {
         // chunks issued so far: min(nq, q + D - 1); those after q may stay in flight
         const int pending = min(nq, q + D - 1) - (q + 1);
-        if (FWN_ABL < 2) wait_vmcnt_le<PW>(pending);
+        if (FWN_ABL_DMA) wait_vmcnt_le<PW>(pending);
         else if (q == 0) FWN_WAIT_VMCNT(0);
         if (FWN_ABL != 5) __builtin_amdgcn_s_barrier();
         // The refill of the slot freed by this barrier (chunk q+D-1) is spread over the k-steps,
         // so every DMA issue (~100 cycles of this wave's issue time) hides under MFMAs in flight.
-        const bool refill = FWN_ABL < 2 && q + D - 1 < nq;
+        const bool refill = FWN_ABL_DMA && q + D - 1 < nq;
         typename Prob::ChunkCtx ccn = p.template chunk_ctx<BK>(refill ? q + D - 1 : 0);
         if (FWN_ABL == 1) {
             if (refill) issue(q + D - 1);

@@ -56,12 +56,14 @@ int main(int argc, char** argv) {
         const double flops = 2.0 * M * (768.0 + (hoist ? 0 : cin)) * 512;
         printf("block %d  M=%d K=%d\n", blk, M, 768 + (hoist ? 0 : cin));
         if (M >= 16128) {
+            timeit("gate halo 256x256", flops, [&] {
+                hipLaunchKernelGGL((gate_halo_kernel<GateProb>), dim3(((M + 255) / 256) * 2), dim3(1024), 0, 0, p, 2); });
             GATE_CFG(256, 256, 2, 4, 64, 2);
             GATE_CFG(256, 256, 4, 4, 64, 2);
             GATE_CFG(256, 256, 4, 4, 32, 2);
             GATE_CFG(256, 256, 4, 4, 32, 3);
-            GATE_CFG(256, 256, 4, 4, 32, 4);
-            GATE_CFG(256, 256, 4, 4, 32, 5);
+            GATE_CFG(128, 256, 2, 4, 32, 3);
+            GATE_CFG(128, 256, 2, 4, 32, 2);
             GATE_CFG(256, 128, 4, 2, 32, 3);
             GATE_CFG(128, 128, 4, 2, 64, 2);
             GATE_CFG(256, 128, 4, 2, 64, 3);
