@@ -852,8 +852,15 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, hipStream_t st) {
     GateProb p{(const bf16*)h, (const bf16*)ca, P, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o,
                M, Ti, dil, cin, kcpad};
-    if (dil <= FWN_HALO_MAXDIL && ((M + 255) / 256) * 2 >= 192) {   // same fill rule as launch_ring's 256 tile
-        hipLaunchKernelGGL((gate_halo_kernel<GateProb>), dim3(((M + 255) / 256) * 2), dim3(1024), 0, st, p, 2);
+    const int t256 = (M + 255) / 256;
+    if (dil <= FWN_HALO_MAXDIL && t256 * 4 >= 192) {
+        // Tap-sharing tiles (gate_halo.h) for the MFMA/L2-bound sizes.  On warm caches they also win at
+        // the small blocks (tools/bench_gemm.hip), but inside a pass every flow's weights arrive cold
+        // from HBM and the deeper plain ring hides that better there (rocprof, in situ).
+        if (t256 * 2 >= 192)
+            hipLaunchKernelGGL((gate_halo_kernel<256, 256, GateProb>), dim3(t256 * 2), dim3(1024), 0, st, p, 2);
+        else
+            hipLaunchKernelGGL((gate_halo_kernel<256, 128, GateProb>), dim3(t256 * 4), dim3(1024), 0, st, p, 4);
         return;
     }
     launch_ring(p, M, 512, st);

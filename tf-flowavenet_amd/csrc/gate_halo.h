@@ -1,4 +1,4 @@
-// Gated dilated layer, 256 x 256 tile, with the three taps sharing one staged activation tile.
+// Gated dilated layer with the three taps sharing one staged activation tile.
 //
 // The ring GEMM (gemm_ring.h) treats the k=3 dilated conv as K = 3 x 256 and stages the same h
 // rows three times, shifted by the dilation.  At 256-row tiles the gate is bound by L2 -> LDS
@@ -17,11 +17,16 @@
 
 #define FWN_HALO_MAXDIL 3
 
-template <class Prob>
-__global__ __launch_bounds__(1024) void gate_halo_kernel(Prob p, int ntn) {
+// Tile BM x BN with BM / 16 waves (so every wave stages 2 activation pieces per slice, wave 0 the
+// odd one) laid out (NWV / WN) x WN, WN = BN / 64.
+template <int BM, int BN, class Prob>
+__global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
     using G = RingGeom<64>;
-    constexpr int BM = 256, BN = 256, WN = 4, NWV = 16, MI = 2;
-    constexpr int AP = 33;                                   // 8-row pieces per activation slice
+    constexpr int NWV = BM / 16, WN = BN / 64, WM = NWV / WN, MI = BM / (32 * WM);
+    constexpr int PB = (BN / 8) / NWV;                       // weight pieces per wave per chunk
+    static_assert(WM * WN == NWV && MI * 32 * WM == BM && PB * NWV * 8 == BN && PB <= 4, "bad tile");
+    constexpr int AP = BM / 8 + 1;                           // 8-row pieces per activation slice
+    static_assert(AP * 8 > BM + 2 * FWN_HALO_MAXDIL, "the zero row must lie beyond the halo");
     constexpr int A_BYTES = AP * 1024, B_BYTES = BN * G::RB;
     constexpr int ZROW = AP * 8 - 1;                         // never staged: reads as zero
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * A_BYTES + 2 * B_BYTES];
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(1024) void gate_halo_kernel(Prob p, int ntn) {
     // wave + 16 j (j < 2)
     // (conditioning addresses are recomputed at each issue: only 2-5 of the steps use them and the
     // conv loop has no registers to spare at 128 VGPRs)
-    uint32_t ah[3], bd[2];
+    uint32_t ah[3], bd[PB];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int jrow = 8 * (wave + NWV * j) + (lane >> 3);
@@ -52,7 +57,11 @@ __global__ __launch_bounds__(1024) void gate_halo_kernel(Prob p, int ntn) {
         const int g = m0 - dil + jrow;
         const bool ok = jrow < BM + 2 * dil && (unsigned)g < (unsigned)M;
         ah[j] = ok ? (uint32_t)(g * FWN_HID + c * 8) * 2u : FWN_OOB;
-        if (j < 2) bd[j] = (uint32_t)((n0 + jrow) * 3 * FWN_HID + c * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int jrow = 8 * (wave + NWV * j) + (lane >> 3);
+        bd[j] = (uint32_t)((n0 + jrow) * 3 * FWN_HID + ((lane & 7) ^ ((jrow >> 1) & 7)) * 8) * 2u;
     }
     const uint32_t hbytes = (uint32_t)((size_t)M * FWN_HID * 2);
     const uint32_t cbytes = (uint32_t)((size_t)M * cin * 2);
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(1024) void gate_halo_kernel(Prob p, int ntn) {
     // tap row leaves the clip read the zero row.  The conditioning chunks sit at slot row i.
     int rb[3][MI], xv[3];
     {
-        const int i0 = wm * 64 + lr;
+        const int i0 = wm * 32 * MI + lr;
 #pragma unroll
         for (int tap = 0; tap < 3; ++tap) {
             const int row = i0 + tap * dil;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(1024) void gate_halo_kernel(Prob p, int ntn) {
         auto ldfrag = [&](int ki, int sb) {
             const int ko = (ki * 32) ^ x;
             af[sb][0] = *(const bf16x8*)(la + rb0 + ko);
-            af[sb][1] = *(const bf16x8*)(la + rb1 + ko);
+            if constexpr (MI > 1) af[sb][1] = *(const bf16x8*)(la + rb1 + ko);
             bf_[sb][0] = *(const bf16x8*)(lb + bfr[ki]);
             bf_[sb][1] = *(const bf16x8*)(lb + bfr[ki] + 32 * G::RB);
         };
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(1024) void gate_halo_kernel(Prob p, int ntn) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) issueA_conv(0, j);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) issueB(0, j);
+    for (int j = 0; j < PB; ++j) issueB(0, j);
 
     // Per step the wave issues [weight piece, weight piece, activation piece] in that order, so
     // "all but the newest one" (vmcnt(1)) leaves only the activation piece of a later slice in flight.
@@ -161,31 +170,30 @@ __global__ __launch_bounds__(1024) void gate_halo_kernel(Prob p, int ntn) {
             else FWN_WAIT_VMCNT(0);
             __builtin_amdgcn_s_barrier();
             const unsigned char* lb = ldsB + (s & 1) * B_BYTES;
-            mma_step(la, lb, rb[tap][0], rb[tap][1], xv[tap], [&](int ki) {
-                if (ki < 2) {
-                    if (s + 1 < S) issueB(s + 1, ki);
-                } else if (ki == 2) {
+            mma_step(la, lb, rb[tap][0], rb[tap][MI - 1], xv[tap], [&](int ki) {
+                if (ki < PB && s + 1 < S) issueB(s + 1, ki);
+                if (ki == (PB < 3 ? 2 : 3)) {        // after this step's weight pieces
                     if (a_next_conv) issueA_conv(kc + 1, tap);
                     else if (a_next_cond && tap < 2) issueA_cond(0, tap);
                 }
             });
         }
     }
-    const int ic = wm * 64 + lr;                     // conditioning chunks sit at slot row i, no mask
+    const int ic = wm * 32 * MI + lr;                // conditioning chunks sit at slot row i, no mask
     const int xc = (lh ^ ((ic >> 1) & 7)) << 4;
-    const int rbc[MI] = {ic * G::RB, (ic + 32) * G::RB};
+    const int rbc[2] = {ic * G::RB, (ic + 32) * G::RB};
     for (int qc = 0; qc < ncond; ++qc, ++s) {
         FWN_WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();
         const unsigned char* la = ldsA + (qc & 1) * A_BYTES;
         const unsigned char* lb = ldsB + (s & 1) * B_BYTES;
-        mma_step(la, lb, rbc[0], rbc[1], xc, [&](int ki) {
-            if (ki < 2) {
-                if (s + 1 < S) issueB(s + 1, ki);
-            } else if (qc + 1 < ncond) {
-                issueA_cond(qc + 1, ki - 2);
+        mma_step(la, lb, rbc[0], rbc[MI - 1], xc, [&](int ki) {
+            if (ki < PB && s + 1 < S) issueB(s + 1, ki);
+            if (ki == 3 && qc + 1 < ncond) {
+                issueA_cond(qc + 1, 0);
+                issueA_cond(qc + 1, 1);
             }
         });
     }
-    p.template epilogue<MI>(acc, m0 + wm * 64, n0 + wn * 64, lane);
+    p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
 }

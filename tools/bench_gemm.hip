@@ -55,9 +55,16 @@ int main(int argc, char** argv) {
         GateProb p{(const bf16*)h, hoist ? nullptr : (const bf16*)ca, hoist ? P : nullptr, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o, M, Ti, 1, cin, kcpad};
         const double flops = 2.0 * M * (768.0 + (hoist ? 0 : cin)) * 512;
         printf("block %d  M=%d K=%d\n", blk, M, 768 + (hoist ? 0 : cin));
+#define HALO_CFG(BM, BN)                                                                                  \
+    timeit("gate halo " #BM "x" #BN, flops, [&] {                                                         \
+        hipLaunchKernelGGL((gate_halo_kernel<BM, BN, GateProb>), dim3(((M + BM - 1) / BM) * (512 / BN)),  \
+                           dim3(BM * 4), 0, 0, p, 512 / BN); })
+        if (M >= 16128) HALO_CFG(256, 256);
+        HALO_CFG(256, 128);
+        HALO_CFG(128, 256);
+        HALO_CFG(128, 128);
+        HALO_CFG(64, 128);
         if (M >= 16128) {
-            timeit("gate halo 256x256", flops, [&] {
-                hipLaunchKernelGGL((gate_halo_kernel<GateProb>), dim3(((M + 255) / 256) * 2), dim3(1024), 0, 0, p, 2); });
             GATE_CFG(256, 256, 2, 4, 64, 2);
             GATE_CFG(256, 256, 4, 4, 64, 2);
             GATE_CFG(256, 256, 4, 4, 32, 2);
