@@ -123,6 +123,13 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
                  void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
                  void* stream);
 
+/* ---- mel front-end (preprocessing.py:58-69; librosa.feature.melspectrogram semantics) ----
+ * wav [B][T] fp32 -> mel [B][1 + T/hop][n_mels] in [0, 1]: centred STFT (reflect padding, `window`
+ * [n_fft], power 2), `fb` [n_mels][n_fft/2 + 1] filterbank, 20 log10(max(1e-4, .)) - ref_level_db,
+ * then clip((. - min_level_db) / -min_level_db, 0, 1).  n_fft a power of two, T > n_fft / 2. */
+int fwn_mel_spectrogram(const float* wav, int64_t B, int64_t T, const float* window, const float* fb, int n_fft,
+                        int hop, int n_mels, float ref_level_db, float min_level_db, float* mel, void* stream);
+
 /* ---- K9: prior + log-det finalisation (model.py:342-347) ----
  * out2[0] = mean(0.5(-log 2pi - z^2)) over n = B*T plane elements, out2[1] = sum(partial)/(B*T). */
 int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_partial, float* out2,

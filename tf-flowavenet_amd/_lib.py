@@ -65,6 +65,7 @@ SIGNATURES = {
     "fwn_flow_run": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,
                                C.c_int, vp]),
     "fwn_prior_logp": (C.c_int, [vp, i64, vp, C.c_int, vp, vp]),
+    "fwn_mel_spectrogram": (C.c_int, [vp, i64, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
     "fwn_grad_norm_partials": (C.c_int, [i64]),
     "fwn_grad_norm": (C.c_int, [vp, i64, C.c_float, vp, vp, vp]),
     "fwn_clip_adam": (C.c_int, [vp, vp, vp, vp, i64, vp, C.c_float, C.c_float, C.c_float, i64, C.c_float,

@@ -200,6 +200,19 @@ int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_p
     return check_launch("fwn_prior_logp");
 }
 
+// ---- mel front-end (the data format on the input side of the path) ------------------------------
+int fwn_mel_spectrogram(const float* wav, int64_t B, int64_t T, const float* window, const float* fb, int n_fft,
+                        int hop, int n_mels, float ref_level_db, float min_level_db, float* mel, void* stream) {
+    REQUIRE(wav && window && fb && mel, "fwn_mel_spectrogram: null pointer");
+    REQUIRE(n_fft >= 32 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0, "fwn_mel_spectrogram: n_fft=%d must be a power of two in [32, 4096]", n_fft);
+    REQUIRE(B > 0 && B < 65536 && hop > 0 && n_mels > 0, "fwn_mel_spectrogram: bad shape");
+    REQUIRE(T > n_fft / 2, "fwn_mel_spectrogram: T=%lld must exceed n_fft/2 (reflect padding)", (long long)T);
+    REQUIRE(min_level_db < 0.0f, "fwn_mel_spectrogram: min_level_db must be negative");
+    fwn_launch_mel(wav, (long)B, (long)T, window, fb, n_fft, hop, n_mels, ref_level_db, min_level_db, mel,
+                   (hipStream_t)stream);
+    return check_launch("fwn_mel_spectrogram");
+}
+
 // ---- data-parallel optimiser step -------------------------------------------------------------
 int fwn_grad_norm_partials(int64_t n) { return fwn_sqnorm_blocks((long)n); }
 

@@ -270,6 +270,60 @@ void fwn_launch_prior(const float* planes, long n, const float* partial, int n_p
     hipLaunchKernelGGL(prior_kernel, dim3(1), dim3(1024), 0, st, planes, n, partial, n_partial, inv_bt, out2);
 }
 
+// ---- mel front-end: wav -> normalised log-mel frames (preprocessing.py:58-69) --------------------
+// One workgroup per (frame, clip): centred reflect-padded frame x periodic Hann window -> direct
+// DFT (the window is 1024 points and a 10 s clip has 862 frames: an FFT would buy microseconds)
+// -> |.|^2 -> mel filterbank -> 20 log10(max(1e-4, .)) - ref -> clip((. - min) / -min, 0, 1).
+// The 20 log10 of a POWER spectrum is the reference's (preprocessing.py:67) and kept.
+__global__ __launch_bounds__(256) void mel_kernel(const float* __restrict__ wav, long T, int frames,
+                                                  const float* __restrict__ window, const float* __restrict__ fb,
+                                                  int n_fft, int hop, int n_mels, float ref_db, float min_db,
+                                                  float* __restrict__ mel) {
+    extern __shared__ float sm[];
+    float* xw = sm;                    // [n_fft] windowed frame
+    float* cs = xw + n_fft;            // [n_fft] cos(2 pi j / n_fft)
+    float* sn = cs + n_fft;            // [n_fft] sin(2 pi j / n_fft)
+    float* pw = sn + n_fft;            // [n_fft/2 + 1] power spectrum
+    const int fr = blockIdx.x, nb = n_fft / 2 + 1;
+    const float* y = wav + (long)blockIdx.y * T;
+    for (int n = threadIdx.x; n < n_fft; n += 256) {
+        long j = (long)fr * hop + n - n_fft / 2;
+        if (j < 0) j = -j;                         // numpy 'reflect': the edge sample is not repeated
+        if (j >= T) j = 2 * (T - 1) - j;
+        xw[n] = y[j] * window[n];
+        float sv, cv;
+        sincospif(2.0f * (float)n / (float)n_fft, &sv, &cv);
+        cs[n] = cv;
+        sn[n] = sv;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nb; k += 256) {
+        float re = 0.0f, im = 0.0f;
+        int idx = 0;
+        for (int n = 0; n < n_fft; ++n) {
+            re = fmaf(xw[n], cs[idx], re);
+            im = fmaf(-xw[n], sn[idx], im);
+            idx = (idx + k) & (n_fft - 1);
+        }
+        pw[k] = re * re + im * im;
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < n_mels; m += 256) {
+        const float* w = fb + (long)m * nb;
+        float acc = 0.0f;
+        for (int k = 0; k < nb; ++k) acc = fmaf(w[k], pw[k], acc);
+        const float db = 20.0f * log10f(fmaxf(1e-4f, acc)) - ref_db;
+        mel[((long)blockIdx.y * frames + fr) * n_mels + m] = fminf(fmaxf((db - min_db) / (-min_db), 0.0f), 1.0f);
+    }
+}
+void fwn_launch_mel(const float* wav, long B, long T, const float* window, const float* fb, int n_fft, int hop,
+                    int n_mels, float ref_db, float min_db, float* mel, hipStream_t st) {
+    const int frames = (int)(1 + T / hop);
+    const size_t lds = (size_t)(3 * n_fft + n_fft / 2 + 1) * sizeof(float);
+    hipLaunchKernelGGL(mel_kernel, dim3(frames, (unsigned)B), dim3(256), lds, st, wav, T, frames, window, fb,
+                       n_fft, hop, n_mels, ref_db, min_db, mel);
+}
+
 int fwn_sqnorm_blocks(long n) { long b = (n + 1023) / 1024; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 void fwn_launch_grad_norm(const float* g, long n, float gscale, double* partial, float* out, hipStream_t st) {
     const int nb = fwn_sqnorm_blocks(n);

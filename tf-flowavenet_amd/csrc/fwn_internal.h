@@ -29,6 +29,8 @@ void fwn_launch_prior(const float* planes, long n, const float* partial, int n_p
                       float* out2, hipStream_t st);
 
 int fwn_sqnorm_blocks(long n);
+void fwn_launch_mel(const float* wav, long B, long T, const float* window, const float* fb, int n_fft, int hop,
+                    int n_mels, float ref_db, float min_db, float* mel, hipStream_t st);
 void fwn_launch_grad_norm(const float* g, long n, float gscale, double* partial, float* out, hipStream_t st);
 void fwn_launch_adam(float* w, const float* g, float* m, float* v, long n, const float* gnorm, float gscale,
                      float clip, float lr_t, float b1, float b2, float eps, hipStream_t st);

@@ -16,6 +16,9 @@
 #include "gemm_ring.h"
 
 #define FWN_HALO_MAXDIL 3
+#ifndef FWN_HABL
+#define FWN_HABL 0   // developer ablation (tools/bench_gemm.hip): 1 no weight refills, 2 no activation refills, 3 neither, 4 no epilogue
+#endif
 
 // Tile BM x BN with BM / 16 waves (so every wave stages 2 activation pieces per slice, wave 0 the
 // odd one) laid out (NWV / WN) x WN, WN = BN / 64.
@@ -67,10 +70,12 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
     const uint32_t cbytes = (uint32_t)((size_t)M * cin * 2);
     auto issueA_conv = [&](int kc, int j) {          // slice kc of h -> slot kc & 1
         if (j == 2 && wave != 0) return;
+        if ((FWN_HABL == 2 || FWN_HABL == 3) && kc > 0) return;
         buf_load16_lds(make_srd(p.h, hbytes), ah[j] + (uint32_t)kc * 128u,
                        ldsA + (kc & 1) * A_BYTES + (wave + NWV * j) * 1024);
     };
     auto issueA_cond = [&](int qc, int j) {          // conditioning chunk qc -> slot qc & 1
+        if (FWN_HABL == 2 || FWN_HABL == 3) return;
         const int jrow = 8 * (wave + NWV * j) + (lane >> 3);
         const int col = qc * 64 + ((lane & 7) ^ ((jrow >> 1) & 7)) * 8;
         const bool ok = col < cin && m0 + jrow < M;
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
                        ldsA + (qc & 1) * A_BYTES + (wave + NWV * j) * 1024);
     };
     auto issueB = [&](int s, int j) {                // weight chunk of step s -> slot s & 1
+        if ((FWN_HABL == 1 || FWN_HABL == 3) && s > 0) return;
         unsigned char* dst = ldsB + (s & 1) * B_BYTES + (wave + NWV * j) * 1024;
         if (s < 12) {
             const int kc = s / 3, tap = s - 3 * kc;
@@ -194,6 +200,16 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
                 issueA_cond(qc + 1, 1);
             }
         });
+    }
+    if (FWN_HABL == 4) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[mi][ni][r];
+        if (sacc != 12345.678f) return;
     }
     p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
 }
