@@ -114,7 +114,7 @@ def gate_roofline(model, hp, b, t, iters=30):
             rec = json.load(f)
         if rec.get("rows") == m:
             traffic = rec["traffic_bytes"]
-    return {"bound": "mfma", "kernel": "gemm_ring_kernel<256,256,4,4,64,2,GateProb> (block 0 gated dilated layer, fwn_gate)",
+    return {"bound": "mfma", "kernel": "gate_halo_kernel<256,256,GateProb> (block 0 gated dilated layer, fwn_gate)",
             "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
             "traffic": traffic, "launch_us": sec * 1e6, "flop_per_launch": flops, "rows": m}
 
