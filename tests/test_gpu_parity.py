@@ -240,6 +240,90 @@ def test_gate_stage_kernel_matches_oracle(full_model, b, ti, layer):
     assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max(), err.mean(), np.unravel_index(err.argmax(), err.shape))
 
 
+def _flow_case(full_model, blk, b, ti, seed):
+    """Inputs of one flow (flow 0 of block `blk`) in the reference's layout and in the device's."""
+    hp, model, _, _, _ = full_model
+    ch = 1 << blk
+    m, half = b * ti, hp.num_mels // 2
+    d = model._packed.flow_descs[blk * hp.n_flow]
+    p64 = onp.to_f64(W.synthetic_params(hp, 1234))
+    for k, v in model.export_actnorm().items():          # the fixture ran DDI: use the device's ActNorm
+        p64[k] = np.asarray(v, np.float64)
+    rng = np.random.default_rng(seed)
+    x_log = rng.standard_normal((b, ti, 2 * ch)).astype(np.float32)
+    ca_dev = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    src = packing.cond_src_k(blk, half)[:d.cin]
+    c_a = np.empty((b, ti, d.cin))
+    c_a[:, :, src] = ca_dev.float().cpu().numpy().astype(np.float64).reshape(b, ti, d.cin)
+    br = packing.bitrev_table(blk).astype(np.int64)
+    return hp, model, d, p64, x_log, c_a, ca_dev, br
+
+
+def _run_flow(model, d, hp, b, ti, xa, xb, ca_dev, inverse):
+    lib = _lib.load()
+    ch, m, L = d.Ch, b * ti, hp.n_layer
+    t = ti * 2 * ch
+    st = torch.cuda.current_stream().cuda_stream
+    h0 = torch.empty(m, 256, device="cuda", dtype=torch.bfloat16)
+    h1 = torch.empty_like(h0)
+    o = torch.empty(L, m, 256, device="cuda", dtype=torch.bfloat16)
+    npart = lib.fwn_tail_partials(m)
+    partial = torch.zeros(npart, device="cuda", dtype=torch.float32)
+    P = None
+    if m < 4096:     # the model hoists the conditioning projections of small-M blocks (api.hip hoist_cond)
+        P = torch.empty(L, m, 512, device="cuda", dtype=torch.float32)
+        _lib.check(lib.fwn_cond(ca_dev.data_ptr(), d.Wc[0], P.data_ptr(), 512 * d.kcpad, m * 512, 0, 1, 1, L, m,
+                                d.cin, d.kcpad, st), "fwn_cond")
+    _lib.check(lib.fwn_flow_run(C.byref(d), b, t, xa.data_ptr(), xb.data_ptr(), None if P is not None else ca_dev.data_ptr(),
+                                h0.data_ptr(), h1.data_ptr(), o.data_ptr(), P.data_ptr() if P is not None else None,
+                                partial.data_ptr(), inverse, 0, st), "fwn_flow_run")
+    torch.cuda.synchronize()
+    return partial
+
+
+FLOW_CASES = [(0, 13, 1000), (0, 26, 1000), (1, 7, 1000), (3, 9, 700), (5, 4, 200), (7, 3, 70)]
+
+
+@pytest.mark.parametrize("blk,b,ti", FLOW_CASES)
+def test_single_flow_forward_matches_oracle(full_model, blk, b, ti):
+    """fwn_flow_run (front -> gate -> res -> gate -> tail) for one flow against the oracle's
+    Flow.forward (model.py:185-194), at row counts that select every tile variant (tap-sharing
+    256x256 / 256x128 gates, plain ring tiles, hoisted conditioning, VALU / ring front, 1..4
+    ZeroConv pair tiles), with clip edges inside the tiles."""
+    hp, model, d, p64, x_log, c_a, ca_dev, br = _flow_case(full_model, blk, b, ti, 100 + blk)
+    ch, m = d.Ch, b * ti
+    xa = torch.from_numpy(np.ascontiguousarray(x_log[:, :, br].reshape(m, ch))).cuda()
+    xb = torch.from_numpy(np.ascontiguousarray(x_log[:, :, ch + br].reshape(m, ch))).cuda()
+    partial = _run_flow(model, d, hp, b, ti, xa, xb, ca_dev, 0)
+    c_full = np.concatenate([c_a, np.zeros_like(c_a)], 2)
+    out, _, logdet = onp.flow_forward(p64, W.flow_prefix(blk, 0), x_log.astype(np.float64), c_full, hp)
+    # after change_order the transformed half comes first
+    err_b = np.abs(xb.cpu().numpy().reshape(b, ti, ch) - out[:, :, br])
+    err_a = np.abs(xa.cpu().numpy().reshape(b, ti, ch) - out[:, :, ch + br])
+    assert err_a.max() < 1e-5 * max(1.0, np.abs(out).max())          # ActNorm only: fp32
+    assert err_b.max() < 2e-2 and err_b.mean() < 2e-3, (err_b.max(), err_b.mean())
+    got = float(partial.double().sum()) / (m * 2 * ch)
+    assert abs(got - logdet) < 1e-3 * max(1.0, abs(logdet)), (got, logdet)
+
+
+@pytest.mark.parametrize("blk,b,ti", [(0, 26, 1000), (3, 9, 700), (6, 3, 130)])
+def test_single_flow_inverse_matches_oracle(full_model, blk, b, ti):
+    """The same chain in the synthesis direction against Flow.reverse (model.py:196-202)."""
+    hp, model, d, p64, y_log, c_a, ca_dev, br = _flow_case(full_model, blk, b, ti, 200 + blk)
+    ch, m = d.Ch, b * ti
+    # y_log = [out_b | out_a]: Flow.reverse swaps the halves (and those of c) first
+    xb = torch.from_numpy(np.ascontiguousarray(y_log[:, :, br].reshape(m, ch))).cuda()
+    xa = torch.from_numpy(np.ascontiguousarray(y_log[:, :, ch + br].reshape(m, ch))).cuda()
+    _run_flow(model, d, hp, b, ti, xa, xb, ca_dev, 1)
+    c_full = np.concatenate([np.zeros_like(c_a), c_a], 2)
+    want, _ = onp.flow_reverse(p64, W.flow_prefix(blk, 0), y_log.astype(np.float64), c_full, hp)
+    err_a = np.abs(xa.cpu().numpy().reshape(b, ti, ch) - want[:, :, br])
+    err_b = np.abs(xb.cpu().numpy().reshape(b, ti, ch) - want[:, :, ch + br])
+    scale = max(1.0, np.abs(want).max())
+    assert err_a.max() < 1e-5 * scale
+    assert err_b.max() < 2e-2 * scale and err_b.mean() < 2e-3 * scale, (err_b.max(), err_b.mean())
+
+
 def test_full_size_round_trip_and_determinism(full_model):
     """BASELINE configs[1] sizes (n_block=8, n_flow=6, B=8, T=16128): encode -> decode round trip,
     bit-reproducibility, batch independence."""
