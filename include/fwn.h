@@ -147,6 +147,38 @@ int fwn_grad_norm(const float* g, int64_t n, float gscale, double* partial, floa
 int fwn_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* gnorm, float gscale,
                   float clip, float lr, int64_t step, float beta1, float beta2, float eps, void* stream);
 
+/* ---- training-side primitives (work in progress: the backward pass) ----
+ * Generic multi-segment GEMM on the LDS-DMA ring core:
+ *   Y[M][N] = oscale * relu?( mask?( sum_s shift_s(X_s)[M][k_s] . W[N][koff_s ..]^T + bias + rscale * R ) )
+ * X_s: bf16 [rows_s][ld_s], row r of the product reads row r + shift_s (a tap); with Ti > 0 rows are
+ * clips of Ti rows and taps that leave their clip read zero, with Ti == 0 only the matrix bounds apply.
+ * W: bf16 [N][ldw], segment s in columns [koff_s, koff_s + k_s) (k_s a multiple of 8; padding finite).
+ * mask: keep where mask[row][col] > 0 (the ReLU derivative from a stored activation).
+ * Output bf16 [M][ldy], or fp32 (out_f32; accumulate: +=).  nsplit > 1 (fp32 only, no bias / R / mask):
+ * the K chunks are split over nsplit partial outputs Y + z*split_stride, to be summed by
+ * fwn_reduce_splits (fixed order: deterministic). */
+#define FWN_GEMM_MAXSEG 8
+typedef struct fwn_gemm_seg { const void* x; int32_t rows, ld, k, shift, koff, pad_; } fwn_gemm_seg;
+typedef struct fwn_gemm_desc {
+    fwn_gemm_seg seg[FWN_GEMM_MAXSEG];
+    int32_t nseg, M, N, Ti;
+    const void* W;      int32_t ldw, pad0_;
+    const float* bias;
+    const void* R;      int32_t ldr;    float rscale;
+    const void* mask;   int32_t ldmask; int32_t relu;
+    void* Y;            int32_t ldy;    int32_t out_f32;
+    int32_t accumulate, nsplit;
+    int64_t split_stride;
+    float oscale;       int32_t pad1_;
+} fwn_gemm_desc;
+int fwn_gemm(const fwn_gemm_desc* g, void* stream);
+/* dst[c][m] = src[m + shift][c] (zero where the tap leaves its clip / the matrix; columns m >= M zero),
+ * dst bf16 [C (+1)][ld_dst]; ones_row: row C = 1 for m < M (bias gradients ride the weight-gradient GEMM). */
+int fwn_transpose_shift(const void* src, int M, int C, int ld_src, int shift, int Ti, void* dst, int ld_dst,
+                        int ones_row, void* stream);
+int fwn_reduce_splits(const float* partial, int nsplit, int64_t stride, int64_t n, float scale, float* out,
+                      void* stream);
+
 /* ---- whole model (replaces FloWaveNet.forward / .reverse, model.py:317-396) ---- */
 typedef struct fwn_model_desc {
     int32_t n_block, n_flow, n_layer, num_mels;

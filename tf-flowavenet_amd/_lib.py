@@ -46,6 +46,28 @@ class ModelDesc(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/fwn.h declares.
+class GemmSeg(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("rows", C.c_int32), ("ld", C.c_int32), ("k", C.c_int32), ("shift", C.c_int32),
+                ("koff", C.c_int32), ("pad_", C.c_int32)]
+
+
+FWN_GEMM_MAXSEG = 8
+
+
+class GemmDesc(C.Structure):
+    """include/fwn.h fwn_gemm_desc."""
+    _fields_ = [("seg", GemmSeg * FWN_GEMM_MAXSEG),
+                ("nseg", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("Ti", C.c_int32),
+                ("W", C.c_void_p), ("ldw", C.c_int32), ("pad0_", C.c_int32),
+                ("bias", C.c_void_p),
+                ("R", C.c_void_p), ("ldr", C.c_int32), ("rscale", C.c_float),
+                ("mask", C.c_void_p), ("ldmask", C.c_int32), ("relu", C.c_int32),
+                ("Y", C.c_void_p), ("ldy", C.c_int32), ("out_f32", C.c_int32),
+                ("accumulate", C.c_int32), ("nsplit", C.c_int32),
+                ("split_stride", C.c_int64),
+                ("oscale", C.c_float), ("pad1_", C.c_int32)]
+
+
 SIGNATURES = {
     "fwn_version": (C.c_int, []),
     "fwn_last_error": (C.c_char_p, []),
@@ -65,6 +87,9 @@ SIGNATURES = {
     "fwn_flow_run": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,
                                C.c_int, vp]),
     "fwn_prior_logp": (C.c_int, [vp, i64, vp, C.c_int, vp, vp]),
+    "fwn_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "fwn_transpose_shift": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "fwn_reduce_splits": (C.c_int, [vp, C.c_int, i64, i64, C.c_float, vp, vp]),
     "fwn_mel_spectrogram": (C.c_int, [vp, i64, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
     "fwn_grad_norm_partials": (C.c_int, [i64]),
     "fwn_grad_norm": (C.c_int, [vp, i64, C.c_float, vp, vp, vp]),

@@ -213,6 +213,40 @@ int fwn_mel_spectrogram(const float* wav, int64_t B, int64_t T, const float* win
     return check_launch("fwn_mel_spectrogram");
 }
 
+// ---- training-side primitives --------------------------------------------------------------------
+int fwn_gemm(const fwn_gemm_desc* g, void* stream) {
+    REQUIRE(g && g->W && g->Y, "fwn_gemm: null pointer");
+    REQUIRE(g->nseg >= 1 && g->nseg <= FWN_GEMM_MAXSEG, "fwn_gemm: nseg=%d", g->nseg);
+    REQUIRE(g->M > 0 && g->N > 0 && g->ldw > 0 && g->ldy >= g->N && g->Ti >= 0, "fwn_gemm: bad shape");
+    REQUIRE(ALIGNED16(g->W) && g->ldw % 8 == 0, "fwn_gemm: W rows must be 16-byte aligned");
+    for (int s = 0; s < g->nseg; ++s) {
+        const fwn_gemm_seg& sg = g->seg[s];
+        REQUIRE(sg.x && sg.k > 0 && sg.k % 8 == 0 && sg.ld >= sg.k && sg.ld % 8 == 0 && ALIGNED16(sg.x) && sg.koff % 8 == 0 &&
+                    sg.koff >= 0 && sg.koff + sg.k <= g->ldw && sg.rows > 0,
+                "fwn_gemm: segment %d: k, ld, koff must be multiples of 8 within the operands", s);
+        REQUIRE((int64_t)sg.rows * sg.ld * 2 < ((int64_t)1 << 31), "fwn_gemm: segment %d exceeds 2 GiB", s);
+    }
+    REQUIRE((int64_t)g->N * g->ldw * 2 < ((int64_t)1 << 31), "fwn_gemm: W exceeds 2 GiB");
+    REQUIRE(g->nsplit >= 1 && g->nsplit <= 1024, "fwn_gemm: nsplit=%d", g->nsplit);
+    REQUIRE(g->nsplit == 1 || (g->out_f32 && !g->bias && !g->R && !g->mask && !g->relu && !g->accumulate),
+            "fwn_gemm: split-K writes plain fp32 partials");
+    REQUIRE(!g->accumulate || g->out_f32, "fwn_gemm: accumulate needs an fp32 output");
+    fwn_gemm_launch(g, (hipStream_t)stream);
+    return check_launch("fwn_gemm");
+}
+int fwn_transpose_shift(const void* src, int M, int C, int ld_src, int shift, int Ti, void* dst, int ld_dst,
+                        int ones_row, void* stream) {
+    REQUIRE(src && dst && M > 0 && C > 0 && ld_src >= C && ld_dst >= M && Ti >= 0, "fwn_transpose_shift: bad argument");
+    fwn_transpose_launch(src, M, C, ld_src, shift, Ti, dst, ld_dst, ones_row, (hipStream_t)stream);
+    return check_launch("fwn_transpose_shift");
+}
+int fwn_reduce_splits(const float* partial, int nsplit, int64_t stride, int64_t n, float scale, float* out,
+                      void* stream) {
+    REQUIRE(partial && out && nsplit >= 1 && n > 0 && stride >= n, "fwn_reduce_splits: bad argument");
+    fwn_reduce_splits_launch(partial, nsplit, (long)stride, (long)n, scale, out, (hipStream_t)stream);
+    return check_launch("fwn_reduce_splits");
+}
+
 // ---- data-parallel optimiser step -------------------------------------------------------------
 int fwn_grad_norm_partials(int64_t n) { return fwn_sqnorm_blocks((long)n); }
 

@@ -34,3 +34,11 @@ void fwn_launch_mel(const float* wav, long B, long T, const float* window, const
 void fwn_launch_grad_norm(const float* g, long n, float gscale, double* partial, float* out, hipStream_t st);
 void fwn_launch_adam(float* w, const float* g, float* m, float* v, long n, const float* gnorm, float gscale,
                      float clip, float lr_t, float b1, float b2, float eps, hipStream_t st);
+
+// train_kernels.hip
+struct fwn_gemm_desc;
+int fwn_gemm_launch(const fwn_gemm_desc* g, hipStream_t st);
+void fwn_transpose_launch(const void* src, int M, int C, int ld_src, int shift, int Ti, void* dst, int ld_dst,
+                          int ones_row, hipStream_t st);
+void fwn_reduce_splits_launch(const float* partial, int nsplit, long stride, long n, float scale, float* out,
+                              hipStream_t st);
