@@ -179,6 +179,32 @@ int fwn_transpose_shift(const void* src, int M, int C, int ld_src, int shift, in
 int fwn_reduce_splits(const float* partial, int nsplit, int64_t stride, int64_t n, float scale, float* out,
                       void* stream);
 
+/* Training forward of a gated layer: as fwn_gate (conditioning fused, never hoisted), also storing
+ * aux [M][512] bf16 = (tanh f | sigmoid g) in natural channel order for fwn_gate_bwd. */
+int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void* ca, void* o, void* aux, int M,
+                   int Ti, void* stream);
+/* Element-wise pieces.  Planes are fp32 [M][Ch]; `an` points at one plane's table [4][Ch] = (shift,
+ * scale, 1/scale, 3 logs) (fwn_flow_desc.an + role*4*Ch); Z is the ZeroConv output before its exp(3 scale)
+ * factor ez [2Ch] (modules.py:51-56), fp32 [M][2Ch]: (log_s | t) = Z * ez.
+ * fwn_actnorm_apply: x <- (x + shift) scale.                                  (model.py:86-94)
+ * fwn_coupling_fwd : y_b <- (y_b - t) exp(-log_s); partial[nblocks] <- sums of -log_s   (:124-141)
+ * fwn_coupling_bwd : g = dL/d out_b <- dL/d y_b; out_b <- y_b; dZ (bf16, ld ldz) <- (dL/dlog_s | dL/dt)
+ *                    with the log-det term cls = 1/(2 M Ch) added; dzz <- dZ * Z (ZeroConv scale gradient)
+ * fwn_gate_bwd     : dpre [M][512] <- (do sg (1 - tf^2) | do tf sg (1 - sg))          (modules.py:124)
+ * fwn_colsum_prod  : out[c] <- scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C], fixed order
+ * fwn_actnorm_bwd  : dy <- dy * scale; y <- y / scale - shift (the plane before ActNorm)
+ * fwn_wn_backward  : weight-norm backward per output column: dW, V fp32 [K][N], g [N] -> dV, dg   (convolutional.py:73-80) */
+int fwn_actnorm_apply(float* x, const float* an, int64_t n, int Ch, void* stream);
+int fwn_coupling_fwd(float* yb, const float* Z, const float* ez, int64_t M, int Ch, float* partial, int nblocks,
+                     void* stream);
+int fwn_coupling_bwd(float* g, float* out_b, const float* Z, const float* ez, int64_t M, int Ch, float cls, void* dZ,
+                     int ldz, float* dzz, void* stream);
+int fwn_gate_bwd(const void* d_o, const void* aux, int64_t M, void* dpre, void* stream);
+int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C, float scale, float* out, void* stream);
+int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, void* stream);
+int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg,
+                    void* stream);
+
 /* ---- whole model (replaces FloWaveNet.forward / .reverse, model.py:317-396) ---- */
 typedef struct fwn_model_desc {
     int32_t n_block, n_flow, n_layer, num_mels;

@@ -88,6 +88,14 @@ SIGNATURES = {
                                C.c_int, vp]),
     "fwn_prior_logp": (C.c_int, [vp, i64, vp, C.c_int, vp, vp]),
     "fwn_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
+    "fwn_gate_train": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "fwn_actnorm_apply": (C.c_int, [vp, vp, i64, C.c_int, vp]),
+    "fwn_coupling_fwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp, C.c_int, vp]),
+    "fwn_coupling_bwd": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, C.c_float, vp, C.c_int, vp, vp]),
+    "fwn_gate_bwd": (C.c_int, [vp, vp, i64, vp, vp]),
+    "fwn_colsum_prod": (C.c_int, [vp, vp, i64, C.c_int, C.c_float, vp, vp]),
+    "fwn_actnorm_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
+    "fwn_wn_backward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "fwn_transpose_shift": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "fwn_reduce_splits": (C.c_int, [vp, C.c_int, i64, i64, C.c_float, vp, vp]),
     "fwn_mel_spectrogram": (C.c_int, [vp, i64, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),

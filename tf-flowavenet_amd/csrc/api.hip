@@ -120,8 +120,20 @@ int fwn_gate(const fwn_flow_desc* d, int layer, const void* h, const void* ca, c
     REQUIRE((ca != nullptr) != (P != nullptr), "fwn_gate: exactly one of ca / P");
     REQUIRE(ALIGNED16(h) && ALIGNED16(o) && ALIGNED16(ca), "fwn_gate: buffers must be 16-byte aligned");
     fwn_launch_gate(h, ca, P, d->Wd[layer], d->Wc[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
-                    d->cin, d->kcpad, (hipStream_t)stream);
+                    d->cin, d->kcpad, nullptr, (hipStream_t)stream);
     return check_launch("fwn_gate");
+}
+
+int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void* ca, void* o, void* aux, int M,
+                   int Ti, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(layer >= 0 && layer < d->L, "fwn_gate_train: layer %d out of range", layer);
+    REQUIRE(h && ca && o && aux && M > 0 && Ti > 0 && M % Ti == 0, "fwn_gate_train: bad argument");
+    REQUIRE(ALIGNED16(h) && ALIGNED16(ca), "fwn_gate_train: buffers must be 16-byte aligned");
+    fwn_launch_gate(h, ca, nullptr, d->Wd[layer], d->Wc[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
+                    d->cin, d->kcpad, aux, (hipStream_t)stream);
+    return check_launch("fwn_gate_train");
 }
 
 int fwn_res(const fwn_flow_desc* d, int layer, const void* o, const void* h_in, void* h_out, int M,
@@ -182,7 +194,7 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
     for (int l = 0; l < d->L; ++l) {
         void* ol = (char*)o + (size_t)l * M * 256 * 2;
         fwn_launch_gate(hc, ca, P ? P + (size_t)l * M * 512 : nullptr, d->Wd[l], d->Wc[l], d->bgate[l], ol, M,
-                        Ti, dilation_of(l), d->cin, d->kcpad, st);
+                        Ti, dilation_of(l), d->cin, d->kcpad, nullptr, st);
         if (l + 1 < d->L) {
             fwn_launch_res(ol, hc, d->Wres[l], d->bres[l], hn, M, st);
             void* t = hc; hc = hn; hn = t;
@@ -245,6 +257,45 @@ int fwn_reduce_splits(const float* partial, int nsplit, int64_t stride, int64_t 
     REQUIRE(partial && out && nsplit >= 1 && n > 0 && stride >= n, "fwn_reduce_splits: bad argument");
     fwn_reduce_splits_launch(partial, nsplit, (long)stride, (long)n, scale, out, (hipStream_t)stream);
     return check_launch("fwn_reduce_splits");
+}
+
+int fwn_actnorm_apply(float* x, const float* an, int64_t n, int Ch, void* stream) {
+    REQUIRE(x && an && n > 0 && Ch >= 1 && (Ch & (Ch - 1)) == 0, "fwn_actnorm_apply: bad argument");
+    fwn_ew_actnorm_fwd(x, an, (long)n, Ch, (hipStream_t)stream);
+    return check_launch("fwn_actnorm_apply");
+}
+int fwn_coupling_fwd(float* yb, const float* Z, const float* ez, int64_t M, int Ch, float* partial, int nblocks,
+                     void* stream) {
+    REQUIRE(yb && Z && ez && partial && M > 0 && Ch >= 1 && nblocks >= 1, "fwn_coupling_fwd: bad argument");
+    fwn_ew_coupling_fwd(yb, Z, ez, (long)M * Ch, Ch, partial, nblocks, (hipStream_t)stream);
+    return check_launch("fwn_coupling_fwd");
+}
+int fwn_coupling_bwd(float* g, float* out_b, const float* Z, const float* ez, int64_t M, int Ch, float cls, void* dZ,
+                     int ldz, float* dzz, void* stream) {
+    REQUIRE(g && out_b && Z && ez && dZ && dzz && M > 0 && Ch >= 1 && ldz >= 2 * Ch, "fwn_coupling_bwd: bad argument");
+    fwn_ew_coupling_bwd(g, out_b, Z, ez, (long)M * Ch, Ch, cls, dZ, ldz, dzz, (hipStream_t)stream);
+    return check_launch("fwn_coupling_bwd");
+}
+int fwn_gate_bwd(const void* d_o, const void* aux, int64_t M, void* dpre, void* stream) {
+    REQUIRE(d_o && aux && dpre && M > 0, "fwn_gate_bwd: bad argument");
+    fwn_ew_gate_bwd(d_o, aux, (long)M * 256, dpre, (hipStream_t)stream);
+    return check_launch("fwn_gate_bwd");
+}
+int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C_, float scale, float* out, void* stream) {
+    REQUIRE(A && out && M > 0 && C_ > 0, "fwn_colsum_prod: bad argument");
+    fwn_ew_colsum_prod(A, B, (long)M, C_, scale, out, (hipStream_t)stream);
+    return check_launch("fwn_colsum_prod");
+}
+int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, void* stream) {
+    REQUIRE(dy && y && an && n > 0 && Ch >= 1 && (Ch & (Ch - 1)) == 0, "fwn_actnorm_bwd: bad argument");
+    fwn_ew_actnorm_bwd(dy, y, an, (long)n, Ch, (hipStream_t)stream);
+    return check_launch("fwn_actnorm_bwd");
+}
+int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg,
+                    void* stream) {
+    REQUIRE(dW && V && g && dV && dg && K > 0 && N > 0, "fwn_wn_backward: bad argument");
+    fwn_ew_wn_backward(dW, V, g, K, N, dV, dg, (hipStream_t)stream);
+    return check_launch("fwn_wn_backward");
 }
 
 // ---- data-parallel optimiser step -------------------------------------------------------------

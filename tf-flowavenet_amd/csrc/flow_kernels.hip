@@ -231,6 +231,7 @@ struct GateProb {
     const float* bias;    // [512] packed-N order (conv bias + cond bias)
     bf16* o;              // [M][256]
     int M, Ti, dil, cin, kcpad;
+    bf16* aux = nullptr;  // training only: [M][512] = (tanh f | sigmoid g) kept for the backward pass
     typedef RowCtxT RowCtx;
     struct ChunkCtx { int cond, acol, bcol, shift, kvalid; };
     template <int BK> __device__ int nchunks() const { return (3 * FWN_HID + (ca ? kcpad : 0)) / BK; }
@@ -291,6 +292,20 @@ struct GateProb {
                     buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r + 1)) * FWN_HID * 2), y.y);
                 }
             }
+        } else if (aux) {   // training forward: the two factors are stored for the gate's derivative
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + mi * 32 + acc_row_c(r);
+                    if (row >= M) continue;
+                    const float a = __builtin_amdgcn_exp2f(fminf(acc[mi][0][r], 40.0f));
+                    const float b = __builtin_amdgcn_exp2f(fminf(acc[mi][1][r], 40.0f));
+                    const float tf = (1.0f - a) * __builtin_amdgcn_rcpf(1.0f + a), sg = __builtin_amdgcn_rcpf(1.0f + b);
+                    o[(size_t)row * FWN_HID + ch] = (bf16)(tf * sg);
+                    aux[(size_t)row * 512 + ch] = (bf16)tf;
+                    aux[(size_t)row * 512 + 256 + ch] = (bf16)sg;
+                }
         } else {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -849,9 +864,11 @@ void fwn_launch_front(const float* xa, const float* an_a, const void* W, const v
 }
 
 void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc,
-                     const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, hipStream_t st) {
+                     const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, void* aux,
+                     hipStream_t st) {
     GateProb p{(const bf16*)h, (const bf16*)ca, P, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o,
                M, Ti, dil, cin, kcpad};
+    p.aux = (bf16*)aux;
     const int t256 = (M + 255) / 256;
     if (dil <= FWN_HALO_MAXDIL && t256 * 4 >= 192) {
         // Tap-sharing tiles (gate_halo.h) for the MFMA/L2-bound sizes.  On warm caches they also win at

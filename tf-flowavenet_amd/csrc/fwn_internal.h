@@ -5,7 +5,8 @@
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,
                       void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st);
 void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc,
-                     const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, hipStream_t st);
+                     const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, void* aux,
+                     hipStream_t st);
 void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M,
                     hipStream_t st);
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
@@ -42,3 +43,12 @@ void fwn_transpose_launch(const void* src, int M, int C, int ld_src, int shift, 
                           int ones_row, hipStream_t st);
 void fwn_reduce_splits_launch(const float* partial, int nsplit, long stride, long n, float scale, float* out,
                               hipStream_t st);
+void fwn_ew_actnorm_fwd(float* x, const float* an, long n, int Ch, hipStream_t st);
+void fwn_ew_coupling_fwd(float* yb, const float* Z, const float* ez, long n, int Ch, float* partial, int nblocks,
+                         hipStream_t st);
+void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
+                         int ldz, float* dzz, hipStream_t st);
+void fwn_ew_gate_bwd(const void* do_, const void* aux, long n, void* dpre, hipStream_t st);
+void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* out, hipStream_t st);
+void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st);
+void fwn_ew_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg, hipStream_t st);

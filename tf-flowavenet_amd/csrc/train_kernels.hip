@@ -148,3 +148,150 @@ void fwn_reduce_splits_launch(const float* partial, int nsplit, long stride, lon
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)nb), dim3(256), 0, st, partial, nsplit, stride, n, scale, out);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise pieces of the training forward / backward.  Planes are fp32 [M][Ch] (device channel
+// order), Z = [log_s | t] is fp32 [M][2*Ch] in the same order.
+// ---------------------------------------------------------------------------------------------
+// ActNorm forward on one plane, in place: y = (x + shift[c]) * scale[c]   (model.py:86-94)
+__global__ __launch_bounds__(256) void actnorm_fwd_kernel(float* __restrict__ x, const float* __restrict__ an,
+                                                          long n, int Ch) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i & (Ch - 1));
+        x[i] = (x[i] + an[c]) * an[Ch + c];
+    }
+}
+// Z here is the ZeroConv output BEFORE its exp(3 scale) factor ez (modules.py:51-56): (log_s | t) = Z * ez.
+// coupling forward (model.py:124-141): out_b = (y_b - t) exp(-log_s), in place over y_b;
+// partial[block] = sum(-log_s) of the block's elements (fixed order).
+__global__ __launch_bounds__(256) void coupling_fwd_kernel(float* __restrict__ yb, const float* __restrict__ Z,
+                                                           const float* __restrict__ ez, long n, int Ch,
+                                                           float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.0f;
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long i0 = (long)blockIdx.x * per, i1 = min(n, i0 + per);
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const long m = i / Ch;
+        const int c = (int)(i - m * Ch);
+        const float ls = Z[m * 2 * Ch + c] * ez[c], t = Z[m * 2 * Ch + Ch + c] * ez[Ch + c];
+        yb[i] = (yb[i] - t) * __expf(-ls);
+        acc -= ls;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// coupling backward.  In: g = dL/d out_b (fp32, becomes dL/d y_b in place), ob = out_b (becomes y_b in
+// place), Z.  Out: dZ bf16 [M][ldz] = gradient wrt Z (already times ez), dzz fp32 [M][2Ch] = d(log_s|t) * (log_s|t)
+// (ZeroConv scale gradient = 3 * column sums).  cls = d(-logdet)/dlog_s = +1 / (2 M Ch)   (model.py:135: mean(-log_s)/2).
+__global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ g, float* __restrict__ ob,
+                                                           const float* __restrict__ Z, const float* __restrict__ ez,
+                                                           long n, int Ch, float cls, bf16* __restrict__ dZ, int ldz,
+                                                           float* __restrict__ dzz) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long m = i / Ch;
+        const int c = (int)(i - m * Ch);
+        const float ls = Z[m * 2 * Ch + c] * ez[c], t = Z[m * 2 * Ch + Ch + c] * ez[Ch + c];
+        const float e = __expf(-ls), gb = g[i], o = ob[i];
+        const float dls = -gb * o + cls, dt = -gb * e;
+        g[i] = gb * e;
+        ob[i] = o / e + t;
+        dZ[m * ldz + c] = (bf16)(dls * ez[c]);
+        dZ[m * ldz + Ch + c] = (bf16)(dt * ez[Ch + c]);
+        dzz[m * 2 * Ch + c] = dls * ls;
+        dzz[m * 2 * Ch + Ch + c] = dt * t;
+    }
+}
+// gate backward: aux = [tanh f | sigmoid g] (bf16 [M][512]), do_ (bf16 [M][256]) ->
+// dpre = [do * sg * (1 - tf^2) | do * tf * sg * (1 - sg)]  (bf16 [M][512], natural channel order)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16* __restrict__ do_, const bf16* __restrict__ aux,
+                                                       long n, bf16* __restrict__ dpre) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long m = i >> 8;
+        const int c = (int)(i & 255);
+        const float d = (float)do_[i], tf = (float)aux[m * 512 + c], sg = (float)aux[m * 512 + 256 + c];
+        dpre[m * 512 + c] = (bf16)(d * sg * (1.0f - tf * tf));
+        dpre[m * 512 + 256 + c] = (bf16)(d * tf * sg * (1.0f - sg));
+    }
+}
+// out[c] = scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C]; one workgroup per 64 channels,
+// fixed summation order (fp64 accumulation).
+__global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          long M, int C, float scale, float* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (c < C)
+        for (long m = part; m < M; m += 4) acc += (double)A[m * C + c] * (B ? (double)B[m * C + c] : 1.0);
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && c < C) out[c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale);
+}
+// ActNorm backward on one plane (model.py:86-94): in dy (becomes dx = dy * scale in place), y (becomes
+// x = y / scale - shift in place).
+__global__ __launch_bounds__(256) void actnorm_bwd_kernel(float* __restrict__ dy, float* __restrict__ y,
+                                                          const float* __restrict__ an, long n, int Ch) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i & (Ch - 1));
+        dy[i] *= an[Ch + c];
+        y[i] = y[i] * an[2 * Ch + c] - an[c];
+    }
+}
+// Weight-norm backward (convolutional.py:73-80): W = V g / ||V||_col.  dW, V: fp32 [K][N]; one
+// workgroup per output column: dg = sum_k dW V / nrm, dV = (g / nrm) (dW - V dg / nrm).
+__global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ dW, const float* __restrict__ V,
+                                                          const float* __restrict__ g, int K, int N,
+                                                          float* __restrict__ dV, float* __restrict__ dg) {
+    __shared__ double red[2][256];
+    const int n = blockIdx.x;
+    double ss = 0.0, dot = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const double v = V[(size_t)k * N + n];
+        ss += v * v;
+        dot += v * (double)dW[(size_t)k * N + n];
+    }
+    red[0][threadIdx.x] = ss;
+    red[1][threadIdx.x] = dot;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    const double nrm = sqrt(fmax(red[0][0], 1e-12)), dgn = red[1][0] / nrm;
+    if (threadIdx.x == 0) dg[n] = (float)dgn;
+    const double gn = (double)g[n] / nrm;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const size_t i = (size_t)k * N + n;
+        dV[i] = (float)(gn * ((double)dW[i] - (double)V[i] * dgn / nrm));
+    }
+}
+
+static inline unsigned ew_grid(long n) { long b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+void fwn_ew_actnorm_fwd(float* x, const float* an, long n, int Ch, hipStream_t st) {
+    hipLaunchKernelGGL(actnorm_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, an, n, Ch);
+}
+void fwn_ew_coupling_fwd(float* yb, const float* Z, const float* ez, long n, int Ch, float* partial, int nblocks,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(coupling_fwd_kernel, dim3(nblocks), dim3(256), 0, st, yb, Z, ez, n, Ch, partial);
+}
+void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
+                         int ldz, float* dzz, hipStream_t st) {
+    hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, ob, Z, ez, n, Ch, cls, (bf16*)dZ, ldz, dzz);
+}
+void fwn_ew_gate_bwd(const void* do_, const void* aux, long n, void* dpre, hipStream_t st) {
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, (const bf16*)do_, (const bf16*)aux, n, (bf16*)dpre);
+}
+void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_prod_kernel, dim3((C + 63) / 64), dim3(256), 0, st, A, B, M, C, scale, out);
+}
+void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st) {
+    hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, an, n, Ch);
+}
+void fwn_ew_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg, hipStream_t st) {
+    hipLaunchKernelGGL(wn_backward_kernel, dim3(N), dim3(256), 0, st, dW, V, g, K, N, dV, dg);
+}
