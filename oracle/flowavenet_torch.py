@@ -135,8 +135,9 @@ def _halves(x, parity):
     return (hi, lo) if parity else (lo, hi)
 
 
-def forward(fp, x, c, hp):
-    """x: [B,T,1], c: [B,F,mels] -> (log_p, logdet, z[B,T_last,C_last] channels-last)."""
+def forward(fp, x, c, hp, as_tensors=False):
+    """x: [B,T,1], c: [B,F,mels] -> (log_p, logdet, z[B,T_last,C_last] channels-last).
+    as_tensors: keep log_p / logdet as 0-dim tensors (for autograd, oracle/grad_torch.py)."""
     b, t, _ = x.shape
     cu = upsample(fp, c, hp)                             # [B, mels, T]
     xs = x.transpose(1, 2)                               # [B, 1, T]
@@ -169,6 +170,8 @@ def forward(fp, x, c, hp):
         h = xs.shape[1] // 2
         xs = torch.cat([xs[:, h:], xs[:, :h]], 1)
     log_p = (0.5 * (-math.log(2.0 * math.pi) - xs * xs)).mean()
+    if as_tensors:
+        return log_p, logdet, xs.transpose(1, 2).contiguous()
     return float(log_p), float(logdet), xs.transpose(1, 2).contiguous()
 
 

@@ -94,3 +94,324 @@ def weight_grad(x, dy, m, kx, n, *, shifts=(0,), ti=0, nsplit=None):
     part = gemm([(xt, mp, 0, 0)], dyt, n, rows + 1, out_f32=True, nsplit=nsplit)
     full = reduce_splits(part) if nsplit > 1 else part
     return full[:rows], full[rows]
+
+
+# =============================================================================================
+# Loss and gradients of the whole model (train.py:56-66: loss = -(log_p + logdet)), assembled from
+# the stage kernels.  Sequencing lives here in Python (one process, one stream); every arithmetic
+# step on activations is a libfwn.so launch.  Still missing: the gradients of the two up-sampling
+# transposed convolutions (returned as zeros) - see DESIGN.md section 8.
+# =============================================================================================
+import numpy as np
+
+from . import packing, weights
+
+SQH = float(np.sqrt(0.5))
+
+
+class _TrainPack:
+    """Inference packing plus the natural-order / transposed bf16 copies the backward GEMMs read."""
+
+    def __init__(self, params, hp, device):
+        import torch
+        self.hp, self.dev = hp, torch.device(device)
+        self.lib = _lib.load()
+        self.pm = packing.pack_model(params, hp, device, cond_mode=1)
+        self.params = params
+        self.flows = {}
+        self._idx = {}
+        self._scale = torch.empty(512, dtype=torch.float32, device=self.dev)
+        for i in range(hp.n_block):
+            for j in range(hp.n_flow):
+                self.flows[(i, j)] = self._pack_flow(i, j)
+
+    def _i32(self, key, arr):
+        import torch
+        if key not in self._idx:
+            self._idx[key] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.dev)
+        return self._idx[key]
+
+    def _f32(self, name):
+        import torch
+        v = self.params[name]
+        if isinstance(v, torch.Tensor):
+            return v.to(device=self.dev, dtype=torch.float32).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.dev)
+
+    def _pack(self, name, src_k, src_n, k_dst, n_dst, out, weight_norm=True):
+        import torch
+        v = self._f32(name + "/kernel")
+        k_src, n_src = v.shape[0] * v.shape[1], v.shape[2]
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        sc = None
+        if weight_norm:
+            g = self._f32(name + "/g")
+            _lib.check(self.lib.fwn_wn_scale(v.data_ptr(), g.data_ptr(), k_src, n_src, self._scale.data_ptr(), st), "fwn_wn_scale")
+            sc = self._scale.data_ptr()
+        _lib.check(self.lib.fwn_pack_bf16(v.data_ptr(), sc, src_k.data_ptr(), src_n.data_ptr(), n_src, k_dst, n_dst,
+                                          int(out.stride(0)), out.data_ptr(), st), "fwn_pack_bf16")
+        v.record_stream(torch.cuda.current_stream(self.dev))
+
+    def _pack_flow(self, i, j):
+        import torch
+        hp, dev = self.hp, self.dev
+        ch, half, L = 1 << i, hp.num_mels // 2, hp.n_layer
+        cin = half * (2 << i)
+        kcpad = packing.roundup(cin, 64)
+        wp = weights.flow_prefix(i, j) + "/WaveNet"
+        bz = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+        id256 = self._i32("id256", np.arange(256))
+        id768 = self._i32("id768", np.arange(768))
+        rows_f = self._i32("rows_f", np.concatenate([np.arange(256), np.full(256, -1)]))
+        rows_g = self._i32("rows_g", np.concatenate([np.full(256, -1), np.arange(256)]))
+        csrc = self._i32(("csrc", i), packing.cond_src_k(i, half))
+        br = packing.bitrev_table(i).astype(np.int64)
+        t = {}
+        # front: K = tap*Ch + tau (plane order)
+        fk = packing.front_src_k(i)[:3 * ch]
+        wf = bz(256, packing.roundup(3 * ch, 8))
+        self._pack(wp + "/Conv_front", self._i32(("fk", i), np.concatenate([fk, np.full(wf.shape[1] - 3 * ch, -1)])), id256,
+                   wf.shape[1], 256, wf)
+        wft = transpose_shift(wf, 256, 3 * ch, ld_dst=256)                      # [3Ch][256]
+        t["WfT"] = wft.view(3, ch, 256).permute(1, 0, 2).reshape(ch, 768).contiguous()       # [Ch][tap*256 + n]
+        t["Wd"], t["WdT"], t["Wc"], t["WcT"], t["WresT"], t["WskipT"] = [], [], [], [], [], []
+        wskip = bz(256, L * 256)
+        for l in range(L):
+            rp = "%s/ResBlock_%d" % (wp, l)
+            wd = bz(512, 768)
+            self._pack(rp + "/Conv_filter", id768, rows_f, 768, 512, wd)
+            self._pack(rp + "/Conv_gate", id768, rows_g, 768, 512, wd)
+            wdt = transpose_shift(wd, 512, 768, ld_dst=512)                     # [768][512]
+            t["WdT"].append(wdt.view(3, 256, 512).permute(1, 0, 2).reshape(256, 1536).contiguous())
+            wc = bz(512, kcpad)
+            self._pack(rp + "/filter_conv_c", csrc, rows_f, kcpad, 512, wc)
+            self._pack(rp + "/gate_conv_c", csrc, rows_g, kcpad, 512, wc)
+            t["WcT"].append(transpose_shift(wc, 512, cin, ld_dst=512))            # [cin][512]
+            if l + 1 < L:
+                wr = bz(256, 256)
+                self._pack(rp + "/res_conv", id256, id256, 256, 256, wr)
+                t["WresT"].append(transpose_shift(wr, 256, 256, ld_dst=256))
+            ws = bz(256, 256)
+            self._pack(rp + "/skip_conv", id256, id256, 256, 256, ws)
+            wskip[:, l * 256:(l + 1) * 256] = ws
+            t["WskipT"].append(transpose_shift(ws, 256, 256, ld_dst=256))
+        t["Wskip"] = wskip
+        t["bskip"] = sum(self._f32("%s/ResBlock_%d/skip_conv/bias" % (wp, l)) for l in range(L))
+        wfin = bz(256, 256)
+        self._pack(wp + "/Conv_final", id256, id256, 256, 256, wfin)
+        t["Wfin"], t["WfinT"] = wfin, transpose_shift(wfin, 256, 256, ld_dst=256)
+        t["bfin"] = self._f32(wp + "/Conv_final/bias")
+        # ZeroConv rows in plane order: row fg*Ch + tau serves logical channel fg*Ch + bitrev(tau)
+        zcol = np.concatenate([br, ch + br])
+        t["zcol"] = torch.from_numpy(zcol).to(dev)
+        n2 = 2 * ch
+        ldz = max(8, n2)
+        wz = bz(n2, 256)
+        self._pack(wp + "/ZeroConv1d", id256, self._i32(("zcol", i), zcol), 256, n2, wz, weight_norm=False)
+        t["Wz"] = wz
+        t["WzT"] = transpose_shift(wz, n2, 256, ld_dst=packing.roundup(n2, 64))[:, :ldz].contiguous()   # [256][ldz], zero padded
+        t["ldz"] = ldz
+        t["bz"] = self._f32(wp + "/ZeroConv1d/bias").reshape(-1)[t["zcol"]].contiguous()
+        t["ez"] = torch.exp(3.0 * self._f32(wp + "/ZeroConv1d/scale").reshape(-1))[t["zcol"]].contiguous()
+        return t
+
+
+class GradEngine:
+    """``loss_and_grads(params, x, c)``: one training forward + backward on the current device.
+
+    params: dict name -> fp32 array / tensor in the reference's layouts (``weights.param_shapes``).
+    Returns ``(loss, log_p, logdet, grads)`` with grads a dict name -> fp32 device tensor of the
+    parameter's shape (``d loss / d param``, loss = -(log_p + logdet), train.py:60)."""
+
+    def __init__(self, hparams, device="cuda"):
+        if not hparams.affine or hparams.causality:
+            raise NotImplementedError("affine=True, causality=False only")
+        self.hp, self.device = hparams, device
+        self.lib = _lib.load()
+
+    # ------------------------------------------------------------------ helpers
+    def _call(self, name, *args):
+        _lib.check(getattr(self.lib, name)(*args), name)
+
+    def loss_and_grads(self, params, x, c):
+        import torch
+        hp, lib = self.hp, self.lib
+        dev = torch.device(self.device)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        tp = _TrainPack(params, hp, self.device)
+        pm, md = tp.pm, tp.pm.model_desc
+        L, half = hp.n_layer, hp.num_mels // 2
+        x = torch.as_tensor(x).to(device=dev, dtype=torch.float32).contiguous()
+        c = torch.as_tensor(c).to(device=dev, dtype=torch.float32).contiguous()
+        B, T = int(x.shape[0]), int(x.shape[1])
+        if T % (1 << hp.n_block) or int(c.shape[1]) * hp.hop_size != T:
+            raise ValueError("bad shapes")
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+
+        # ---------------- forward, keeping what the backward needs ----------------
+        cplanes = b16(2, B, T, half)
+        cur, ups = c, []
+        for n, s_ in enumerate(hp.upsample_scales):
+            last = n == len(hp.upsample_scales) - 1
+            bb, hh, ww = cur.shape
+            out = None if last else f32(bb, hh * s_, ww)
+            self._call("fwn_upsample_stage", cur.data_ptr(), bb, hh, ww, md.up_w[n], md.up_bias[n], int(s_),
+                       None if last else out.data_ptr(), cplanes.data_ptr() if last else None, st)
+            ups.append(cur)
+            cur = out
+        planes = f32(2, B * T // 2)
+        self._call("fwn_split_planes", x.data_ptr(), B, T, planes.data_ptr(), st)
+        saved, partials, an_logdet = [], [], 0.0
+        p = 0
+        for i in range(hp.n_block):
+            ch = 1 << i
+            ti = T // (2 * ch)
+            m = B * ti
+            cin = half * (2 << i)
+            for j in range(hp.n_flow):
+                d = pm.flow_descs[i * hp.n_flow + j]
+                t = tp.flows[(i, j)]
+                an = pm.an[(i, j)]                                   # [2][4][Ch]
+                xa, xb = planes[p].view(m, ch), planes[p ^ 1].view(m, ch)
+                ca = cplanes[p].view(m, cin)
+                self._call("fwn_actnorm_apply", xa.data_ptr(), an[0].data_ptr(), m * ch, ch, st)
+                self._call("fwn_actnorm_apply", xb.data_ptr(), an[1].data_ptr(), m * ch, ch, st)
+                an_logdet = an_logdet + an[:, 3, :].sum() / (2 * ch)        # mean_C(3 logs): parameter-only scalar
+                h = [b16(m, 256) for _ in range(L)]
+                o = [b16(m, 256) for _ in range(L)]
+                aux = [b16(m, 512) for _ in range(L)]
+                self._call("fwn_front", C.byref(d), xa.data_ptr(), h[0].data_ptr(), None, m, ti, 0, st)
+                for l in range(L):
+                    self._call("fwn_gate_train", C.byref(d), l, h[l].data_ptr(), ca.data_ptr(), o[l].data_ptr(),
+                               aux[l].data_ptr(), m, ti, st)
+                    if l + 1 < L:
+                        self._call("fwn_res", C.byref(d), l, o[l].data_ptr(), h[l].data_ptr(), h[l + 1].data_ptr(), m, st)
+                s_act = gemm([(o[l], 256, 0, l * 256) for l in range(L)], t["Wskip"], 256, m, bias=t["bskip"], relu=True)
+                u_act = gemm([(s_act, 256, 0, 0)], t["Wfin"], 256, m, bias=t["bfin"], relu=True)
+                z = gemm([(u_act, 256, 0, 0)], t["Wz"], 2 * ch, m, bias=t["bz"], out_f32=True)
+                nb = max(1, min(256, m * ch // 1024))
+                part = f32(nb)
+                self._call("fwn_coupling_fwd", xb.data_ptr(), z.data_ptr(), t["ez"].data_ptr(), m, ch, part.data_ptr(), nb, st)
+                partials.append(part)
+                saved.append((i, j, p, h, o, aux, s_act, u_act, z))
+                p ^= 1
+        partial_all = torch.cat(partials)
+        out2 = f32(2)
+        self._call("fwn_prior_logp", planes.data_ptr(), B * T, partial_all.data_ptr(), partial_all.numel(), out2.data_ptr(), st)
+        log_p, logdet = out2[0], out2[1] + an_logdet
+        loss = -(log_p + logdet)
+
+        # ---------------- backward ----------------
+        grads = {}
+        # d loss / d z = z / (B T)   (log_p = mean 0.5(-log 2pi - z^2)): a copy, scaled by the ActNorm kernel
+        gplanes = planes.clone()
+        inv = torch.tensor([0.0, 1.0 / (B * T), 0.0, 0.0], dtype=torch.float32, device=dev)
+        self._call("fwn_actnorm_apply", gplanes.data_ptr(), inv.data_ptr(), B * T, 1, st)
+        dcplanes = torch.zeros(2, B * T * half, dtype=torch.float32, device=dev)
+        for (i, j, p, h, o, aux, s_act, u_act, z) in reversed(saved):
+            ch = 1 << i
+            ti = T // (2 * ch)
+            m = B * ti
+            cin = half * (2 << i)
+            t = tp.flows[(i, j)]
+            an = pm.an[(i, j)]
+            fp = weights.flow_prefix(i, j)
+            wp = fp + "/WaveNet"
+            xa, xb = planes[p].view(m, ch), planes[p ^ 1].view(m, ch)          # y_a, out_b
+            ga, gb = gplanes[p].view(m, ch), gplanes[p ^ 1].view(m, ch)
+            ca = cplanes[p].view(m, cin)
+            dca = dcplanes[p].view(m, cin)
+            br = torch.from_numpy(packing.bitrev_table(i).astype(np.int64)).to(dev)
+            # coupling
+            ldz = t["ldz"]
+            dz = torch.zeros(m, ldz, dtype=torch.bfloat16, device=dev)
+            dzz = f32(m, 2 * ch)
+            self._call("fwn_coupling_bwd", gb.data_ptr(), xb.data_ptr(), z.data_ptr(), t["ez"].data_ptr(), m, ch,
+                       1.0 / (2.0 * m * ch), dz.data_ptr(), ldz, dzz.data_ptr(), st)
+            dscale = f32(2 * ch)
+            self._call("fwn_colsum_prod", dzz.data_ptr(), None, m, 2 * ch, 3.0, dscale.data_ptr(), st)
+            zc = t["zcol"]
+            g_scale = f32(2 * ch); g_scale[zc] = dscale
+            grads[wp + "/ZeroConv1d/scale"] = g_scale.view(1, 1, -1)
+            dwz, dbz = weight_grad(u_act, dz, m, 256, 2 * ch)
+            g_wz = f32(256, 2 * ch); g_wz[:, zc] = dwz
+            g_bz = f32(2 * ch); g_bz[zc] = dbz
+            grads[wp + "/ZeroConv1d/kernel"] = g_wz.view(1, 256, 2 * ch)
+            grads[wp + "/ZeroConv1d/bias"] = g_bz
+            du = gemm([(dz, ldz, 0, 0)], t["WzT"], 256, m, mask=u_act)
+            self._wn(grads, params, wp + "/Conv_final", *weight_grad(s_act, du, m, 256, 256), (1, 256, 256))
+            ds = gemm([(du, 256, 0, 0)], t["WfinT"], 256, m, mask=s_act)
+            d_o = []
+            for l in range(L):
+                rp = "%s/ResBlock_%d" % (wp, l)
+                self._wn(grads, params, rp + "/skip_conv", *weight_grad(o[l], ds, m, 256, 256), (1, 256, 256))
+                d_o.append(gemm([(ds, 256, 0, 0)], t["WskipT"][l], 256, m))
+            dh_next = None
+            for l in range(L - 1, -1, -1):
+                rp = "%s/ResBlock_%d" % (wp, l)
+                dil = 3 ** l
+                if dh_next is not None:      # h_{l+1} = (h_l + res(o_l)) sqrt(1/2)
+                    dw, db = weight_grad(o[l], dh_next, m, 256, 256)
+                    self._wn(grads, params, rp + "/res_conv", dw * SQH, db * SQH, (1, 256, 256))
+                    d_o[l] = gemm([(dh_next, 256, 0, 0)], t["WresT"][l], 256, m, res=d_o[l], rscale=1.0 / SQH, oscale=SQH)
+                else:
+                    shp = weights.param_shapes(hp)
+                    for nm in ("kernel", "g", "bias"):      # dead res_conv of the last layer (modules.py:126-128)
+                        grads["%s/res_conv/%s" % (rp, nm)] = torch.zeros(shp["%s/res_conv/%s" % (rp, nm)], dtype=torch.float32, device=dev)
+                dpre = b16(m, 512)
+                self._call("fwn_gate_bwd", d_o[l].data_ptr(), aux[l].data_ptr(), m, dpre.data_ptr(), st)
+                dw, db = weight_grad(h[l], dpre, m, 256, 512, shifts=(-dil, 0, dil), ti=ti)
+                self._wn(grads, params, rp + "/Conv_filter", dw[:, :256].contiguous(), db[:256], (3, 256, 256))
+                self._wn(grads, params, rp + "/Conv_gate", dw[:, 256:].contiguous(), db[256:], (3, 256, 256))
+                dwc, dbc = weight_grad(ca, dpre, m, cin, 512)
+                src = torch.from_numpy(packing.cond_src_k(i, half)[:cin].astype(np.int64)).to(dev)
+                dwc_log = f32(cin, 512); dwc_log[src] = dwc
+                self._wn(grads, params, rp + "/filter_conv_c", dwc_log[:, :256].contiguous(), dbc[:256], (1, cin, 256))
+                self._wn(grads, params, rp + "/gate_conv_c", dwc_log[:, 256:].contiguous(), dbc[256:], (1, cin, 256))
+                gemm([(dpre, 512, 0, 0)], t["WcT"][l], cin, m, out=dca, accumulate=True)
+                segs = [(dpre, 512, -(tap - 1) * dil, tap * 512) for tap in range(3)]
+                dh = gemm(segs, t["WdT"][l], 256, m, ti=ti, res=dh_next, rscale=SQH if dh_next is not None else 0.0,
+                          mask=h[0] if l == 0 else None)
+                dh_next = dh
+            # front conv
+            ya_bf = xa.to(torch.bfloat16)
+            dwf, dbf = weight_grad(ya_bf, dh_next, m, ch, 256, shifts=(-1, 0, 1), ti=ti)
+            dwf_log = f32(3, ch, 256); dwf_log[:, br] = dwf.view(3, ch, 256)
+            self._wn(grads, params, wp + "/Conv_front", dwf_log.view(3 * ch, 256), dbf, (3, ch, 256))
+            segs = [(dh_next, 256, -(tap - 1), tap * 256) for tap in range(3)]
+            gemm(segs, t["WfT"], ch, m, ti=ti, out=ga, accumulate=True)
+            # ActNorm (both planes), back to the flow's inputs
+            g_b, g_logs = f32(2 * ch), f32(2 * ch)
+            for role, (yy, gg) in enumerate(((xa, ga), (xb, gb))):
+                s1, s2 = f32(ch), f32(ch)
+                self._call("fwn_colsum_prod", gg.data_ptr(), None, m, ch, 1.0, s1.data_ptr(), st)
+                self._call("fwn_colsum_prod", gg.data_ptr(), yy.data_ptr(), m, ch, 3.0, s2.data_ptr(), st)
+                g_b[role * ch + br] = s1 * an[role, 1]
+                g_logs[role * ch + br] = s2 - 3.0 / (2 * ch)
+                self._call("fwn_actnorm_bwd", gg.data_ptr(), yy.data_ptr(), an[role].data_ptr(), m * ch, ch, st)
+            grads[fp + "/ActNorm/b"] = g_b.view(1, 1, -1)
+            grads[fp + "/ActNorm/logs"] = g_logs.view(1, 1, -1)
+        # TODO(round 2): backward of the up-sampling transposed convolutions from dcplanes
+        shp = weights.param_shapes(hp)
+        for n in range(len(hp.upsample_scales)):
+            for nm in ("kernel", "g", "bias"):
+                k = "upsample_%d/%s" % (n, nm)
+                grads[k] = torch.zeros(shp[k], dtype=torch.float32, device=dev)
+        self.last_dcplanes = dcplanes
+        return loss, log_p, logdet, grads
+
+    def _wn(self, grads, params, name, dw, db, shape):
+        """dW (fp32 [K][N], reference order) of a weight-normed conv -> grads of kernel, g, bias."""
+        import torch
+        dev = dw.device
+        v = torch.as_tensor(params[name + "/kernel"]).to(device=dev, dtype=torch.float32).contiguous()
+        g = torch.as_tensor(params[name + "/g"]).to(device=dev, dtype=torch.float32).contiguous()
+        k, n = dw.shape
+        dv, dg = torch.empty(k, n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+        dw = dw.contiguous()
+        self._call("fwn_wn_backward", dw.data_ptr(), v.data_ptr(), g.data_ptr(), k, n, dv.data_ptr(), dg.data_ptr(),
+                   torch.cuda.current_stream(dev).cuda_stream)
+        grads[name + "/kernel"] = dv.view(shape)
+        grads[name + "/g"] = dg
+        grads[name + "/bias"] = db.clone()
