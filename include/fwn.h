@@ -205,6 +205,12 @@ int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, voi
 int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg,
                     void* stream);
 
+/* Backward of one up-sampling stage (fwn_upsample_stage with fp32 output): y, dy [B][H*s][W], x [B][H][W].
+ * dy <- dy * LeakyReLU'(y) in place; dx (may be NULL) <- gradient wrt x; dwk [2s][3] and dbias[1] <-
+ * gradients of the (weight-normed) kernel and bias, fixed summation order.          (model.py:301-311) */
+int fwn_upsample_bwd(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
+                     float* dx, float* dwk, float* dbias, void* stream);
+
 /* ---- whole model (replaces FloWaveNet.forward / .reverse, model.py:317-396) ---- */
 typedef struct fwn_model_desc {
     int32_t n_block, n_flow, n_layer, num_mels;

@@ -298,6 +298,14 @@ int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int 
     return check_launch("fwn_wn_backward");
 }
 
+int fwn_upsample_bwd(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
+                     float* dx, float* dwk, float* dbias, void* stream) {
+    REQUIRE(dy && y && x && wk && dwk && dbias, "fwn_upsample_bwd: null pointer");
+    REQUIRE(B > 0 && H > 0 && W > 0 && s > 0 && (s % 2) == 0, "fwn_upsample_bwd: bad shape (s must be even)");
+    fwn_up_bwd_launch(dy, y, x, B, H, W, s, wk, dx, dwk, dbias, (hipStream_t)stream);
+    return check_launch("fwn_upsample_bwd");
+}
+
 // ---- data-parallel optimiser step -------------------------------------------------------------
 int fwn_grad_norm_partials(int64_t n) { return fwn_sqnorm_blocks((long)n); }
 

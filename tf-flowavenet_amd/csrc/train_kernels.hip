@@ -295,3 +295,69 @@ void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hi
 void fwn_ew_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg, hipStream_t st) {
     hipLaunchKernelGGL(wn_backward_kernel, dim3(N), dim3(256), 0, st, dW, V, g, K, N, dV, dg);
 }
+
+// ---- backward of one up-sampling stage: Conv2DTranspose((2s,3),(s,1),'same') + LeakyReLU(0.4) -----
+// (model.py:301-311; forward in aux_kernels.hip upsample_kernel).  y, dy: [B][H*s][W]; x: [B][H][W].
+// dpre = dy * (y > 0 ? 1 : 0.4), in place over dy.
+__global__ __launch_bounds__(256) void up_dpre_kernel(float* __restrict__ dy, const float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        dy[i] *= y[i] > 0.0f ? 1.0f : 0.4f;
+}
+// dx[b,i,w] = sum_{k,kw} dpre[b, i*s + k - s/2, w + kw - 1] * wk[k][kw]
+__global__ __launch_bounds__(256) void up_dx_kernel(const float* __restrict__ dpre, int B, int H, int W, int s,
+                                                    const float* __restrict__ wk, float* __restrict__ dx) {
+    const long total = (long)B * H * W;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int w = (int)(idx % W), i = (int)((idx / W) % H), b = (int)(idx / ((long)W * H));
+        float acc = 0.0f;
+        for (int k = 0; k < 2 * s; ++k) {
+            const int tau = i * s + k - s / 2;
+            if (tau < 0 || tau >= H * s) continue;
+            const float* row = dpre + ((long)b * H * s + tau) * W;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = w + kw - 1;
+                if (ww >= 0 && ww < W) acc = fmaf(row[ww], wk[k * 3 + kw], acc);
+            }
+        }
+        dx[idx] = acc;
+    }
+}
+// one workgroup per kernel tap (k, kw), plus one for the bias: fixed-order sums over (b, i, w).
+__global__ __launch_bounds__(256) void up_dw_kernel(const float* __restrict__ dpre, const float* __restrict__ x, int B,
+                                                    int H, int W, int s, float* __restrict__ dwk,
+                                                    float* __restrict__ dbias) {
+    __shared__ double red[256];
+    const int tap = blockIdx.x, ntap = 6 * s;
+    double acc = 0.0;
+    if (tap < ntap) {
+        const int k = tap / 3, kw = tap % 3;
+        const long total = (long)B * H * W;
+        for (long idx = threadIdx.x; idx < total; idx += 256) {
+            const int w = (int)(idx % W), i = (int)((idx / W) % H), b = (int)(idx / ((long)W * H));
+            const int tau = i * s + k - s / 2, ww = w + kw - 1;
+            if (tau >= 0 && tau < H * s && ww >= 0 && ww < W)
+                acc += (double)x[idx] * (double)dpre[((long)b * H * s + tau) * W + ww];
+        }
+    } else {
+        const long total = (long)B * H * s * W;
+        for (long idx = threadIdx.x; idx < total; idx += 256) acc += (double)dpre[idx];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (tap < ntap) dwk[tap] = (float)red[0];
+        else *dbias = (float)red[0];
+    }
+}
+void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
+                       float* dx, float* dwk, float* dbias, hipStream_t st) {
+    const long n = (long)B * H * s * W;
+    hipLaunchKernelGGL(up_dpre_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, n);
+    if (dx) hipLaunchKernelGGL(up_dx_kernel, dim3(ew_grid((long)B * H * W)), dim3(256), 0, st, dy, B, H, W, s, wk, dx);
+    hipLaunchKernelGGL(up_dw_kernel, dim3(6 * s + 1), dim3(256), 0, st, dy, x, B, H, W, s, dwk, dbias);
+}

@@ -99,8 +99,8 @@ def weight_grad(x, dy, m, kx, n, *, shifts=(0,), ti=0, nsplit=None):
 # =============================================================================================
 # Loss and gradients of the whole model (train.py:56-66: loss = -(log_p + logdet)), assembled from
 # the stage kernels.  Sequencing lives here in Python (one process, one stream); every arithmetic
-# step on activations is a libfwn.so launch.  Still missing: the gradients of the two up-sampling
-# transposed convolutions (returned as zeros) - see DESIGN.md section 8.
+# step on activations is a libfwn.so launch.  A few parameter-sized
+# finishing steps (per-channel scalings of reduced sums, constants of the log-det terms) are torch ops.
 # =============================================================================================
 import numpy as np
 
@@ -392,12 +392,25 @@ class GradEngine:
                 self._call("fwn_actnorm_bwd", gg.data_ptr(), yy.data_ptr(), an[role].data_ptr(), m * ch, ch, st)
             grads[fp + "/ActNorm/b"] = g_b.view(1, 1, -1)
             grads[fp + "/ActNorm/logs"] = g_logs.view(1, 1, -1)
-        # TODO(round 2): backward of the up-sampling transposed convolutions from dcplanes
-        shp = weights.param_shapes(hp)
-        for n in range(len(hp.upsample_scales)):
-            for nm in ("kernel", "g", "bias"):
-                k = "upsample_%d/%s" % (n, nm)
-                grads[k] = torch.zeros(shp[k], dtype=torch.float32, device=dev)
+        # up-sampling transposed convolutions (model.py:301-311), last stage first
+        nmel = 2 * half
+        dy = dcplanes.view(2, B, T, half).permute(1, 2, 0, 3).reshape(B, T, nmel).contiguous()
+        y = cplanes.permute(1, 2, 0, 3).reshape(B, T, nmel).float().contiguous()
+        for n in range(len(hp.upsample_scales) - 1, -1, -1):
+            xin, s_ = ups[n], int(hp.upsample_scales[n])
+            hh = int(xin.shape[1])
+            dx = f32(B, hh, nmel) if n > 0 else None
+            dwk, dbias = f32(2 * s_, 3), f32(1)
+            self._call("fwn_upsample_bwd", dy.data_ptr(), y.data_ptr(), xin.data_ptr(), B, hh, nmel, s_, md.up_w[n],
+                       dx.data_ptr() if dx is not None else None, dwk.data_ptr(), dbias.data_ptr(), st)
+            v = torch.as_tensor(params["upsample_%d/kernel" % n]).to(device=dev, dtype=torch.float32).reshape(2 * s_, 3).contiguous()
+            g3 = torch.as_tensor(params["upsample_%d/g" % n]).to(device=dev, dtype=torch.float32).reshape(1).expand(3).contiguous()
+            dv, dg3 = f32(2 * s_, 3), f32(3)
+            self._call("fwn_wn_backward", dwk.data_ptr(), v.data_ptr(), g3.data_ptr(), 2 * s_, 3, dv.data_ptr(), dg3.data_ptr(), st)
+            grads["upsample_%d/kernel" % n] = dv.view(2 * s_, 3, 1, 1)
+            grads["upsample_%d/g" % n] = dg3.sum().view(1)      # the three kw columns share one scalar g (convolutional.py:186)
+            grads["upsample_%d/bias" % n] = dbias
+            dy, y = dx, xin
         self.last_dcplanes = dcplanes
         return loss, log_p, logdet, grads
 
