@@ -124,3 +124,20 @@ def test_gradient_is_reproducible_bit_for_bit():
     _, _, _, (l1, _, _, g1) = _grad_case(cfg, 2, 128, 7)
     _, _, _, (l2, _, _, g2) = _grad_case(cfg, 2, 128, 7)
     assert float(l1) == float(l2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+
+
+def test_trainer_steps_reduce_the_loss_on_a_fixed_batch():
+    """DDI + a few clip/Adam steps (train.py:15-32,221-229) driven by the HIP gradients."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import Trainer
+    hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
+    inp = W.synthetic_inputs(hp, 4, 256)
+    x, c = torch.from_numpy(inp["x"]).reshape(4, 256).cuda(), torch.from_numpy(inp["c"]).cuda()
+    tr = Trainer(hp, W.synthetic_params(hp, 11))
+    tr.ddi(x, c)
+    losses = [float(tr.step(x, c)[0]) for _ in range(25)]
+    assert np.isfinite(losses).all()
+    assert min(losses[-5:]) < losses[0] - 0.05, losses

@@ -428,3 +428,37 @@ class GradEngine:
         grads[name + "/kernel"] = dv.view(shape)
         grads[name + "/g"] = dg
         grads[name + "/bias"] = db.clone()
+
+
+class Trainer:
+    """One rank of the data-parallel training step (train.py:35-83 ``build_model`` + the session loop
+    body): gradients of -(log_p + logdet) on this rank's batch (``GradEngine``), then
+    ``optim.DataParallelAdam`` = RCCL all-reduce of the flat gradient, global-norm clip, Adam on the
+    fp32 masters.  ``ddi`` performs the ActNorm data-dependent init of the first step
+    (train.py:221,229 with init=True)."""
+
+    def __init__(self, hparams, params, device="cuda", group=None):
+        from .optim import DataParallelAdam
+        self.hp, self.device = hparams, device
+        self.opt = DataParallelAdam(hparams, params, device, group=group)
+        self.engine = GradEngine(hparams, device)
+
+    def ddi(self, x, c):
+        from .model import FloWaveNet
+        import torch
+        views = self.opt.master_views()
+        m = FloWaveNet(self.hp, init=True, device=self.device, cond_mode=1).load_params(views)
+        xx = torch.as_tensor(x).to(self.device)
+        m.forward(xx.reshape(xx.shape[0], -1, 1), torch.as_tensor(c).to(self.device))
+        for k, v in m.export_actnorm().items():
+            views[k].copy_(torch.as_tensor(v).to(self.device).reshape(views[k].shape))
+
+    def step(self, x, c):
+        """-> (loss, log_p, logdet, grad_norm) device scalars; the masters are updated in place."""
+        params = self.opt.master_views()
+        loss, log_p, logdet, grads = self.engine.loss_and_grads(params, x, c)
+        gv = self.opt.grad_views()
+        for k, g in grads.items():
+            gv[k].copy_(g.reshape(gv[k].shape))
+        gnorm = self.opt.step()
+        return loss, log_p, logdet, gnorm
