@@ -155,6 +155,9 @@ def upsample_kernel(params, n: int) -> "tuple[np.ndarray, float]":
 # ---------------------------------------------------------------------------------------------
 # Device side
 # ---------------------------------------------------------------------------------------------
+_IDX_CACHE = {}
+
+
 class PackedModel:
     """Owns the packed device tensors and the ctypes descriptors that point into them."""
 
@@ -186,22 +189,59 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
     dev = torch.device(device)
     stream = torch.cuda.current_stream(dev).cuda_stream
     L = hp.n_layer
-    idx_cache = {}
 
     def dev_i32(key, fn):
-        if key not in idx_cache:
-            idx_cache[key] = pm.keep(torch.from_numpy(np.ascontiguousarray(fn(), dtype=np.int32)).to(dev))
-        return idx_cache[key]
+        # index tables depend only on (block, num_mels): kept across calls (a training step re-packs
+        # the weights every step)
+        gk = (str(dev), hp.num_mels, key)
+        if gk not in _IDX_CACHE:
+            _IDX_CACHE[gk] = torch.from_numpy(np.ascontiguousarray(fn(), dtype=np.int32)).to(dev)
+        return _IDX_CACHE[gk]
 
-    def dev_f32(a):
-        return pm.keep(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev))
+    # Small fp32 tables (biases, ActNorm / ZeroConv tables, up-sampling kernels) are gathered on the
+    # host and uploaded in ONE copy at the end; `put(setter, array)` calls setter(view) once the
+    # device copy exists.  Every table starts on a 16-byte boundary (float4 loads in the kernels).
+    pending = []
+
+    def put(setter, a):
+        pending.append((setter, np.ascontiguousarray(a, dtype=np.float32).reshape(-1), np.shape(a)))
+
+    def flush_tables():
+        offs, total = [], 0
+        for _, a, _ in pending:
+            offs.append(total)
+            total += (a.size + 3) // 4 * 4
+        host = np.zeros(max(total, 4), dtype=np.float32)
+        for (_, a, _), off in zip(pending, offs):
+            host[off:off + a.size] = a
+        buf = pm.keep(torch.from_numpy(host).to(dev))
+        for (setter, a, shape), off in zip(pending, offs):
+            setter(buf[off:off + a.size].view(shape))
 
     class _HostView(dict):
         """params may hold device tensors (fp32 masters of optim.DataParallelAdam): the few
-        host-side reductions (bias sums, ActNorm / ZeroConv scale tables) read them through here."""
+        host-side reductions (bias sums, ActNorm / ZeroConv scale tables) read them through here.
+        All small device tensors come over in ONE copy (a per-tensor .cpu() is a sync each)."""
+        _cache = None
+
+        def _fill(self):
+            small = [(k, v) for k, v in params.items() if isinstance(v, torch.Tensor) and v.numel() <= 4096]
+            self._cache = {}
+            if small:
+                flat = torch.cat([v.detach().reshape(-1).to(torch.float32) for _, v in small]).cpu().numpy()
+                off = 0
+                for k, v in small:
+                    n = v.numel()
+                    self._cache[k] = flat[off:off + n].reshape(tuple(v.shape))
+                    off += n
+
         def __getitem__(self, k):
             v = params[k]
-            return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v
+            if not isinstance(v, torch.Tensor):
+                return v
+            if self._cache is None:
+                self._fill()
+            return self._cache[k] if k in self._cache else v.detach().cpu().numpy()
 
     hostp = _HostView()
 
@@ -217,6 +257,8 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
         output channel (folded into the weight-norm scale before the bf16 rounding)."""
         def up(x):
             if isinstance(x, torch.Tensor):
+                if x.device == dev and x.dtype == torch.float32 and x.is_contiguous():
+                    return x
                 return x.to(device=dev, dtype=torch.float32).contiguous()
             return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
 
@@ -268,7 +310,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
                 wfront2 = bf16_zeros(FILTER, 6 * ch)
                 pack(wp + "/Conv_front", f2, ident256, 6 * ch, FILTER, wfront2, 6 * ch)
                 d.Wfront2 = wfront2.data_ptr()
-            d.bfront = dev_f32(hostp[wp + "/Conv_front/bias"]).data_ptr()
+            put(lambda v, d=d: setattr(d, "bfront", v.data_ptr()), hostp[wp + "/Conv_front/bias"])
 
             wskip = bf16_zeros(FILTER, L * FILTER)
             bskip = np.zeros(FILTER, dtype=np.float64)
@@ -289,21 +331,21 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
                 bg = np.where(fg == 0, bsum[0][gch], bsum[1][gch])
                 d.Wd[l] = wd.data_ptr()
                 d.Wc[l] = wc.data_ptr()
-                d.bgate[l] = dev_f32(bg).data_ptr()
+                put(lambda v, d=d, l=l: d.bgate.__setitem__(l, v.data_ptr()), bg)
                 if l + 1 < L:   # the last layer's res_conv is dead (modules.py:126-128,175-176)
                     wr = bf16_zeros(FILTER, FILTER)
                     pack(rp + "/res_conv", ident256, ident256, FILTER, FILTER, wr, FILTER)
                     d.Wres[l] = wr.data_ptr()
-                    d.bres[l] = dev_f32(hostp[rp + "/res_conv/bias"]).data_ptr()
+                    put(lambda v, d=d, l=l: d.bres.__setitem__(l, v.data_ptr()), hostp[rp + "/res_conv/bias"])
                 pack(rp + "/skip_conv", ident256, ident256, FILTER, FILTER, wskip, L * FILTER, col_off=l * FILTER)
                 bskip += np.asarray(hostp[rp + "/skip_conv/bias"], np.float64)
             d.Wskip = wskip.data_ptr()
-            d.bskip = dev_f32(bskip).data_ptr()
+            put(lambda v, d=d: setattr(d, "bskip", v.data_ptr()), bskip)
 
             wfin = bf16_zeros(FILTER, FILTER)
             pack(wp + "/Conv_final", accperm, ident256, FILTER, FILTER, wfin, FILTER)
             d.Wfinal = wfin.data_ptr()
-            d.bfinal = dev_f32(hostp[wp + "/Conv_final/bias"]).data_ptr()
+            put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), hostp[wp + "/Conv_final/bias"])
 
             wz = bf16_zeros(npt * 64, FILTER)
             pack(wp + "/ZeroConv1d", accperm, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
@@ -315,12 +357,13 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             bz[valid] = zb[zsn_host[valid]]
             ez[valid] = np.exp(3.0 * zs[zsn_host[valid]])
             d.Wzero = wz.data_ptr()
-            d.bzero = dev_f32(bz).data_ptr()
-            d.ezero = dev_f32(ez).data_ptr()
+            put(lambda v, d=d: setattr(d, "bzero", v.data_ptr()), bz)
+            put(lambda v, d=d: setattr(d, "ezero", v.data_ptr()), ez)
 
-            an = dev_f32(actnorm_table(hostp[fp + "/ActNorm/b"], hostp[fp + "/ActNorm/logs"], i))
-            pm.an[(i, j)] = an
-            d.an = an.data_ptr()
+            def set_an(v, d=d, key=(i, j)):
+                pm.an[key] = v
+                d.an = v.data_ptr()
+            put(set_an, actnorm_table(hostp[fp + "/ActNorm/b"], hostp[fp + "/ActNorm/logs"], i))
 
     md = pm.model_desc
     md.n_block, md.n_flow, md.n_layer, md.num_mels = hp.n_block, hp.n_flow, L, hp.num_mels
@@ -330,8 +373,9 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
     for n, s in enumerate(hp.upsample_scales):
         wk, bias = upsample_kernel(hostp, n)
         md.up_scale[n] = int(s)
-        md.up_w[n] = dev_f32(wk).data_ptr()
+        put(lambda v, n=n: md.up_w.__setitem__(n, v.data_ptr()), wk)
         md.up_bias[n] = bias
+    flush_tables()
     md.flows = C.cast(pm.flow_descs, C.POINTER(_lib.FlowDesc))
     md.cond_mode = int(cond_mode)
     torch.cuda.current_stream(dev).synchronize()

@@ -14,9 +14,13 @@ import ctypes as C
 from . import _lib
 
 
+_STREAMS = {}     # device -> stream handle, only while a GradEngine call is running (it never switches streams)
+
+
 def _stream(t):
     import torch
-    return torch.cuda.current_stream(t.device).cuda_stream
+    h = _STREAMS.get(t.device)
+    return h if h is not None else torch.cuda.current_stream(t.device).cuda_stream
 
 
 def gemm(segs, w, n, m, *, ti=0, bias=None, res=None, rscale=1.0, mask=None, relu=False, oscale=1.0,
@@ -121,20 +125,33 @@ class _TrainPack:
         self.flows = {}
         self._idx = {}
         self._scale = torch.empty(512, dtype=torch.float32, device=self.dev)
+        self.br = [self._i64(("br", i), packing.bitrev_table(i)) for i in range(hp.n_block)]
+        self.csrc64 = [self._i64(("csrc", i), packing.cond_src_k(i, hp.num_mels // 2)[:(hp.num_mels // 2) * (2 << i)])
+                       for i in range(hp.n_block)]
         for i in range(hp.n_block):
             for j in range(hp.n_flow):
                 self.flows[(i, j)] = self._pack_flow(i, j)
 
     def _i32(self, key, arr):
         import torch
-        if key not in self._idx:
-            self._idx[key] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.dev)
-        return self._idx[key]
+        gk = (str(self.dev), self.hp.num_mels, "train", key)
+        if gk not in packing._IDX_CACHE:
+            packing._IDX_CACHE[gk] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(self.dev)
+        return packing._IDX_CACHE[gk]
+
+    def _i64(self, key, arr):
+        import torch
+        gk = (str(self.dev), self.hp.num_mels, "train64", key)
+        if gk not in packing._IDX_CACHE:
+            packing._IDX_CACHE[gk] = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(self.dev)
+        return packing._IDX_CACHE[gk]
 
     def _f32(self, name):
         import torch
         v = self.params[name]
         if isinstance(v, torch.Tensor):
+            if v.device == self.dev and v.dtype == torch.float32 and v.is_contiguous():
+                return v
             return v.to(device=self.dev, dtype=torch.float32).contiguous()
         return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.dev)
 
@@ -203,7 +220,7 @@ class _TrainPack:
         t["bfin"] = self._f32(wp + "/Conv_final/bias")
         # ZeroConv rows in plane order: row fg*Ch + tau serves logical channel fg*Ch + bitrev(tau)
         zcol = np.concatenate([br, ch + br])
-        t["zcol"] = torch.from_numpy(zcol).to(dev)
+        t["zcol"] = self._i64(("zcol", i), zcol)
         n2 = 2 * ch
         ldz = max(8, n2)
         wz = bz(n2, 256)
@@ -234,11 +251,20 @@ class GradEngine:
         _lib.check(getattr(self.lib, name)(*args), name)
 
     def loss_and_grads(self, params, x, c):
+        try:
+            return self._loss_and_grads(params, x, c)
+        finally:
+            _STREAMS.clear()
+
+    def _loss_and_grads(self, params, x, c):
         import torch
         hp, lib = self.hp, self.lib
         dev = torch.device(self.device)
         st = torch.cuda.current_stream(dev).cuda_stream
-        tp = _TrainPack(params, hp, self.device)
+        _STREAMS.clear()
+        _STREAMS[torch.zeros(0, device=dev).device] = st
+        shp = weights.param_shapes(hp)
+        tp = self._tp = _TrainPack(params, hp, self.device)
         pm, md = tp.pm, tp.pm.model_desc
         L, half = hp.n_layer, hp.num_mels // 2
         x = torch.as_tensor(x).to(device=dev, dtype=torch.float32).contiguous()
@@ -322,7 +348,7 @@ class GradEngine:
             ga, gb = gplanes[p].view(m, ch), gplanes[p ^ 1].view(m, ch)
             ca = cplanes[p].view(m, cin)
             dca = dcplanes[p].view(m, cin)
-            br = torch.from_numpy(packing.bitrev_table(i).astype(np.int64)).to(dev)
+            br = tp.br[i]
             # coupling
             ldz = t["ldz"]
             dz = torch.zeros(m, ldz, dtype=torch.bfloat16, device=dev)
@@ -356,7 +382,6 @@ class GradEngine:
                     self._wn(grads, params, rp + "/res_conv", dw * SQH, db * SQH, (1, 256, 256))
                     d_o[l] = gemm([(dh_next, 256, 0, 0)], t["WresT"][l], 256, m, res=d_o[l], rscale=1.0 / SQH, oscale=SQH)
                 else:
-                    shp = weights.param_shapes(hp)
                     for nm in ("kernel", "g", "bias"):      # dead res_conv of the last layer (modules.py:126-128)
                         grads["%s/res_conv/%s" % (rp, nm)] = torch.zeros(shp["%s/res_conv/%s" % (rp, nm)], dtype=torch.float32, device=dev)
                 dpre = b16(m, 512)
@@ -365,8 +390,7 @@ class GradEngine:
                 self._wn(grads, params, rp + "/Conv_filter", dw[:, :256].contiguous(), db[:256], (3, 256, 256))
                 self._wn(grads, params, rp + "/Conv_gate", dw[:, 256:].contiguous(), db[256:], (3, 256, 256))
                 dwc, dbc = weight_grad(ca, dpre, m, cin, 512)
-                src = torch.from_numpy(packing.cond_src_k(i, half)[:cin].astype(np.int64)).to(dev)
-                dwc_log = f32(cin, 512); dwc_log[src] = dwc
+                dwc_log = f32(cin, 512); dwc_log[tp.csrc64[i]] = dwc
                 self._wn(grads, params, rp + "/filter_conv_c", dwc_log[:, :256].contiguous(), dbc[:256], (1, cin, 256))
                 self._wn(grads, params, rp + "/gate_conv_c", dwc_log[:, 256:].contiguous(), dbc[256:], (1, cin, 256))
                 gemm([(dpre, 512, 0, 0)], t["WcT"][l], cin, m, out=dca, accumulate=True)
@@ -418,8 +442,7 @@ class GradEngine:
         """dW (fp32 [K][N], reference order) of a weight-normed conv -> grads of kernel, g, bias."""
         import torch
         dev = dw.device
-        v = torch.as_tensor(params[name + "/kernel"]).to(device=dev, dtype=torch.float32).contiguous()
-        g = torch.as_tensor(params[name + "/g"]).to(device=dev, dtype=torch.float32).contiguous()
+        v, g = self._tp._f32(name + "/kernel"), self._tp._f32(name + "/g")
         k, n = dw.shape
         dv, dg = torch.empty(k, n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
         dw = dw.contiguous()
@@ -452,6 +475,12 @@ class Trainer:
         m.forward(xx.reshape(xx.shape[0], -1, 1), torch.as_tensor(c).to(self.device))
         for k, v in m.export_actnorm().items():
             views[k].copy_(torch.as_tensor(v).to(self.device).reshape(views[k].shape))
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.opt.group) > 1:
+            # every rank must start from the same ActNorm init: rank 0's statistics win (the reference
+            # lets its towers race on this assign)
+            dist.broadcast(self.opt.w, src=dist.get_global_rank(self.opt.group, 0) if self.opt.group is not None else 0,
+                           group=self.opt.group)
 
     def step(self, x, c):
         """-> (loss, log_p, logdet, grad_norm) device scalars; the masters are updated in place."""
