@@ -191,7 +191,8 @@ int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void*
  * fwn_coupling_bwd : g = dL/d out_b <- dL/d y_b; out_b <- y_b; dZ (bf16, ld ldz) <- (dL/dlog_s | dL/dt)
  *                    with the log-det term cls = 1/(2 M Ch) added; dzz <- dZ * Z (ZeroConv scale gradient)
  * fwn_gate_bwd     : dpre [M][512] <- (do sg (1 - tf^2) | do tf sg (1 - sg))          (modules.py:124)
- * fwn_colsum_prod  : out[c] <- scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C], fixed order
+ * fwn_colsum_prod  : out[c] <- scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C], fixed order;
+ *                    partial: scratch of fwn_colsum_partials(M, C) floats
  * fwn_actnorm_bwd  : dy <- dy * scale; y <- y / scale - shift (the plane before ActNorm)
  * fwn_wn_backward  : weight-norm backward per output column: dW, V fp32 [K][N], g [N] -> dV, dg   (convolutional.py:73-80) */
 int fwn_actnorm_apply(float* x, const float* an, int64_t n, int Ch, void* stream);
@@ -200,7 +201,9 @@ int fwn_coupling_fwd(float* yb, const float* Z, const float* ez, int64_t M, int 
 int fwn_coupling_bwd(float* g, float* out_b, const float* Z, const float* ez, int64_t M, int Ch, float cls, void* dZ,
                      int ldz, float* dzz, void* stream);
 int fwn_gate_bwd(const void* d_o, const void* aux, int64_t M, void* dpre, void* stream);
-int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C, float scale, float* out, void* stream);
+int fwn_colsum_partials(int64_t M, int C);
+int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C, float scale, float* partial, float* out,
+                    void* stream);
 int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, void* stream);
 int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg,
                     void* stream);

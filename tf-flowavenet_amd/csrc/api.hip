@@ -281,9 +281,11 @@ int fwn_gate_bwd(const void* d_o, const void* aux, int64_t M, void* dpre, void* 
     fwn_ew_gate_bwd(d_o, aux, (long)M * 256, dpre, (hipStream_t)stream);
     return check_launch("fwn_gate_bwd");
 }
-int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C_, float scale, float* out, void* stream) {
-    REQUIRE(A && out && M > 0 && C_ > 0, "fwn_colsum_prod: bad argument");
-    fwn_ew_colsum_prod(A, B, (long)M, C_, scale, out, (hipStream_t)stream);
+int fwn_colsum_partials(int64_t M, int C_) { return fwn_colsum_blocks((long)M, C_) * C_; }
+int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C_, float scale, float* partial, float* out,
+                    void* stream) {
+    REQUIRE(A && out && partial && M > 0 && C_ > 0, "fwn_colsum_prod: bad argument");
+    fwn_ew_colsum_prod(A, B, (long)M, C_, scale, partial, out, (hipStream_t)stream);
     return check_launch("fwn_colsum_prod");
 }
 int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, void* stream) {

@@ -7,23 +7,26 @@
 #include "fwn_internal.h"
 
 // ---- weight-norm scale: scale[n] = g[n] / sqrt(max(sum_k V[k][n]^2, 1e-12)) ----------------
-__global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__ v, const float* __restrict__ g,
-                                                       int k_src, int n_src, float* __restrict__ scale) {
-    __shared__ double red[4][64];
-    const int nl = threadIdx.x & 63, kg = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + nl;
+__global__ __launch_bounds__(1024) void wn_scale_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                        int k_src, int n_src, float* __restrict__ scale) {
+    // 32 output channels x 32 K-partitions per workgroup (K is up to 10240 for the conditioning convs
+    // and a training step recomputes every scale): coalesced over n, fixed-order tree over the partitions.
+    __shared__ double red[32][33];
+    const int nl = threadIdx.x & 31, kg = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + nl;
     double s = 0.0;
     if (n < n_src)
-        for (int k = kg; k < k_src; k += 4) {
+        for (int k = kg; k < k_src; k += 32) {
             const double x = v[(size_t)k * n_src + n];
             s += x * x;
         }
     red[kg][nl] = s;
     __syncthreads();
-    if (kg == 0 && n < n_src) {
-        const double ss = (red[0][nl] + red[1][nl]) + (red[2][nl] + red[3][nl]);
-        scale[n] = (float)((double)g[n] / sqrt(fmax(ss, 1e-12)));
+    for (int st = 16; st > 0; st >>= 1) {
+        if (kg < st) red[kg][nl] += red[kg + st][nl];
+        __syncthreads();
     }
+    if (kg == 0 && n < n_src) scale[n] = (float)((double)g[n] / sqrt(fmax(red[0][nl], 1e-12)));
 }
 
 // ---- gather + scale + cast: out[n'][k'] = bf16(V[src_k[k']][src_n[n']] * scale[src_n[n']]) --
@@ -242,7 +245,7 @@ static inline int grid_for(long total) {
     return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st) {
-    hipLaunchKernelGGL(wn_scale_kernel, dim3((n_src + 63) / 64), dim3(256), 0, st, v, g, k_src, n_src, scale);
+    hipLaunchKernelGGL(wn_scale_kernel, dim3((n_src + 31) / 32), dim3(1024), 0, st, v, g, k_src, n_src, scale);
 }
 void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,
                      int k_dst, int n_dst, long ld_dst, void* out, hipStream_t st) {

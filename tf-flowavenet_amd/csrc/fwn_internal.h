@@ -49,7 +49,9 @@ void fwn_ew_coupling_fwd(float* yb, const float* Z, const float* ez, long n, int
 void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
                          int ldz, float* dzz, hipStream_t st);
 void fwn_ew_gate_bwd(const void* do_, const void* aux, long n, void* dpre, hipStream_t st);
-void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* out, hipStream_t st);
+int fwn_colsum_blocks(long M, int C);
+void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* partial, float* out,
+                        hipStream_t st);
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st);
 void fwn_ew_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg, hipStream_t st);
 void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,

@@ -219,18 +219,30 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16* __restrict__ 
         dpre[m * 512 + 256 + c] = (bf16)(d * tf * sg * (1.0f - sg));
     }
 }
-// out[c] = scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C]; one workgroup per 64 channels,
-// fixed summation order (fp64 accumulation).
+// out[c] = scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C].  Two passes, both in a fixed order:
+// blockIdx.y owns a contiguous range of rows and writes partial[blockIdx.y][c]; colsum_final sums them.
 __global__ __launch_bounds__(256) void colsum_prod_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                          long M, int C, float scale, float* __restrict__ out) {
+                                                          long M, int C, float* __restrict__ partial) {
     __shared__ double red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const long per = (M + gridDim.y - 1) / gridDim.y;
+    const long m0 = (long)blockIdx.y * per, m1 = min(M, m0 + per);
     double acc = 0.0;
     if (c < C)
-        for (long m = part; m < M; m += 4) acc += (double)A[m * C + c] * (B ? (double)B[m * C + c] : 1.0);
+        for (long m = m0 + part; m < m1; m += 4) acc += (double)A[m * C + c] * (B ? (double)B[m * C + c] : 1.0);
     red[part][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (part == 0 && c < C) out[c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale);
+    if (part == 0 && c < C)
+        partial[(size_t)blockIdx.y * C + c] =
+            (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int C, float scale,
+                                                           float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += (double)partial[(size_t)b * C + c];
+    out[c] = (float)(a * scale);
 }
 // ActNorm backward on one plane (model.py:86-94): in dy (becomes dx = dy * scale in place), y (becomes
 // x = y / scale - shift in place).
@@ -286,8 +298,17 @@ void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, l
 void fwn_ew_gate_bwd(const void* do_, const void* aux, long n, void* dpre, hipStream_t st) {
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, (const bf16*)do_, (const bf16*)aux, n, (bf16*)dpre);
 }
-void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_prod_kernel, dim3((C + 63) / 64), dim3(256), 0, st, A, B, M, C, scale, out);
+int fwn_colsum_blocks(long M, int C) {
+    long nb = M / 256;                                    // >= 256 rows per block
+    const long cap = 1024 / ((C + 63) / 64);
+    if (nb > cap) nb = cap;
+    return (int)(nb < 1 ? 1 : nb);
+}
+void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* partial, float* out,
+                        hipStream_t st) {
+    const int nb = fwn_colsum_blocks(M, C);
+    hipLaunchKernelGGL(colsum_prod_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, st, A, B, M, C, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nb, C, scale, out);
 }
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st) {
     hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, an, n, Ch);

@@ -356,7 +356,8 @@ class GradEngine:
             self._call("fwn_coupling_bwd", gb.data_ptr(), xb.data_ptr(), z.data_ptr(), t["ez"].data_ptr(), m, ch,
                        1.0 / (2.0 * m * ch), dz.data_ptr(), ldz, dzz.data_ptr(), st)
             dscale = f32(2 * ch)
-            self._call("fwn_colsum_prod", dzz.data_ptr(), None, m, 2 * ch, 3.0, dscale.data_ptr(), st)
+            scratch = f32(max(lib.fwn_colsum_partials(m, 2 * ch), lib.fwn_colsum_partials(m, ch)))
+            self._call("fwn_colsum_prod", dzz.data_ptr(), None, m, 2 * ch, 3.0, scratch.data_ptr(), dscale.data_ptr(), st)
             zc = t["zcol"]
             g_scale = f32(2 * ch); g_scale[zc] = dscale
             grads[wp + "/ZeroConv1d/scale"] = g_scale.view(1, 1, -1)
@@ -409,8 +410,8 @@ class GradEngine:
             g_b, g_logs = f32(2 * ch), f32(2 * ch)
             for role, (yy, gg) in enumerate(((xa, ga), (xb, gb))):
                 s1, s2 = f32(ch), f32(ch)
-                self._call("fwn_colsum_prod", gg.data_ptr(), None, m, ch, 1.0, s1.data_ptr(), st)
-                self._call("fwn_colsum_prod", gg.data_ptr(), yy.data_ptr(), m, ch, 3.0, s2.data_ptr(), st)
+                self._call("fwn_colsum_prod", gg.data_ptr(), None, m, ch, 1.0, scratch.data_ptr(), s1.data_ptr(), st)
+                self._call("fwn_colsum_prod", gg.data_ptr(), yy.data_ptr(), m, ch, 3.0, scratch.data_ptr(), s2.data_ptr(), st)
                 g_b[role * ch + br] = s1 * an[role, 1]
                 g_logs[role * ch + br] = s2 - 3.0 / (2 * ch)
                 self._call("fwn_actnorm_bwd", gg.data_ptr(), yy.data_ptr(), an[role].data_ptr(), m * ch, ch, st)
