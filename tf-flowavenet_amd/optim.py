@@ -11,8 +11,7 @@ Replaces, for one process per GPU:
     (``packing.pack_model`` reading device views; bf16 needs no loss scale, ``scale`` is kept only
     to consume gradients of a scaled loss).
 
-The backward kernels that would fill ``grad`` are not part of this round (DESIGN.md section 8);
-tests drive the step with known gradients.
+``training.GradEngine`` fills ``grad``; ``training.Trainer`` ties the two together.
 """
 from __future__ import annotations
 
