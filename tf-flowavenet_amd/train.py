@@ -1,0 +1,225 @@
+"""``train`` CLI - the reference's training loop (train.py:153-283) on MI355X.
+
+    python -m tf_flowavenet_amd.train --base_dir data/ --input training_data/train.txt
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        -m tf_flowavenet_amd.train --base_dir data/            # one process per GPU, RCCL gradient all-reduce
+
+Same flags as the reference (``--base_dir --input --restore --summary_interval --checkpoint_interval
+--eval_interval --train_steps``) plus ``--log_dir`` / ``--seed``.  Input is the output of
+``preprocessing.preprocess``: ``train.txt`` with ``audios/*.npy`` and ``mels/*.npy`` beside it.
+
+Differences (deliberate): the TFRecord round trip (tfrecord.py, dataset.py:20-44) is skipped - the
+``.npy`` files are read directly and cropped like ``Dataset._load_sample`` (dataset.py:70-76); the
+train / test split is the reference's ``train_test_split(test_size, random_state)`` (tfrecord.py:81-82);
+summaries are JSON lines (``<log_dir>/train/summary.jsonl``, ``test/summary.jsonl``) and evaluation
+audio is written as wav files instead of TensorBoard events; checkpoints are ``.npz`` files that
+``synthesize.py`` loads (parameters in the reference's layouts, plus the Adam slots and global step).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import os
+import time
+
+import numpy as np
+
+
+class Dataset:
+    """Random fixed-length crops of (mel, audio) pairs (dataset.py:47-85)."""
+
+    def __init__(self, metadata_path, hparams, seed=None, rank=0):
+        self._hp = hparams
+        self._basedir = os.path.dirname(metadata_path)
+        with open(metadata_path, "rt", encoding="utf-8") as f:
+            meta = [m.split("|") for m in f.read().strip().split("\n") if m]
+        self._frames = hparams.max_time_steps // hparams.hop_size            # dataset.py:13-14
+        self._steps = self._frames * hparams.hop_size
+        # dataset.py:73 draws the crop start from [0, frames - max_time_frames): needs strictly longer clips
+        meta = [m for m in meta if int(m[2]) // hparams.hop_size > self._frames]
+        if not meta:
+            raise ValueError("no utterance longer than max_time_steps=%d in %s" % (hparams.max_time_steps, metadata_path))
+        idx = np.arange(len(meta))
+        if len(meta) > hparams.test_size:                                    # tfrecord.py:81-82
+            from sklearn.model_selection import train_test_split
+            tr, te = train_test_split(idx, test_size=hparams.test_size, random_state=hparams.split_random_state)
+        else:
+            tr, te = idx, idx
+        self.train_meta, self.test_meta = [meta[i] for i in tr], [meta[i] for i in te]
+        base = hparams.shuffle_random_seed if seed is None else seed
+        self._rng = np.random.RandomState(base + 7919 * rank)
+        self._cache = {}
+
+    def _load(self, m):
+        if m[0] not in self._cache:
+            self._cache[m[0]] = (np.load(os.path.join(self._basedir, "audios", m[0])),
+                                 np.load(os.path.join(self._basedir, "mels", m[1])))
+        return self._cache[m[0]]
+
+    def _batch(self, metas):
+        hp = self._hp
+        mels = np.empty((len(metas), self._frames, hp.num_mels), dtype=np.float32)
+        audios = np.empty((len(metas), self._steps), dtype=np.float32)
+        for k, m in enumerate(metas):
+            audio, mel = self._load(m)
+            start = self._rng.randint(0, mel.shape[0] - self._frames)        # dataset.py:73-76
+            mels[k] = mel[start:start + self._frames]
+            audios[k] = audio[start * hp.hop_size:start * hp.hop_size + self._steps]
+        return mels, audios
+
+    def next_train(self):
+        pick = self._rng.randint(0, len(self.train_meta), size=self._hp.batch_size)
+        return self._batch([self.train_meta[i] for i in pick])
+
+    def next_test(self):
+        pick = self._rng.randint(0, len(self.test_meta), size=self._hp.batch_size)
+        return self._batch([self.test_meta[i] for i in pick])
+
+    def eval_sample(self):
+        """One utterance, capped at eval_max_time_steps (train.py:118-131)."""
+        hp = self._hp
+        m = self.test_meta[self._rng.randint(0, len(self.test_meta))]
+        audio, mel = self._load(m)
+        frames = min(int(hp.eval_max_time_steps // hp.hop_size), mel.shape[0])
+        while frames > 1 and (frames * hp.hop_size) % (1 << hp.n_block):      # model.py:226: T % 2^n_block == 0
+            frames -= 1
+        return mel[:frames], audio[:frames * hp.hop_size]
+
+
+def save_checkpoint(path, trainer):
+    views = trainer.opt.master_views()
+    out = {k: v.detach().cpu().numpy() for k, v in views.items()}
+    out["__opt/m"] = trainer.opt.m.cpu().numpy()
+    out["__opt/v"] = trainer.opt.v.cpu().numpy()
+    out["__opt/global_step"] = np.asarray(trainer.opt.global_step, dtype=np.int64)
+    tmp = path + ".tmp.npz"
+    np.savez(tmp, **out)
+    os.replace(tmp, path)
+
+
+def restore_checkpoint(save_dir, trainer):
+    """Newest ``flowavenet_model.ckpt-*.npz`` -> masters, Adam slots, global step.  Returns the step or None."""
+    import torch
+    files = sorted(glob.glob(os.path.join(save_dir, "flowavenet_model.ckpt-*.npz")), key=os.path.getmtime)
+    if not files:
+        return None
+    print("Loading checkpoint {}".format(files[-1]))
+    with np.load(files[-1]) as f:
+        views = trainer.opt.master_views()
+        for k, v in views.items():
+            v.copy_(torch.from_numpy(f[k]).reshape(v.shape))
+        trainer.opt.m.copy_(torch.from_numpy(f["__opt/m"]))
+        trainer.opt.v.copy_(torch.from_numpy(f["__opt/v"]))
+        trainer.opt.global_step = int(f["__opt/global_step"])
+    return trainer.opt.global_step
+
+
+def train(log_dir, args, hparams, input_path, device="cuda", params=None):
+    import torch
+    import torch.distributed as dist
+    from . import weights
+    from .model import FloWaveNet
+    from .optim import learning_rate
+    from .synthesize import write_wav
+    from .training import Trainer
+
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    save_dir = os.path.join(log_dir, "pretrained")
+    train_logdir, test_logdir = os.path.join(log_dir, "train"), os.path.join(log_dir, "test")
+    for d in (save_dir, train_logdir, test_logdir):
+        os.makedirs(d, exist_ok=True)
+    checkpoint_path = os.path.join(save_dir, "flowavenet_model.ckpt")
+    metadata_filename = os.path.join(args.base_dir, input_path)
+    if rank == 0:
+        print("Checkpoint_path: {}".format(checkpoint_path))
+        print("Loading training data from: {}".format(metadata_filename))
+    seed = getattr(args, "seed", None)
+    dataset = Dataset(metadata_filename, hparams, seed=seed, rank=rank)
+    if params is None:     # the reference's initialisers: he-uniform convs, g = 1, ZeroConv1d all zeros (modules.py:21-22,47-49)
+        params = weights.synthetic_params(hparams, hparams.tf_random_seed if seed is None else seed, zero_conv="zeros")
+    trainer = Trainer(hparams, params, device=device)
+    step = None
+    if args.restore:
+        step = restore_checkpoint(save_dir, trainer)
+    if step is None:
+        if rank == 0:
+            print("Starting new training!" if not args.restore else "No checkpoint found.")
+            print("Init ActNorm layer...", end="")
+        mels, audios = dataset.next_train()
+        trainer.ddi(audios, mels)                                             # train.py:221,229 (init=True)
+        init_loss = float(trainer.step(audios, mels)[0])                     # ... which also applies an update
+        step = trainer.opt.global_step
+        if rank == 0:
+            print(" OK. Init loss: {:.5f}".format(init_loss))
+    if rank == 0:
+        print("FloWaveNet training set to a maximum of {} steps".format(args.train_steps))
+
+    def log(path, rec):
+        with open(os.path.join(path, "summary.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+    while step < args.train_steps:
+        start_time = time.time()
+        mels, audios = dataset.next_train()
+        loss, log_p, logdet, gnorm = trainer.step(audios, mels)
+        step = trainer.opt.global_step
+        total_loss = float(loss)                                             # synchronises: the step time is real
+        step_duration = time.time() - start_time
+        if rank == 0:
+            print("Step {:7d} [{:.3f} sec/step, loss={:.5f}, log_p={:.5f}, logdet={:.5f}]".format(
+                step, step_duration, total_loss, float(log_p), float(logdet)), end="\r")
+        if rank == 0 and step % args.summary_interval == 0:
+            print("\nWriting summary at step {}".format(step))
+            log(train_logdir, {"step": step, "losses/total_loss": total_loss, "losses/log_p": float(log_p),
+                               "losses/logdet": float(logdet), "learning_rate": learning_rate(step - 1),
+                               "gradient_global_norm": float(gnorm)})
+            tm, ta = dataset.next_test()                                     # get_test_losses, train.py:85-91
+            model = FloWaveNet(hparams, device=device, cond_mode=1).load_params(trainer.opt.master_views())
+            tlp, tld = model.forward(torch.from_numpy(ta).reshape(ta.shape[0], -1, 1), torch.from_numpy(tm))
+            log(test_logdir, {"step": step, "losses/total_loss": -(float(tlp) + float(tld)),
+                              "losses/log_p": float(tlp), "losses/logdet": float(tld)})
+        if rank == 0 and (step % args.checkpoint_interval == 0 or step == args.train_steps):
+            save_checkpoint("%s-%d.npz" % (checkpoint_path, step), trainer)
+        if rank == 0 and step % args.eval_interval == 0:
+            print("\nEvaluating at step {}".format(step))                     # predict_random_samples, train.py:114-139
+            mel, wav = dataset.eval_sample()
+            model = FloWaveNet(hparams, device=device, cond_mode=1).load_params(trainer.opt.master_views())
+            g = torch.Generator().manual_seed(step)
+            z = torch.randn(1, len(wav), 1, generator=g) * hparams.temp
+            pred = model.reverse(z, torch.from_numpy(mel[None])).reshape(-1).cpu().numpy()
+            write_wav(os.path.join(train_logdir, "predictions-%d.wav" % step), pred, hparams.sample_rate)
+            write_wav(os.path.join(train_logdir, "targets-%d.wav" % step), wav, hparams.sample_rate)
+    return save_dir
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--base_dir", default="")
+    parser.add_argument("--input", default="training_data/train.txt")
+    parser.add_argument("--input_dir", default="training_data/", help="folder to contain inputs sentences/targets")
+    parser.add_argument("--restore", type=lambda s: str(s).lower() not in ("false", "0", "no"), default=True,
+                        help="Set this to False to do a fresh training")
+    parser.add_argument("--summary_interval", type=int, default=500, help="Steps between running summary ops")
+    parser.add_argument("--checkpoint_interval", type=int, default=2000, help="Steps between writing checkpoints")
+    parser.add_argument("--eval_interval", type=int, default=5000, help="Steps between eval on test data")
+    parser.add_argument("--train_steps", type=int, default=2000000, help="total number of model training steps")
+    parser.add_argument("--log_dir", default="logs")
+    parser.add_argument("--seed", type=int, default=None)
+    args = parser.parse_args(argv)
+    import torch
+    import torch.distributed as dist
+    from .hparams import hparams
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        dist.init_process_group("nccl")
+    try:
+        train(os.path.join(args.base_dir, args.log_dir), args, hparams, args.input)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
