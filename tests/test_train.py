@@ -188,3 +188,62 @@ def test_train_cli_loop_checkpoint_resume_and_synthesis(tmp_path):
     mel = np.load(data / "mels" / "dataset-mel-00001.npy")[:16]
     x = m.reverse(torch.randn(1, 16 * hp.hop_size, 1) * 0.7, torch.from_numpy(mel[None]))
     assert bool(torch.isfinite(x).all())
+
+
+# ------------------------------------------------------------------ data-parallel step, 2 ranks on one GPU
+def _dp_worker(rank, world, port, out_dir):
+    import os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import Trainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves CUDA tensors through the host
+    torch.cuda.set_device(0)
+    hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
+    inp = W.synthetic_inputs(hp, 4, 256)
+    x = torch.from_numpy(inp["x"]).reshape(4, 256)[2 * rank:2 * rank + 2].cuda()
+    c = torch.from_numpy(inp["c"])[2 * rank:2 * rank + 2].cuda()
+    tr = Trainer(hp, W.synthetic_params(hp, 11))
+    tr.ddi(x, c)
+    w0 = tr.opt.w.clone()
+    tr.step(x, c)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), w0=w0.cpu().numpy(), g=tr.opt.g.cpu().numpy(),
+             w1=tr.opt.w.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_matches_one_process_on_the_whole_batch(tmp_path):
+    """Two processes (gloo, both on cuda:0), two clips each: after DDI both hold rank 0's ActNorm
+    init, the all-reduced gradient equals world x the gradient of the 4-clip batch in one process,
+    and both ranks end the step with bit-identical weights (utils.py:34-60, train.py:75-81)."""
+    import os, socket, sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import Trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    r0, r1 = (np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2))
+    assert np.array_equal(r0["w0"], r1["w0"]) and np.array_equal(r0["g"], r1["g"]) and np.array_equal(r0["w1"], r1["w1"])
+    # one process, the whole batch, same initial weights
+    hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
+    inp = W.synthetic_inputs(hp, 4, 256)
+    tr = Trainer(hp, W.synthetic_params(hp, 11))
+    tr.opt.w.copy_(torch.from_numpy(r0["w0"]))
+    _, _, _, grads = tr.engine.loss_and_grads(tr.opt.master_views(), torch.from_numpy(inp["x"]).reshape(4, 256), torch.from_numpy(inp["c"]))
+    gv = tr.opt.grad_views()
+    for k, g in grads.items():
+        gv[k].copy_(g.reshape(gv[k].shape))
+    want, got = 2.0 * tr.opt.g.cpu().numpy().astype(np.float64), r0["g"].astype(np.float64)
+    cos = float((want * got).sum() / np.sqrt((want * want).sum() * (got * got).sum()))
+    assert cos > 0.999 and abs(np.linalg.norm(got) / np.linalg.norm(want) - 1.0) < 2e-2, (cos, np.linalg.norm(got), np.linalg.norm(want))
