@@ -209,10 +209,12 @@ int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int 
                     void* stream);
 
 /* Backward of one up-sampling stage (fwn_upsample_stage with fp32 output): y, dy [B][H*s][W], x [B][H][W].
- * dy <- dy * LeakyReLU'(y) in place; dx (may be NULL) <- gradient wrt x; dwk [2s][3] and dbias[1] <-
- * gradients of the (weight-normed) kernel and bias, fixed summation order.          (model.py:301-311) */
+ * dy <- dy * LeakyReLU'(y) in place; dx (may be NULL) <- gradient wrt x; dwk_bias [6s + 1] <- gradients of
+ * the (weight-normed) kernel [2s][3] followed by the bias, two fixed-order passes through `partial`
+ * (fwn_upsample_bwd_partials(B, H, s) floats).                                      (model.py:301-311) */
+int fwn_upsample_bwd_partials(int B, int H, int s);
 int fwn_upsample_bwd(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
-                     float* dx, float* dwk, float* dbias, void* stream);
+                     float* dx, float* dwk_bias, float* partial, void* stream);
 
 /* ---- whole model (replaces FloWaveNet.forward / .reverse, model.py:317-396) ---- */
 typedef struct fwn_model_desc {

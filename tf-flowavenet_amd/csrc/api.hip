@@ -300,11 +300,12 @@ int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int 
     return check_launch("fwn_wn_backward");
 }
 
+int fwn_upsample_bwd_partials(int B, int H, int s) { return fwn_up_bwd_chunks(B, H) * (6 * s + 1); }
 int fwn_upsample_bwd(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
-                     float* dx, float* dwk, float* dbias, void* stream) {
-    REQUIRE(dy && y && x && wk && dwk && dbias, "fwn_upsample_bwd: null pointer");
+                     float* dx, float* dwk_bias, float* partial, void* stream) {
+    REQUIRE(dy && y && x && wk && dwk_bias && partial, "fwn_upsample_bwd: null pointer");
     REQUIRE(B > 0 && H > 0 && W > 0 && s > 0 && (s % 2) == 0, "fwn_upsample_bwd: bad shape (s must be even)");
-    fwn_up_bwd_launch(dy, y, x, B, H, W, s, wk, dx, dwk, dbias, (hipStream_t)stream);
+    fwn_up_bwd_launch(dy, y, x, B, H, W, s, wk, dx, dwk_bias, partial, (hipStream_t)stream);
     return check_launch("fwn_upsample_bwd");
 }
 

@@ -54,5 +54,6 @@ void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float sca
                         hipStream_t st);
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st);
 void fwn_ew_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg, hipStream_t st);
+int fwn_up_bwd_chunks(int B, int H);
 void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
-                       float* dx, float* dwk, float* dbias, hipStream_t st);
+                       float* dx, float* dwk_bias, float* partial, hipStream_t st);

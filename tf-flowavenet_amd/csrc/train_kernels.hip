@@ -344,25 +344,31 @@ __global__ __launch_bounds__(256) void up_dx_kernel(const float* __restrict__ dp
         dx[idx] = acc;
     }
 }
-// one workgroup per kernel tap (k, kw), plus one for the bias: fixed-order sums over (b, i, w).
+// blockIdx.x = kernel tap (k, kw), the last one the bias; blockIdx.y = a contiguous chunk of the
+// (b, i) rows.  partial[chunk][tap] in a fixed order, summed by colsum_final_kernel.
 __global__ __launch_bounds__(256) void up_dw_kernel(const float* __restrict__ dpre, const float* __restrict__ x, int B,
-                                                    int H, int W, int s, float* __restrict__ dwk,
-                                                    float* __restrict__ dbias) {
+                                                    int H, int W, int s, float* __restrict__ partial) {
     __shared__ double red[256];
     const int tap = blockIdx.x, ntap = 6 * s;
+    const long rows = (long)B * H, per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
     double acc = 0.0;
     if (tap < ntap) {
         const int k = tap / 3, kw = tap % 3;
-        const long total = (long)B * H * W;
-        for (long idx = threadIdx.x; idx < total; idx += 256) {
-            const int w = (int)(idx % W), i = (int)((idx / W) % H), b = (int)(idx / ((long)W * H));
-            const int tau = i * s + k - s / 2, ww = w + kw - 1;
-            if (tau >= 0 && tau < H * s && ww >= 0 && ww < W)
-                acc += (double)x[idx] * (double)dpre[((long)b * H * s + tau) * W + ww];
+        for (long r = r0; r < r1; ++r) {
+            const int i = (int)(r % H), b = (int)(r / H);
+            const int tau = i * s + k - s / 2;
+            if (tau < 0 || tau >= H * s) continue;
+            const float* drow = dpre + ((long)b * H * s + tau) * W;
+            const float* xrow = x + r * W;
+            for (int w = threadIdx.x; w < W; w += 256) {
+                const int ww = w + kw - 1;
+                if (ww >= 0 && ww < W) acc += (double)xrow[w] * (double)drow[ww];
+            }
         }
     } else {
-        const long total = (long)B * H * s * W;
-        for (long idx = threadIdx.x; idx < total; idx += 256) acc += (double)dpre[idx];
+        const long e0 = r0 * s * W, e1 = r1 * s * W;
+        for (long idx = e0 + threadIdx.x; idx < e1; idx += 256) acc += (double)dpre[idx];
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -370,15 +376,15 @@ __global__ __launch_bounds__(256) void up_dw_kernel(const float* __restrict__ dp
         if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        if (tap < ntap) dwk[tap] = (float)red[0];
-        else *dbias = (float)red[0];
-    }
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * (ntap + 1) + tap] = (float)red[0];
 }
+int fwn_up_bwd_chunks(int B, int H) { const long r = (long)B * H; return (int)(r < 64 ? 1 : (r / 16 > 64 ? 64 : r / 16)); }
 void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
-                       float* dx, float* dwk, float* dbias, hipStream_t st) {
+                       float* dx, float* dwk_bias, float* partial, hipStream_t st) {
     const long n = (long)B * H * s * W;
+    const int nc = fwn_up_bwd_chunks(B, H);
     hipLaunchKernelGGL(up_dpre_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, n);
     if (dx) hipLaunchKernelGGL(up_dx_kernel, dim3(ew_grid((long)B * H * W)), dim3(256), 0, st, dy, B, H, W, s, wk, dx);
-    hipLaunchKernelGGL(up_dw_kernel, dim3(6 * s + 1), dim3(256), 0, st, dy, x, B, H, W, s, dwk, dbias);
+    hipLaunchKernelGGL(up_dw_kernel, dim3(6 * s + 1, nc), dim3(256), 0, st, dy, x, B, H, W, s, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((6 * s + 1 + 255) / 256), dim3(256), 0, st, partial, nc, 6 * s + 1, 1.0f, dwk_bias);
 }

@@ -159,7 +159,7 @@ class _TrainPack:
         import torch
         v = self._f32(name + "/kernel")
         k_src, n_src = v.shape[0] * v.shape[1], v.shape[2]
-        st = torch.cuda.current_stream(self.dev).cuda_stream
+        st = _stream(v)
         sc = None
         if weight_norm:
             g = self._f32(name + "/g")
@@ -167,7 +167,6 @@ class _TrainPack:
             sc = self._scale.data_ptr()
         _lib.check(self.lib.fwn_pack_bf16(v.data_ptr(), sc, src_k.data_ptr(), src_n.data_ptr(), n_src, k_dst, n_dst,
                                           int(out.stride(0)), out.data_ptr(), st), "fwn_pack_bf16")
-        v.record_stream(torch.cuda.current_stream(self.dev))
 
     def _pack_flow(self, i, j):
         import torch
@@ -245,16 +244,21 @@ class GradEngine:
             raise NotImplementedError("affine=True, causality=False only")
         self.hp, self.device = hparams, device
         self.lib = _lib.load()
+        self._gout = None
 
     # ------------------------------------------------------------------ helpers
     def _call(self, name, *args):
         _lib.check(getattr(self.lib, name)(*args), name)
 
-    def loss_and_grads(self, params, x, c):
+    def loss_and_grads(self, params, x, c, grad_out=None):
+        """grad_out: optional dict name -> fp32 tensor (e.g. views of a flat gradient buffer); the large
+        gradients (conv kernels) are then written in place and returned as those very tensors."""
+        self._gout = grad_out
         try:
             return self._loss_and_grads(params, x, c)
         finally:
             _STREAMS.clear()
+            self._gout = None
 
     def _loss_and_grads(self, params, x, c):
         import torch
@@ -425,9 +429,11 @@ class GradEngine:
             xin, s_ = ups[n], int(hp.upsample_scales[n])
             hh = int(xin.shape[1])
             dx = f32(B, hh, nmel) if n > 0 else None
-            dwk, dbias = f32(2 * s_, 3), f32(1)
+            dwb = f32(6 * s_ + 1)
+            dwk, dbias = dwb[:6 * s_].view(2 * s_, 3), dwb[6 * s_:]
+            scr = f32(lib.fwn_upsample_bwd_partials(B, hh, s_))
             self._call("fwn_upsample_bwd", dy.data_ptr(), y.data_ptr(), xin.data_ptr(), B, hh, nmel, s_, md.up_w[n],
-                       dx.data_ptr() if dx is not None else None, dwk.data_ptr(), dbias.data_ptr(), st)
+                       dx.data_ptr() if dx is not None else None, dwb.data_ptr(), scr.data_ptr(), st)
             v = torch.as_tensor(params["upsample_%d/kernel" % n]).to(device=dev, dtype=torch.float32).reshape(2 * s_, 3).contiguous()
             g3 = torch.as_tensor(params["upsample_%d/g" % n]).to(device=dev, dtype=torch.float32).reshape(1).expand(3).contiguous()
             dv, dg3 = f32(2 * s_, 3), f32(3)
@@ -445,7 +451,10 @@ class GradEngine:
         dev = dw.device
         v, g = self._tp._f32(name + "/kernel"), self._tp._f32(name + "/g")
         k, n = dw.shape
-        dv, dg = torch.empty(k, n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+        if self._gout is not None and self._gout[name + "/kernel"].is_contiguous():
+            dv, dg = self._gout[name + "/kernel"].view(k, n), self._gout[name + "/g"]
+        else:
+            dv, dg = torch.empty(k, n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
         dw = dw.contiguous()
         self._call("fwn_wn_backward", dw.data_ptr(), v.data_ptr(), g.data_ptr(), k, n, dv.data_ptr(), dg.data_ptr(),
                    torch.cuda.current_stream(dev).cuda_stream)
@@ -486,9 +495,10 @@ class Trainer:
     def step(self, x, c):
         """-> (loss, log_p, logdet, grad_norm) device scalars; the masters are updated in place."""
         params = self.opt.master_views()
-        loss, log_p, logdet, grads = self.engine.loss_and_grads(params, x, c)
         gv = self.opt.grad_views()
+        loss, log_p, logdet, grads = self.engine.loss_and_grads(params, x, c, grad_out=gv)
         for k, g in grads.items():
-            gv[k].copy_(g.reshape(gv[k].shape))
+            if g.data_ptr() != gv[k].data_ptr():
+                gv[k].copy_(g.reshape(gv[k].shape))
         gnorm = self.opt.step()
         return loss, log_p, logdet, gnorm
