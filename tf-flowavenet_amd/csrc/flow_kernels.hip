@@ -894,6 +894,17 @@ void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_
     CondBatch cb{(const bf16*)ca, (const bf16*)Wc_base, P_base, w_stride, p_stride, flow0, flow_step, L,
                  M, cin, kcpad};
     const int nz = nflow * L;
+    // weights dominate the bytes and arrive from HBM: take the largest balanced tile that still
+    // gives about one workgroup per CU (block 4: 256 x 256, block 5: 256 x 128 at the bench batch)
+    const int t256 = (M + 255) / 256;
+    if (t256 * 2 * nz >= 192) {
+        hipLaunchKernelGGL((cond_batch_kernel<256, 256, 4, 4, 64, 2>), dim3(t256 * 2, nz), dim3(1024), 0, st, cb, 2);
+        return;
+    }
+    if (t256 * 4 * nz >= 192) {
+        hipLaunchKernelGGL((cond_batch_kernel<256, 128, 8, 2, 64, 3>), dim3(t256 * 4, nz), dim3(1024), 0, st, cb, 4);
+        return;
+    }
     if (((M + 127) / 128) * 4 * nz >= 192) {
         hipLaunchKernelGGL((cond_batch_kernel<128, 128, 2, 2, 64, 3>), dim3(((M + 127) / 128) * 4, nz), dim3(256), 0,
                            st, cb, 4);
