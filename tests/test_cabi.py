@@ -64,3 +64,32 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.FwnError, match="no CPU fallback"):
         _lib.load()
+
+
+def _build_c_consumer(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "cabi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "cabi_smoke.c"), "-o", exe, "-ldl", "-lm"])
+    return exe
+
+
+def test_plain_c_program_binds_the_abi(lib, tmp_path):
+    """include/fwn.h compiles as C99 and a torch-free C program gets version, error codes and messages."""
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    out = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert "C ABI ok: version 100" in out.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_program_runs_kernels_on_the_gpu(lib, tmp_path):
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    out = subprocess.run([exe, _lib.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GPU round trip ok" in out.stdout
