@@ -499,10 +499,16 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     const int nq1 = a.L * 4, NC = nq1 + 8;
     const int Ch = a.Ch;
 
-    // constants -> LDS (ordinary loads, all retired before the first DMA is issued)
-    for (int i = tid; i < 256; i += 64 * NW) { cst[i] = a.bs[i]; cst[256 + i] = a.bfin[i]; }
-    for (int i = tid; i < a.npt * 64; i += 64 * NW) { cst[512 + i] = a.bz[i]; cst[1024 + i] = a.ez[i]; }
-    for (int i = tid; i < 8 * Ch; i += 64 * NW) cst[1536 + i] = a.an[i];
+    // constants -> LDS, also by LDS-DMA (8 pieces of 1 KB spread over the waves, ahead of chunk 0 in
+    // the same queue: the first step() wait covers them).  Ordinary loads here would have to retire
+    // before the first DMA is issued - a cold-miss stall at the head of every tail launch.
+    for (int pc = wave; pc < 8; pc += NW) {
+        const float* src = pc == 0 ? a.bs : pc == 1 ? a.bfin : pc == 2 ? a.bz : pc == 3 ? a.ez : a.an;
+        const uint32_t bytes = pc < 2 ? 1024u : pc < 4 ? (uint32_t)a.npt * 256u : (uint32_t)Ch * 32u;
+        const int dst = pc == 0 ? 0 : pc == 1 ? 256 : pc == 2 ? 512 : pc == 3 ? 1024 : 1536 + (pc - 4) * 256;
+        buf_load16_lds(make_srd(src, bytes), (uint32_t)((pc >= 4 ? (pc - 4) * 1024 : 0) + lane * 16),
+                       (unsigned char*)(cst + dst));
+    }
 
     // ---- ring: chunk c (weights, and in phase 1 the o rows) goes to slot c % 3 ----
     int wrow[PWW], wc8[PWW], orow[PWO], oc8[PWO];
