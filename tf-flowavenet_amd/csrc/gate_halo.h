@@ -117,14 +117,6 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
     for (int ki = 0; ki < G::KS; ++ki) bfr[ki] = G::off(wn * 64 + lr, ki * 2 + lh);
 
     f32x16 acc[MI][2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const float c0 = p.acc_init(n0 + wn * 64 + ni * 32 + lr);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = c0;
-    }
 
     // one step: 4 k-steps of 4 MFMAs, fragments double-buffered, `issue(ki)` slipped under them
     auto mma_step = [&](const unsigned char* la, const unsigned char* lb, int rb0, int rb1, int x, auto&& issue) {
@@ -160,6 +152,15 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
     for (int j = 0; j < 3; ++j) issueA_conv(0, j);
 #pragma unroll
     for (int j = 0; j < PB; ++j) issueB(0, j);
+    // bias -> accumulators, after the prologue DMAs are queued (see gemm_ring.h)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const float c0 = p.acc_init(n0 + wn * 64 + ni * 32 + lr);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = c0;
+    }
 
     // Per step the wave issues [weight piece, weight piece, activation piece] in that order, so
     // "all but the newest one" (vmcnt(1)) leaves only the activation piece of a later slice in flight.

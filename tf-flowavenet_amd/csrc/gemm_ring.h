@@ -118,17 +118,6 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         for (int j = 0; j < PW; ++j) issue_piece(cc, q, j);
     };
 
-    // accumulators start from the problem's per-column constant (the bias, where the epilogue would
-    // otherwise add it per element); with split-K only the first wave group carries it
-    f32x16 acc[MI][2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const float c0 = wk == 0 ? p.acc_init(n0 + wn * 64 + ni * 32 + lr) : 0.0f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = c0;
-    }
 
     // fragment addresses: the swizzle sees only lr (32-row tiles preserve the low row bits)
     // (indexed by this wave's own k-step counter ki: k-step wk + ki*KSP of the chunk)
@@ -143,6 +132,20 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
 #pragma unroll
     for (int q = 0; q < D - 1; ++q)
         if (q < nq) issue(q);
+
+    // Accumulators start from the problem's per-column constant (the bias, where the epilogue would
+    // otherwise add it per element); with split-K only the first wave group carries it.  Loaded
+    // AFTER the prologue DMAs are in the queue: ahead of them, the wait for these (cold) loads would
+    // hold back the first DMA issue of every launch.
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const float c0 = wk == 0 ? p.acc_init(n0 + wn * 64 + ni * 32 + lr) : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = c0;
+    }
 
     for (int q = 0; q < nq; ++q) {
         // chunks issued so far: min(nq, q + D - 1); those after q may stay in flight
