@@ -424,3 +424,30 @@ def test_oversized_call_is_rejected_with_a_message(full_model):
     big_c = torch.zeros(40, 862, 80, device="cuda")
     with pytest.raises(_lib.FwnError, match="2 GiB"):
         model.forward(big_x, big_c)
+
+
+def test_random_small_configurations_match_oracle():
+    """Seeded sweep over (n_block, n_flow, n_layer, up-sampling factors, num_mels, B, T, conditioning
+    mode) - the shapes nobody would write down by hand (tools/fuzz_parity.py is the open-ended version)."""
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 14:
+        n_block, n_flow, n_layer = int(rng.integers(1, 6)), int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        s0, s1 = int(rng.choice([2, 4])), int(rng.choice([2, 4, 8]))
+        hop, num_mels = s0 * s1, int(rng.choice([8, 16, 24, 80]))
+        hp = default_hparams().replace(n_block=n_block, n_flow=n_flow, n_layer=n_layer, hop_size=hop,
+                                       upsample_scales=[s0, s1], num_mels=num_mels)
+        t, b = int(np.lcm(hop, 1 << n_block)) * int(rng.integers(1, 9)), int(rng.integers(1, 6))
+        p = W.synthetic_params(hp, int(rng.integers(1 << 30)), actnorm="random")
+        inp = W.synthetic_inputs(hp, b, t)
+        p64 = onp.to_f64(p)
+        lp0, ld0, z0 = onp.forward(p64, inp["x"].astype(np.float64), inp["c"].astype(np.float64), hp)
+        m = FloWaveNet(hp, cond_mode=int(rng.integers(0, 3))).load_params(p)
+        lp, ld, zp = m.forward(dev(inp["x"]), dev(inp["c"]), return_z=True)
+        check_scalars(lp, ld, lp0, ld0)
+        assert np.abs(z_planes_to_squeezed(zp, n_block, n_flow).cpu().numpy() - z0).max() < ABS_Z, (n_block, n_flow, n_layer, b, t)
+        if (n_block * n_flow) % 2 == 0:
+            x0 = onp.reverse(p64, inp["z"].astype(np.float64), inp["c"].astype(np.float64), hp)
+            xr = m.reverse(dev(inp["z"]), dev(inp["c"])).cpu().numpy()
+            assert np.abs(xr - x0).max() < ABS_WAV * max(1.0, np.abs(x0).max()), (n_block, n_flow, n_layer, b, t)
+        done += 1
