@@ -52,6 +52,18 @@ int fwn_wn_scale(const float* v, const float* g, int k_src, int n_src, float* sc
 int fwn_pack_bf16(const float* v, const float* scale, const int32_t* src_k, const int32_t* src_n,
                   int n_src, int k_dst, int n_dst, int64_t ld_dst, void* out_bf16, void* stream);
 
+/* Grouped form: a whole model's scales and packed copies in two launches.  Both job tables live in
+ * device memory; scale job s writes scales[s][0..n_src) (g / ||V||_col), pack job p multiplies by
+ * scales[p.scale_slot] (slot < 0: none) and by p.mul; transposed: out[k][n] (ld_dst >= n_dst)
+ * instead of out[n][k].  Index tables as in fwn_pack_bf16. */
+typedef struct fwn_scale_job { const float* v; const float* g; int32_t k_src, n_src; } fwn_scale_job;
+typedef struct fwn_pack_job {
+    const float* v; const int32_t* src_k; const int32_t* src_n; void* out; int64_t ld_dst;
+    int32_t n_src, k_dst, n_dst, scale_slot, transposed; float mul;
+} fwn_pack_job;
+int fwn_pack_jobs(const fwn_scale_job* scale_jobs, int n_scale_jobs, const fwn_pack_job* pack_jobs, int n_pack_jobs,
+                  float* scales, int scale_ld, void* stream);
+
 /* ---- K1: one upsampling stage (replaces Conv2DTranspose.call + leaky_relu, model.py:301-311,
  * 398-404).  in [B][H][W] fp32, wk = weight-normed kernel [2s][3] fp32 (device), out rows H*s.
  * Exactly one of out_f32 ([B][H*s][W]) / out_cplanes (bf16 [2][B][H*s][W/2]) may be NULL. */

@@ -46,6 +46,16 @@ class ModelDesc(C.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/fwn.h declares.
+class ScaleJob(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("k_src", C.c_int32), ("n_src", C.c_int32)]
+
+
+class PackJob(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("src_k", C.c_void_p), ("src_n", C.c_void_p), ("out", C.c_void_p), ("ld_dst", C.c_int64),
+                ("n_src", C.c_int32), ("k_dst", C.c_int32), ("n_dst", C.c_int32), ("scale_slot", C.c_int32),
+                ("transposed", C.c_int32), ("mul", C.c_float)]
+
+
 class GemmSeg(C.Structure):
     _fields_ = [("x", C.c_void_p), ("rows", C.c_int32), ("ld", C.c_int32), ("k", C.c_int32), ("shift", C.c_int32),
                 ("koff", C.c_int32), ("pad_", C.c_int32)]
@@ -87,6 +97,7 @@ SIGNATURES = {
     "fwn_flow_run": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,
                                C.c_int, vp]),
     "fwn_prior_logp": (C.c_int, [vp, i64, vp, C.c_int, vp, vp]),
+    "fwn_pack_jobs": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),
     "fwn_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "fwn_upsample_bwd_partials": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "fwn_upsample_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

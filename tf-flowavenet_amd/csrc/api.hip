@@ -46,6 +46,15 @@ int fwn_pack_bf16(const float* v, const float* scale, const int32_t* src_k, cons
     return check_launch("fwn_pack_bf16");
 }
 
+int fwn_pack_jobs(const fwn_scale_job* scale_jobs, int n_scale_jobs, const fwn_pack_job* pack_jobs, int n_pack_jobs,
+                  float* scales, int scale_ld, void* stream) {
+    REQUIRE(n_scale_jobs >= 0 && n_pack_jobs >= 0 && (n_scale_jobs == 0 || (scale_jobs && scales)) &&
+                (n_pack_jobs == 0 || pack_jobs) && scale_ld > 0 && scale_ld % 32 == 0, "fwn_pack_jobs: bad argument");
+    REQUIRE(n_scale_jobs < 65536 * 32 && n_pack_jobs < 65536 * 32, "fwn_pack_jobs: too many jobs");
+    fwn_launch_pack_jobs(scale_jobs, n_scale_jobs, pack_jobs, n_pack_jobs, scales, scale_ld, (hipStream_t)stream);
+    return check_launch("fwn_pack_jobs");
+}
+
 int fwn_upsample_stage(const float* in, int B, int H, int W, const float* wk, float bias, int s,
                        float* out_f32, void* out_cplanes, void* stream) {
     REQUIRE(in && wk, "fwn_upsample_stage: null pointer");

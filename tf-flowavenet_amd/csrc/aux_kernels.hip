@@ -5,6 +5,7 @@
 //   prior / log-det finalisation (model.py:342-343).
 #include "common.h"
 #include "fwn_internal.h"
+#include "../../include/fwn.h"
 
 // ---- weight-norm scale: scale[n] = g[n] / sqrt(max(sum_k V[k][n]^2, 1e-12)) ----------------
 __global__ __launch_bounds__(1024) void wn_scale_kernel(const float* __restrict__ v, const float* __restrict__ g,
@@ -47,6 +48,58 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ v, 
         }
         out[(size_t)nd * ld_dst + kd] = (bf16)val;
     }
+}
+
+// ---- grouped form of the two kernels above: a whole model's weight-norm scales and packed copies
+// in two launches driven by device-resident job tables (a training step re-packs every weight from
+// the fp32 masters; the tables are built once because master and output pointers are stable).
+__global__ __launch_bounds__(1024) void wn_scale_jobs_kernel(const fwn_scale_job* __restrict__ jobs,
+                                                             float* __restrict__ scales, int scale_ld) {
+    __shared__ double red[32][33];
+    const fwn_scale_job j = jobs[blockIdx.x];
+    const int nl = threadIdx.x & 31, kg = threadIdx.x >> 5;
+    const int n = blockIdx.y * 32 + nl;
+    if (blockIdx.y * 32 >= j.n_src) return;
+    double s = 0.0;
+    if (n < j.n_src)
+        for (int k = kg; k < j.k_src; k += 32) {
+            const double x = j.v[(size_t)k * j.n_src + n];
+            s += x * x;
+        }
+    red[kg][nl] = s;
+    __syncthreads();
+    for (int st = 16; st > 0; st >>= 1) {
+        if (kg < st) red[kg][nl] += red[kg + st][nl];
+        __syncthreads();
+    }
+    if (kg == 0 && n < j.n_src)
+        scales[(size_t)blockIdx.x * scale_ld + n] = (float)((double)j.g[n] / sqrt(fmax(red[0][nl], 1e-12)));
+}
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const fwn_pack_job* __restrict__ jobs,
+                                                        const float* __restrict__ scales, int scale_ld) {
+    const fwn_pack_job j = jobs[blockIdx.x];
+    const float* sc = j.scale_slot >= 0 ? scales + (size_t)j.scale_slot * scale_ld : nullptr;
+    const long total = (long)j.k_dst * j.n_dst;
+    bf16* out = (bf16*)j.out;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        // the fastest index follows the output's contiguous axis
+        const int kd = j.transposed ? (int)(i / j.n_dst) : (int)(i % j.k_dst);
+        const int nd = j.transposed ? (int)(i % j.n_dst) : (int)(i / j.k_dst);
+        const int sk = j.src_k[kd], sn = j.src_n[nd];
+        if (sn < 0) continue;
+        float val = 0.0f;
+        if (sk >= 0) {
+            val = j.v[(size_t)sk * j.n_src + sn] * j.mul;
+            if (sc) val *= sc[sn];
+        }
+        out[j.transposed ? (size_t)kd * j.ld_dst + nd : (size_t)nd * j.ld_dst + kd] = (bf16)val;
+    }
+}
+void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack_job* jobs, int njobs, float* scales,
+                          int scale_ld, hipStream_t st) {
+    if (nsjobs > 0)
+        hipLaunchKernelGGL(wn_scale_jobs_kernel, dim3(nsjobs, (scale_ld + 31) / 32), dim3(1024), 0, st, sjobs, scales, scale_ld);
+    if (njobs > 0) hipLaunchKernelGGL(pack_jobs_kernel, dim3(njobs, 16), dim3(256), 0, st, jobs, scales, scale_ld);
 }
 
 // ---- one Conv2DTranspose(filters=1, kernel (2s,3), strides (s,1), 'same') + LeakyReLU(0.4) --

@@ -57,3 +57,7 @@ void fwn_ew_wn_backward(const float* dW, const float* V, const float* g, int K, 
 int fwn_up_bwd_chunks(int B, int H);
 void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
                        float* dx, float* dwk_bias, float* partial, hipStream_t st);
+struct fwn_scale_job;
+struct fwn_pack_job;
+void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack_job* jobs, int njobs, float* scales,
+                          int scale_ld, hipStream_t st);

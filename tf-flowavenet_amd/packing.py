@@ -158,6 +158,84 @@ def upsample_kernel(params, n: int) -> "tuple[np.ndarray, float]":
 _IDX_CACHE = {}
 
 
+class PackPlan:
+    """Recorded packing work for parameters that live in device memory at stable addresses (the fp32
+    masters of a training run): ``refresh()`` re-packs every weight with two grouped launches
+    (``fwn_pack_jobs``) and re-uploads the small host-computed tables in one copy, into the same
+    device buffers - the descriptors built at record time stay valid."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.sjobs, self.slot, self.jobs = [], {}, []
+        self.tables, self.host_cbs, self.keep = [], [], []
+        self.hostview = None
+        self._built = False
+
+    def add(self, v, g, src_k, src_n, k_dst, n_dst, out_ptr, ld_dst, mul=1.0, transposed=False):
+        slot = -1
+        if g is not None:
+            key = (v.data_ptr(), g.data_ptr())
+            if key not in self.slot:
+                self.slot[key] = len(self.sjobs)
+                self.sjobs.append((v.data_ptr(), g.data_ptr(), int(v.shape[0] * v.shape[1]), int(v.shape[2])))
+            slot = self.slot[key]
+        self.jobs.append((v.data_ptr(), src_k.data_ptr(), src_n.data_ptr(), int(out_ptr), int(ld_dst), int(v.shape[2]),
+                          int(k_dst), int(n_dst), slot, int(bool(transposed)), float(mul)))
+        self.keep += [v, g, src_k, src_n]
+        self._built = False
+
+    def table(self, setter, fn):
+        self.tables.append((setter, fn))
+
+    def _build(self):
+        import torch
+        sj = (_lib.ScaleJob * max(1, len(self.sjobs)))()
+        for i, (v, g, k, n) in enumerate(self.sjobs):
+            sj[i].v, sj[i].g, sj[i].k_src, sj[i].n_src = v, g, k, n
+        pj = (_lib.PackJob * max(1, len(self.jobs)))()
+        for i, (v, sk, sn, out, ld, n_src, kd, nd, slot, tr, mul) in enumerate(self.jobs):
+            j = pj[i]
+            j.v, j.src_k, j.src_n, j.out, j.ld_dst = v, sk, sn, out, ld
+            j.n_src, j.k_dst, j.n_dst, j.scale_slot, j.transposed, j.mul = n_src, kd, nd, slot, tr, mul
+        self._sj = torch.frombuffer(bytearray(bytes(sj)), dtype=torch.uint8).to(self.dev)
+        self._pj = torch.frombuffer(bytearray(bytes(pj)), dtype=torch.uint8).to(self.dev)
+        self._scales = torch.empty(max(1, len(self.sjobs)), 512, dtype=torch.float32, device=self.dev)
+        self._built = True
+
+    def run_kernels(self):
+        import torch
+        if not self._built:
+            self._build()
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.check(_lib.load().fwn_pack_jobs(self._sj.data_ptr(), len(self.sjobs), self._pj.data_ptr(), len(self.jobs),
+                                             self._scales.data_ptr(), 512, st), "fwn_pack_jobs")
+
+    def upload_tables(self):
+        import torch
+        arrs = [np.ascontiguousarray(fn(), dtype=np.float32) for _, fn in self.tables]
+        offs, total = [], 0
+        for a in arrs:
+            offs.append(total)
+            total += (a.size + 3) // 4 * 4
+        host = np.zeros(max(total, 4), dtype=np.float32)
+        for a, off in zip(arrs, offs):
+            host[off:off + a.size] = a.reshape(-1)
+        if getattr(self, "_tbuf", None) is None:
+            self._tbuf = torch.from_numpy(host).to(self.dev)
+            for (setter, _), a, off in zip(self.tables, arrs, offs):
+                setter(self._tbuf[off:off + a.size].view(a.shape))
+        else:
+            self._tbuf.copy_(torch.from_numpy(host))
+        for cb in self.host_cbs:
+            cb()
+
+    def refresh(self):
+        """The masters changed: recompute everything that was recorded."""
+        self.hostview.reset()
+        self.upload_tables()
+        self.run_kernels()
+
+
 class PackedModel:
     """Owns the packed device tensors and the ctypes descriptors that point into them."""
 
@@ -175,8 +253,10 @@ class PackedModel:
         return t
 
 
-def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
-    """Upload ``params`` (reference layouts, fp32) and run the packing kernels (K10)."""
+def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | None" = None) -> PackedModel:
+    """Upload ``params`` (reference layouts, fp32) and run the packing kernels (K10).
+    With ``plan`` (params must then be device tensors at stable addresses) the work is recorded into it
+    and executed once; ``plan.refresh()`` repeats it after the parameters changed."""
     import torch
 
     lib = _lib.load()
@@ -203,10 +283,18 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
     # device copy exists.  Every table starts on a 16-byte boundary (float4 loads in the kernels).
     pending = []
 
-    def put(setter, a):
-        pending.append((setter, np.ascontiguousarray(a, dtype=np.float32).reshape(-1), np.shape(a)))
+    def put(setter, fn):
+        """fn() -> the table's current value (re-evaluated by plan.refresh())."""
+        if plan is not None:
+            plan.table(setter, fn)
+        else:
+            a = fn()
+            pending.append((setter, np.ascontiguousarray(a, dtype=np.float32).reshape(-1), np.shape(a)))
 
     def flush_tables():
+        if plan is not None:
+            plan.upload_tables()
+            return
         offs, total = [], 0
         for _, a, _ in pending:
             offs.append(total)
@@ -223,6 +311,9 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
         host-side reductions (bias sums, ActNorm / ZeroConv scale tables) read them through here.
         All small device tensors come over in ONE copy (a per-tensor .cpu() is a sync each)."""
         _cache = None
+
+        def reset(self):
+            self._cache = None
 
         def _fill(self):
             small = [(k, v) for k, v in params.items() if isinstance(v, torch.Tensor) and v.numel() <= 4096]
@@ -244,6 +335,8 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             return self._cache[k] if k in self._cache else v.detach().cpu().numpy()
 
     hostp = _HostView()
+    if plan is not None:
+        plan.hostview = hostp
 
     ident256 = dev_i32("id256", lambda: np.arange(FILTER))
     ident768 = dev_i32("id768", lambda: np.arange(3 * FILTER))
@@ -263,6 +356,14 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
             return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
 
         v = up(params[name + "/kernel"])
+        if plan is not None:
+            if v is not params[name + "/kernel"]:
+                raise ValueError("a PackPlan needs contiguous fp32 device parameters (%s)" % name)
+            if mul is not None and not weight_norm:
+                raise ValueError("mul needs weight_norm")
+            plan.add(v, up(params[name + "/g"]) if weight_norm else None, src_k, src_n, k_dst, n_dst,
+                     out.data_ptr() + 2 * col_off, ld_dst, 1.0 if mul is None else mul)
+            return
         k_src = v.shape[0] * v.shape[1]
         n_src = v.shape[2]
         sc = None
@@ -310,10 +411,9 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
                 wfront2 = bf16_zeros(FILTER, 6 * ch)
                 pack(wp + "/Conv_front", f2, ident256, 6 * ch, FILTER, wfront2, 6 * ch)
                 d.Wfront2 = wfront2.data_ptr()
-            put(lambda v, d=d: setattr(d, "bfront", v.data_ptr()), hostp[wp + "/Conv_front/bias"])
+            put(lambda v, d=d: setattr(d, "bfront", v.data_ptr()), lambda wp=wp: hostp[wp + "/Conv_front/bias"])
 
             wskip = bf16_zeros(FILTER, L * FILTER)
-            bskip = np.zeros(FILTER, dtype=np.float64)
             for l in range(L):
                 rp = "%s/ResBlock_%d" % (wp, l)
                 wd = bf16_zeros(GATE_N, 3 * FILTER)
@@ -324,46 +424,51 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
                 wc = wc_blk[j, l]
                 pack(rp + "/filter_conv_c", c_src_k, gate_rows[0], kcpad, GATE_N, wc, kcpad, mul=GATE_MUL[0])
                 pack(rp + "/gate_conv_c", c_src_k, gate_rows[1], kcpad, GATE_N, wc, kcpad, mul=GATE_MUL[1])
-                bsum = [GATE_MUL[0] * (np.asarray(hostp[rp + "/Conv_filter/bias"], np.float64)
-                                       + np.asarray(hostp[rp + "/filter_conv_c/bias"], np.float64)),
-                        GATE_MUL[1] * (np.asarray(hostp[rp + "/Conv_gate/bias"], np.float64)
-                                       + np.asarray(hostp[rp + "/gate_conv_c/bias"], np.float64))]
-                bg = np.where(fg == 0, bsum[0][gch], bsum[1][gch])
+                def gate_bias(rp=rp):
+                    bsum = [GATE_MUL[0] * (np.asarray(hostp[rp + "/Conv_filter/bias"], np.float64)
+                                           + np.asarray(hostp[rp + "/filter_conv_c/bias"], np.float64)),
+                            GATE_MUL[1] * (np.asarray(hostp[rp + "/Conv_gate/bias"], np.float64)
+                                           + np.asarray(hostp[rp + "/gate_conv_c/bias"], np.float64))]
+                    return np.where(fg == 0, bsum[0][gch], bsum[1][gch])
                 d.Wd[l] = wd.data_ptr()
                 d.Wc[l] = wc.data_ptr()
-                put(lambda v, d=d, l=l: d.bgate.__setitem__(l, v.data_ptr()), bg)
+                put(lambda v, d=d, l=l: d.bgate.__setitem__(l, v.data_ptr()), gate_bias)
                 if l + 1 < L:   # the last layer's res_conv is dead (modules.py:126-128,175-176)
                     wr = bf16_zeros(FILTER, FILTER)
                     pack(rp + "/res_conv", ident256, ident256, FILTER, FILTER, wr, FILTER)
                     d.Wres[l] = wr.data_ptr()
-                    put(lambda v, d=d, l=l: d.bres.__setitem__(l, v.data_ptr()), hostp[rp + "/res_conv/bias"])
+                    put(lambda v, d=d, l=l: d.bres.__setitem__(l, v.data_ptr()), lambda rp=rp: hostp[rp + "/res_conv/bias"])
                 pack(rp + "/skip_conv", ident256, ident256, FILTER, FILTER, wskip, L * FILTER, col_off=l * FILTER)
-                bskip += np.asarray(hostp[rp + "/skip_conv/bias"], np.float64)
             d.Wskip = wskip.data_ptr()
-            put(lambda v, d=d: setattr(d, "bskip", v.data_ptr()), bskip)
+            put(lambda v, d=d: setattr(d, "bskip", v.data_ptr()),
+                lambda wp=wp: sum(np.asarray(hostp["%s/ResBlock_%d/skip_conv/bias" % (wp, l)], np.float64) for l in range(L)))
 
             wfin = bf16_zeros(FILTER, FILTER)
             pack(wp + "/Conv_final", accperm, ident256, FILTER, FILTER, wfin, FILTER)
             d.Wfinal = wfin.data_ptr()
-            put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), hostp[wp + "/Conv_final/bias"])
+            put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), lambda wp=wp: hostp[wp + "/Conv_final/bias"])
 
             wz = bf16_zeros(npt * 64, FILTER)
             pack(wp + "/ZeroConv1d", accperm, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
-            zb = np.asarray(hostp[wp + "/ZeroConv1d/bias"], np.float64).reshape(-1)
-            zs = np.asarray(hostp[wp + "/ZeroConv1d/scale"], np.float64).reshape(-1)
-            valid = zsn_host >= 0
-            bz = np.zeros(npt * 64)
-            ez = np.ones(npt * 64)
-            bz[valid] = zb[zsn_host[valid]]
-            ez[valid] = np.exp(3.0 * zs[zsn_host[valid]])
+            def zero_tables(which, wp=wp, zsn_host=zsn_host, npt=npt):
+                valid = zsn_host >= 0
+                if which == 0:
+                    zb = np.asarray(hostp[wp + "/ZeroConv1d/bias"], np.float64).reshape(-1)
+                    out = np.zeros(npt * 64)
+                    out[valid] = zb[zsn_host[valid]]
+                else:
+                    zs = np.asarray(hostp[wp + "/ZeroConv1d/scale"], np.float64).reshape(-1)
+                    out = np.ones(npt * 64)
+                    out[valid] = np.exp(3.0 * zs[zsn_host[valid]])
+                return out
             d.Wzero = wz.data_ptr()
-            put(lambda v, d=d: setattr(d, "bzero", v.data_ptr()), bz)
-            put(lambda v, d=d: setattr(d, "ezero", v.data_ptr()), ez)
+            put(lambda v, d=d: setattr(d, "bzero", v.data_ptr()), lambda f=zero_tables: f(0))
+            put(lambda v, d=d: setattr(d, "ezero", v.data_ptr()), lambda f=zero_tables: f(1))
 
             def set_an(v, d=d, key=(i, j)):
                 pm.an[key] = v
                 d.an = v.data_ptr()
-            put(set_an, actnorm_table(hostp[fp + "/ActNorm/b"], hostp[fp + "/ActNorm/logs"], i))
+            put(set_an, lambda fp=fp, i=i: actnorm_table(hostp[fp + "/ActNorm/b"], hostp[fp + "/ActNorm/logs"], i))
 
     md = pm.model_desc
     md.n_block, md.n_flow, md.n_layer, md.num_mels = hp.n_block, hp.n_flow, L, hp.num_mels
@@ -371,11 +476,15 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0) -> PackedModel:
     if md.n_up > _lib.FWN_MAX_UPSAMPLE:
         raise ValueError("too many upsample stages")
     for n, s in enumerate(hp.upsample_scales):
-        wk, bias = upsample_kernel(hostp, n)
         md.up_scale[n] = int(s)
-        put(lambda v, n=n: md.up_w.__setitem__(n, v.data_ptr()), wk)
-        md.up_bias[n] = bias
+        put(lambda v, n=n: md.up_w.__setitem__(n, v.data_ptr()), lambda n=n: upsample_kernel(hostp, n)[0])
+        md.up_bias[n] = upsample_kernel(hostp, n)[1]
+        if plan is not None:
+            plan.host_cbs.append(lambda n=n: md.up_bias.__setitem__(n, upsample_kernel(hostp, n)[1]))
     flush_tables()
+    if plan is not None:
+        plan.run_kernels()
+        pm.plan = plan
     md.flows = C.cast(pm.flow_descs, C.POINTER(_lib.FlowDesc))
     md.cond_mode = int(cond_mode)
     torch.cuda.current_stream(dev).synchronize()
