@@ -247,3 +247,29 @@ def test_two_rank_data_parallel_step_matches_one_process_on_the_whole_batch(tmp_
     want, got = 2.0 * tr.opt.g.cpu().numpy().astype(np.float64), r0["g"].astype(np.float64)
     cos = float((want * got).sum() / np.sqrt((want * want).sum() * (got * got).sum()))
     assert cos > 0.999 and abs(np.linalg.norm(got) / np.linalg.norm(want) - 1.0) < 2e-2, (cos, np.linalg.norm(got), np.linalg.norm(want))
+
+
+def test_recorded_packing_matches_immediate_packing():
+    """Device-resident parameters take the PackPlan path (grouped, transposed packing, refreshed in
+    place every step); NumPy parameters the immediate one: same gradients, also after the
+    parameters changed in place."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import GradEngine
+    hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
+    p = W.synthetic_params(hp, 9, actnorm="random")
+    inp = W.synthetic_inputs(hp, 2, 256)
+    x, c = torch.from_numpy(inp["x"]).reshape(2, 256), torch.from_numpy(inp["c"])
+    pd = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in p.items()}
+    eng = GradEngine(hp)
+    for step in range(2):
+        l_d, _, _, g_d = eng.loss_and_grads(pd, x, c)
+        assert eng._tp.plan is not None
+        l_n, _, _, g_n = GradEngine(hp).loss_and_grads({k: v.cpu().numpy() for k, v in pd.items()}, x, c)
+        assert float(l_d) == float(l_n)
+        for k in g_n:
+            assert torch.equal(g_d[k].reshape(-1), g_n[k].reshape(-1)), k
+        for k, v in pd.items():          # "an optimiser step": every parameter moves, in place
+            v.mul_(1.01)

@@ -88,10 +88,8 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const fwn_pack_job* __re
         const int sk = j.src_k[kd], sn = j.src_n[nd];
         if (sn < 0) continue;
         float val = 0.0f;
-        if (sk >= 0) {
-            val = j.v[(size_t)sk * j.n_src + sn] * j.mul;
-            if (sc) val *= sc[sn];
-        }
+        if (sk >= 0)      // (scale * mul) first, like fwn_pack_bf16 fed a pre-multiplied scale: same bf16 bits
+            val = j.v[(size_t)sk * j.n_src + sn] * (sc ? sc[sn] * j.mul : j.mul);
         out[j.transposed ? (size_t)kd * j.ld_dst + nd : (size_t)nd * j.ld_dst + kd] = (bf16)val;
     }
 }

@@ -267,6 +267,8 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
     half = hp.num_mels // 2
     pm = PackedModel(hp, device)
     dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:       # "cuda" != "cuda:0" for torch: make it concrete
+        dev = torch.device("cuda", torch.cuda.current_device())
     stream = torch.cuda.current_stream(dev).cuda_stream
     L = hp.n_layer
 

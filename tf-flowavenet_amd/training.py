@@ -119,9 +119,16 @@ class _TrainPack:
     def __init__(self, params, hp, device):
         import torch
         self.hp, self.dev = hp, torch.device(device)
+        if self.dev.type == "cuda" and self.dev.index is None:      # "cuda" != "cuda:0" for torch: make it concrete
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.load()
-        self.pm = packing.pack_model(params, hp, device, cond_mode=1)
         self.params = params
+        # parameters that are contiguous fp32 device tensors (the masters of a training run) have
+        # stable addresses: record the packing once (packing.PackPlan) and refresh() it every step
+        stable = all(isinstance(v, torch.Tensor) and v.device == self.dev and v.dtype == torch.float32 and v.is_contiguous()
+                     for v in params.values())
+        self.plan = packing.PackPlan(self.dev) if stable else None
+        self.pm = packing.pack_model(params, hp, device, cond_mode=1, plan=self.plan)
         self.flows = {}
         self._idx = {}
         self._scale = torch.empty(512, dtype=torch.float32, device=self.dev)
@@ -130,7 +137,84 @@ class _TrainPack:
                        for i in range(hp.n_block)]
         for i in range(hp.n_block):
             for j in range(hp.n_flow):
-                self.flows[(i, j)] = self._pack_flow(i, j)
+                self.flows[(i, j)] = self._pack_flow_plan(i, j) if stable else self._pack_flow(i, j)
+        if stable:
+            self.plan.run_kernels()
+        self._small_tables()
+
+    def refresh(self):
+        """The masters changed (an optimiser step): re-pack everything into the same buffers."""
+        self.plan.refresh()
+        self._small_tables()
+
+    def _small_tables(self):
+        """Per-flow bias / scale vectors of the un-fused tail, in device channel order (parameter-sized)."""
+        import torch
+        hp = self.hp
+        for (i, j), t in self.flows.items():
+            wp = weights.flow_prefix(i, j) + "/WaveNet"
+            t["bskip"] = sum(self._f32("%s/ResBlock_%d/skip_conv/bias" % (wp, l)) for l in range(hp.n_layer))
+            t["bfin"] = self._f32(wp + "/Conv_final/bias")
+            t["bz"] = self._f32(wp + "/ZeroConv1d/bias").reshape(-1)[t["zcol"]].contiguous()
+            t["ez"] = torch.exp(3.0 * self._f32(wp + "/ZeroConv1d/scale").reshape(-1))[t["zcol"]].contiguous()
+
+    def _pack_flow_plan(self, i, j):
+        """The backward's transposed / natural-order copies as jobs of the plan (transposed packing:
+        no separate transposes)."""
+        import torch
+        hp, dev, plan = self.hp, self.dev, self.plan
+        ch, half, L = 1 << i, hp.num_mels // 2, hp.n_layer
+        cin = half * (2 << i)
+        wp = weights.flow_prefix(i, j) + "/WaveNet"
+        bz = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=dev)
+        id256 = self._i32("id256", np.arange(256))
+        taps = [self._i32(("tap256", tap), tap * 256 + np.arange(256)) for tap in range(3)]
+        csrc = self._i32(("csrc", i), packing.cond_src_k(i, half))
+        br = packing.bitrev_table(i).astype(np.int64)
+        fk = packing.front_src_k(i)
+        P = self.params
+
+        def job(name, src_k, k_dst, src_n, n_dst, out, col, transposed, weight_norm=True):
+            plan.add(P[name + "/kernel"], P[name + "/g"] if weight_norm else None, src_k, src_n, k_dst, n_dst,
+                     out.data_ptr() + 2 * col, int(out.stride(0)), 1.0, transposed)
+
+        t = {}
+        t["WfT"] = bz(ch, 768)
+        for tap in range(3):
+            job(wp + "/Conv_front", self._i32(("fk", i, tap), fk[tap * ch:(tap + 1) * ch]), ch, id256, 256, t["WfT"], tap * 256, True)
+        t["WdT"], t["WcT"], t["WresT"], t["WskipT"] = [], [], [], []
+        t["Wskip"] = bz(256, L * 256)
+        for l in range(L):
+            rp = "%s/ResBlock_%d" % (wp, l)
+            wdt = bz(256, 1536)
+            for tap in range(3):
+                job(rp + "/Conv_filter", taps[tap], 256, id256, 256, wdt, tap * 512, True)
+                job(rp + "/Conv_gate", taps[tap], 256, id256, 256, wdt, tap * 512 + 256, True)
+            t["WdT"].append(wdt)
+            wct = bz(cin, 512)
+            job(rp + "/filter_conv_c", csrc, cin, id256, 256, wct, 0, True)
+            job(rp + "/gate_conv_c", csrc, cin, id256, 256, wct, 256, True)
+            t["WcT"].append(wct)
+            if l + 1 < L:
+                wrt = bz(256, 256)
+                job(rp + "/res_conv", id256, 256, id256, 256, wrt, 0, True)
+                t["WresT"].append(wrt)
+            job(rp + "/skip_conv", id256, 256, id256, 256, t["Wskip"], l * 256, False)
+            wst = bz(256, 256)
+            job(rp + "/skip_conv", id256, 256, id256, 256, wst, 0, True)
+            t["WskipT"].append(wst)
+        t["Wfin"], t["WfinT"] = bz(256, 256), bz(256, 256)
+        job(wp + "/Conv_final", id256, 256, id256, 256, t["Wfin"], 0, False)
+        job(wp + "/Conv_final", id256, 256, id256, 256, t["WfinT"], 0, True)
+        zcol = np.concatenate([br, ch + br])
+        t["zcol"] = self._i64(("zcol", i), zcol)
+        zc32 = self._i32(("zcol", i), zcol)
+        n2 = 2 * ch
+        t["ldz"] = max(8, n2)
+        t["Wz"], t["WzT"] = bz(n2, 256), bz(256, t["ldz"])
+        job(wp + "/ZeroConv1d", id256, 256, zc32, n2, t["Wz"], 0, False, weight_norm=False)
+        job(wp + "/ZeroConv1d", id256, 256, zc32, n2, t["WzT"], 0, True, weight_norm=False)
+        return t
 
     def _i32(self, key, arr):
         import torch
@@ -212,11 +296,9 @@ class _TrainPack:
             wskip[:, l * 256:(l + 1) * 256] = ws
             t["WskipT"].append(transpose_shift(ws, 256, 256, ld_dst=256))
         t["Wskip"] = wskip
-        t["bskip"] = sum(self._f32("%s/ResBlock_%d/skip_conv/bias" % (wp, l)) for l in range(L))
         wfin = bz(256, 256)
         self._pack(wp + "/Conv_final", id256, id256, 256, 256, wfin)
         t["Wfin"], t["WfinT"] = wfin, transpose_shift(wfin, 256, 256, ld_dst=256)
-        t["bfin"] = self._f32(wp + "/Conv_final/bias")
         # ZeroConv rows in plane order: row fg*Ch + tau serves logical channel fg*Ch + bitrev(tau)
         zcol = np.concatenate([br, ch + br])
         t["zcol"] = self._i64(("zcol", i), zcol)
@@ -227,8 +309,6 @@ class _TrainPack:
         t["Wz"] = wz
         t["WzT"] = transpose_shift(wz, n2, 256, ld_dst=packing.roundup(n2, 64))[:, :ldz].contiguous()   # [256][ldz], zero padded
         t["ldz"] = ldz
-        t["bz"] = self._f32(wp + "/ZeroConv1d/bias").reshape(-1)[t["zcol"]].contiguous()
-        t["ez"] = torch.exp(3.0 * self._f32(wp + "/ZeroConv1d/scale").reshape(-1))[t["zcol"]].contiguous()
         return t
 
 
@@ -268,7 +348,14 @@ class GradEngine:
         _STREAMS.clear()
         _STREAMS[torch.zeros(0, device=dev).device] = st
         shp = weights.param_shapes(hp)
-        tp = self._tp = _TrainPack(params, hp, self.device)
+        key = tuple(v.data_ptr() for v in list(params.values())[:4]) if all(hasattr(v, "data_ptr") for v in list(params.values())[:4]) else None
+        tp = getattr(self, "_tp", None)
+        if tp is not None and tp.plan is not None and key is not None and getattr(self, "_tp_key", None) == key:
+            tp.params = params
+            tp.refresh()
+        else:
+            tp = self._tp = _TrainPack(params, hp, self.device)
+            self._tp_key = key if tp.plan is not None else None
         pm, md = tp.pm, tp.pm.model_desc
         L, half = hp.n_layer, hp.num_mels // 2
         x = torch.as_tensor(x).to(device=dev, dtype=torch.float32).contiguous()
