@@ -3,11 +3,11 @@ crops, n_block=8 n_flow=6) on one GPU: step time, memory, loss trajectory on a f
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from tf_flowavenet_amd.hparams import default_hparams
+from tf_flowavenet_amd.hparams import default_hparams, hparams8000
 from tf_flowavenet_amd import weights as W
 from tf_flowavenet_amd.training import Trainer
 
-hp = default_hparams()
+hp = hparams8000() if os.environ.get("FWN_8K") else default_hparams()
 b, t = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 6400
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 p = W.synthetic_params(hp, 1234)
