@@ -184,10 +184,11 @@ typedef struct fwn_gemm_desc {
     float oscale;       int32_t pad1_;
 } fwn_gemm_desc;
 int fwn_gemm(const fwn_gemm_desc* g, void* stream);
-/* dst[c][m] = src[m + shift][c] (zero where the tap leaves its clip / the matrix; columns m >= M zero),
- * dst bf16 [C (+1)][ld_dst]; ones_row: row C = 1 for m < M (bias gradients ride the weight-gradient GEMM). */
-int fwn_transpose_shift(const void* src, int M, int C, int ld_src, int shift, int Ti, void* dst, int ld_dst,
-                        int ones_row, void* stream);
+/* For tap z < ntap (shift = shift0 + z*dshift): dst[z*C + c][m] = src[m + shift][c] (zero where the tap
+ * leaves its clip / the matrix; columns m >= M zero), dst bf16 [ntap*C (+1)][ld_dst]; ones_row: the row after
+ * the last tap = 1 for m < M (bias gradients ride the weight-gradient GEMM). */
+int fwn_transpose_shift(const void* src, int M, int C, int ld_src, int shift0, int dshift, int ntap, int Ti, void* dst,
+                        int ld_dst, int ones_row, void* stream);
 int fwn_reduce_splits(const float* partial, int nsplit, int64_t stride, int64_t n, float scale, float* out,
                       void* stream);
 
@@ -206,7 +207,10 @@ int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void*
  * fwn_colsum_prod  : out[c] <- scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C], fixed order;
  *                    partial: scratch of fwn_colsum_partials(M, C) floats
  * fwn_actnorm_bwd  : dy <- dy * scale; y <- y / scale - shift (the plane before ActNorm)
- * fwn_wn_backward  : weight-norm backward per output column: dW, V fp32 [K][N], g [N] -> dV, dg   (convolutional.py:73-80) */
+ * fwn_wn_backward  : weight-norm backward per output column, straight from the split-K partials of the
+ *                    weight-gradient GEMM: dW[k][n] = scale * sum_s part[s][row_src ? row_src[k] : k][col0 + n]
+ *                    (part rows have ldp columns), db[n] = the same sum over row bias_row (< 0 / NULL: none);
+ *                    V fp32 [K][N], g [N] -> dV, dg; g == NULL: dV = dW (no weight norm)   (convolutional.py:73-80) */
 int fwn_actnorm_apply(float* x, const float* an, int64_t n, int Ch, void* stream);
 int fwn_coupling_fwd(float* yb, const float* Z, const float* ez, int64_t M, int Ch, float* partial, int nblocks,
                      void* stream);
@@ -217,8 +221,9 @@ int fwn_colsum_partials(int64_t M, int C);
 int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C, float scale, float* partial, float* out,
                     void* stream);
 int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, void* stream);
-int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg,
-                    void* stream);
+int fwn_wn_backward(const float* part, int nsplit, int64_t split_stride, int ldp, const int32_t* row_src, int col0,
+                    int bias_row, float scale, const float* V, const float* g, int K, int N, float* dV, float* dg,
+                    float* db, void* stream);
 
 /* Backward of one up-sampling stage (fwn_upsample_stage with fp32 output): y, dy [B][H*s][W], x [B][H][W].
  * dy <- dy * LeakyReLU'(y) in place; dx (may be NULL) <- gradient wrt x; dwk_bias [6s + 1] <- gradients of

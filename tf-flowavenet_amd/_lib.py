@@ -109,8 +109,8 @@ SIGNATURES = {
     "fwn_colsum_partials": (C.c_int, [i64, C.c_int]),
     "fwn_colsum_prod": (C.c_int, [vp, vp, i64, C.c_int, C.c_float, vp, vp, vp]),
     "fwn_actnorm_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
-    "fwn_wn_backward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
-    "fwn_transpose_shift": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "fwn_wn_backward": (C.c_int, [vp, C.c_int, i64, C.c_int, vp, C.c_int, C.c_int, C.c_float, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "fwn_transpose_shift": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "fwn_reduce_splits": (C.c_int, [vp, C.c_int, i64, i64, C.c_float, vp, vp]),
     "fwn_mel_spectrogram": (C.c_int, [vp, i64, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
     "fwn_grad_norm_partials": (C.c_int, [i64]),

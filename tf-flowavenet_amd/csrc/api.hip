@@ -255,10 +255,11 @@ int fwn_gemm(const fwn_gemm_desc* g, void* stream) {
     fwn_gemm_launch(g, (hipStream_t)stream);
     return check_launch("fwn_gemm");
 }
-int fwn_transpose_shift(const void* src, int M, int C, int ld_src, int shift, int Ti, void* dst, int ld_dst,
-                        int ones_row, void* stream) {
-    REQUIRE(src && dst && M > 0 && C > 0 && ld_src >= C && ld_dst >= M && Ti >= 0, "fwn_transpose_shift: bad argument");
-    fwn_transpose_launch(src, M, C, ld_src, shift, Ti, dst, ld_dst, ones_row, (hipStream_t)stream);
+int fwn_transpose_shift(const void* src, int M, int C, int ld_src, int shift0, int dshift, int ntap, int Ti, void* dst,
+                        int ld_dst, int ones_row, void* stream) {
+    REQUIRE(src && dst && M > 0 && C > 0 && ld_src >= C && ld_dst >= M && Ti >= 0 && ntap >= 1 && ntap <= 64,
+            "fwn_transpose_shift: bad argument");
+    fwn_transpose_launch(src, M, C, ld_src, shift0, dshift, ntap, Ti, dst, ld_dst, ones_row, (hipStream_t)stream);
     return check_launch("fwn_transpose_shift");
 }
 int fwn_reduce_splits(const float* partial, int nsplit, int64_t stride, int64_t n, float scale, float* out,
@@ -302,10 +303,13 @@ int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, voi
     fwn_ew_actnorm_bwd(dy, y, an, (long)n, Ch, (hipStream_t)stream);
     return check_launch("fwn_actnorm_bwd");
 }
-int fwn_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg,
-                    void* stream) {
-    REQUIRE(dW && V && g && dV && dg && K > 0 && N > 0, "fwn_wn_backward: bad argument");
-    fwn_ew_wn_backward(dW, V, g, K, N, dV, dg, (hipStream_t)stream);
+int fwn_wn_backward(const float* part, int nsplit, int64_t split_stride, int ldp, const int32_t* row_src, int col0,
+                    int bias_row, float scale, const float* V, const float* g, int K, int N, float* dV, float* dg,
+                    float* db, void* stream) {
+    REQUIRE(part && dV && K > 0 && N > 0 && nsplit >= 1 && ldp >= col0 + N && col0 >= 0, "fwn_wn_backward: bad argument");
+    REQUIRE(!g || (V && dg), "fwn_wn_backward: weight norm needs V and dg");
+    fwn_ew_wn_backward(part, nsplit, (long)split_stride, ldp, row_src, col0, bias_row, scale, V, g, K, N, dV, dg, db,
+                       (hipStream_t)stream);
     return check_launch("fwn_wn_backward");
 }
 

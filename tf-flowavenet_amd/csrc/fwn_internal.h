@@ -39,8 +39,8 @@ void fwn_launch_adam(float* w, const float* g, float* m, float* v, long n, const
 // train_kernels.hip
 struct fwn_gemm_desc;
 int fwn_gemm_launch(const fwn_gemm_desc* g, hipStream_t st);
-void fwn_transpose_launch(const void* src, int M, int C, int ld_src, int shift, int Ti, void* dst, int ld_dst,
-                          int ones_row, hipStream_t st);
+void fwn_transpose_launch(const void* src, int M, int C, int ld_src, int shift0, int dshift, int ntap, int Ti, void* dst,
+                          int ld_dst, int ones_row, hipStream_t st);
 void fwn_reduce_splits_launch(const float* partial, int nsplit, long stride, long n, float scale, float* out,
                               hipStream_t st);
 void fwn_ew_actnorm_fwd(float* x, const float* an, long n, int Ch, hipStream_t st);
@@ -53,7 +53,9 @@ int fwn_colsum_blocks(long M, int C);
 void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* partial, float* out,
                         hipStream_t st);
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st);
-void fwn_ew_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg, hipStream_t st);
+void fwn_ew_wn_backward(const float* part, int nsplit, long split_stride, int ldp, const int* row_src, int col0,
+                        int bias_row, float scale, const float* V, const float* g, int K, int N, float* dV, float* dg,
+                        float* db, hipStream_t st);
 int fwn_up_bwd_chunks(int B, int H);
 void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
                        float* dx, float* dwk_bias, float* partial, hipStream_t st);

@@ -105,10 +105,13 @@ int fwn_gemm_launch(const fwn_gemm_desc* g, hipStream_t st) {
 // ones_row) is 1 for m < M - so the weight-gradient GEMM over the transposed copy also yields the
 // bias gradient (column sums) in its extra output row.
 __global__ __launch_bounds__(256) void transpose_shift_kernel(const bf16* __restrict__ src, int M, int C, int lds_,
-                                                              int shift, int Ti, bf16* __restrict__ dst, int ldd,
-                                                              int ones_row) {
+                                                              int shift0, int dshift, int Ti, bf16* __restrict__ dst,
+                                                              int ldd, int ones_row) {
+    // blockIdx.z = tap: shift = shift0 + z * dshift, written to dst rows [z*C, (z+1)*C)
     __shared__ bf16 tile[64][66];
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int shift = shift0 + (int)blockIdx.z * dshift;
+    dst += (size_t)blockIdx.z * C * ldd;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int mm = i >> 6, cc = i & 63;
         const int m = m0 + mm, c = c0 + cc;
@@ -122,15 +125,15 @@ __global__ __launch_bounds__(256) void transpose_shift_kernel(const bf16* __rest
         const int m = m0 + mm, c = c0 + cc;
         if (c < C && m < ldd) dst[(size_t)c * ldd + m] = tile[mm][cc];
     }
-    if (ones_row && blockIdx.y == 0 && threadIdx.x < 64) {
+    if (ones_row && blockIdx.z == gridDim.z - 1 && blockIdx.y == 0 && threadIdx.x < 64) {
         const int m = m0 + threadIdx.x;
         if (m < ldd) dst[(size_t)C * ldd + m] = (bf16)(m < M ? 1.0f : 0.0f);
     }
 }
-void fwn_transpose_launch(const void* src, int M, int C, int ld_src, int shift, int Ti, void* dst, int ld_dst,
-                          int ones_row, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_shift_kernel, dim3((ld_dst + 63) / 64, (C + 63) / 64), dim3(256), 0, st,
-                       (const bf16*)src, M, C, ld_src, shift, Ti, (bf16*)dst, ld_dst, ones_row);
+void fwn_transpose_launch(const void* src, int M, int C, int ld_src, int shift0, int dshift, int ntap, int Ti, void* dst,
+                          int ld_dst, int ones_row, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_shift_kernel, dim3((ld_dst + 63) / 64, (C + 63) / 64, ntap), dim3(256), 0, st,
+                       (const bf16*)src, M, C, ld_src, shift0, dshift, Ti, (bf16*)dst, ld_dst, ones_row);
 }
 
 // ---- out[i] = scale * sum_s partial[s][i], fixed order (deterministic split-K second pass) -------
@@ -254,19 +257,37 @@ __global__ __launch_bounds__(256) void actnorm_bwd_kernel(float* __restrict__ dy
         y[i] = y[i] * an[2 * Ch + c] - an[c];
     }
 }
-// Weight-norm backward (convolutional.py:73-80): W = V g / ||V||_col.  dW, V: fp32 [K][N]; one
-// workgroup per output column: dg = sum_k dW V / nrm, dV = (g / nrm) (dW - V dg / nrm).
-__global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ dW, const float* __restrict__ V,
+// Weight-norm backward (convolutional.py:73-80): W = V g / ||V||_col, straight from the split-K
+// partials of the weight-gradient GEMM: dW[k][n] = scale * sum_s part[s][row_src ? row_src[k] : k][col0 + n]
+// (fixed order), bias gradient = the same sum over the ones row `bias_row` (< 0: none).  One workgroup
+// per output column: dg = sum_k dW V / nrm, dV = (g / nrm) (dW - V dg / nrm).  g == NULL: no weight norm,
+// dV = dW.
+__global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ part, int nsplit, long split_stride,
+                                                          int ldp, const int* __restrict__ row_src, int col0,
+                                                          int bias_row, float scale, const float* __restrict__ V,
                                                           const float* __restrict__ g, int K, int N,
-                                                          float* __restrict__ dV, float* __restrict__ dg) {
+                                                          float* __restrict__ dV, float* __restrict__ dg,
+                                                          float* __restrict__ db) {
     __shared__ double red[2][256];
     const int n = blockIdx.x;
+    auto dw = [&](int row) {
+        float a = 0.0f;
+        const size_t off = (size_t)row * ldp + col0 + n;
+        for (int s = 0; s < nsplit; ++s) a += part[(size_t)s * split_stride + off];
+        return a * scale;
+    };
+    if (threadIdx.x == 0 && db && bias_row >= 0) db[n] = dw(bias_row);
     double ss = 0.0, dot = 0.0;
     for (int k = threadIdx.x; k < K; k += 256) {
-        const double v = V[(size_t)k * N + n];
-        ss += v * v;
-        dot += v * (double)dW[(size_t)k * N + n];
+        const float d = dw(row_src ? row_src[k] : k);
+        dV[(size_t)k * N + n] = d;                       // staged: finalised below
+        if (g) {
+            const double v = V[(size_t)k * N + n];
+            ss += v * v;
+            dot += v * (double)d;
+        }
     }
+    if (!g) return;
     red[0][threadIdx.x] = ss;
     red[1][threadIdx.x] = dot;
     __syncthreads();
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restric
     const double gn = (double)g[n] / nrm;
     for (int k = threadIdx.x; k < K; k += 256) {
         const size_t i = (size_t)k * N + n;
-        dV[i] = (float)(gn * ((double)dW[i] - (double)V[i] * dgn / nrm));
+        dV[i] = (float)(gn * ((double)dV[i] - (double)V[i] * dgn / nrm));
     }
 }
 
@@ -313,8 +334,11 @@ void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float sca
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st) {
     hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, an, n, Ch);
 }
-void fwn_ew_wn_backward(const float* dW, const float* V, const float* g, int K, int N, float* dV, float* dg, hipStream_t st) {
-    hipLaunchKernelGGL(wn_backward_kernel, dim3(N), dim3(256), 0, st, dW, V, g, K, N, dV, dg);
+void fwn_ew_wn_backward(const float* part, int nsplit, long split_stride, int ldp, const int* row_src, int col0,
+                        int bias_row, float scale, const float* V, const float* g, int K, int N, float* dV, float* dg,
+                        float* db, hipStream_t st) {
+    hipLaunchKernelGGL(wn_backward_kernel, dim3(N), dim3(256), 0, st, part, nsplit, split_stride, ldp, row_src, col0,
+                       bias_row, scale, V, g, K, N, dV, dg, db);
 }
 
 // ---- backward of one up-sampling stage: Conv2DTranspose((2s,3),(s,1),'same') + LeakyReLU(0.4) -----

@@ -56,14 +56,15 @@ def gemm(segs, w, n, m, *, ti=0, bias=None, res=None, rscale=1.0, mask=None, rel
     return out
 
 
-def transpose_shift(x, m, c, *, shift=0, ti=0, ones_row=False, ld_dst=None):
-    """``dst[c', m'] = x[m' + shift, c']`` (zero where the tap leaves its clip), bf16 ``[c (+1), ld_dst]``."""
+def transpose_shift(x, m, c, *, shift=0, dshift=0, ntap=1, ti=0, ones_row=False, ld_dst=None):
+    """``dst[z*c + c', m'] = x[m' + shift + z*dshift, c']`` for tap z < ntap (zero where the tap leaves its
+    clip), bf16 ``[ntap*c (+1), ld_dst]``; ones_row appends a row of ones (for m' < m)."""
     import torch
     lib = _lib.load()
     ld_dst = ld_dst or (m + 63) // 64 * 64
-    dst = torch.empty(c + (1 if ones_row else 0), ld_dst, dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.fwn_transpose_shift(x.data_ptr(), int(m), int(c), int(x.stride(0)), int(shift), int(ti),
-                                       dst.data_ptr(), int(ld_dst), int(bool(ones_row)), _stream(x)), "fwn_transpose_shift")
+    dst = torch.empty(ntap * c + (1 if ones_row else 0), ld_dst, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.fwn_transpose_shift(x.data_ptr(), int(m), int(c), int(x.stride(0)), int(shift), int(dshift), int(ntap),
+                                       int(ti), dst.data_ptr(), int(ld_dst), int(bool(ones_row)), _stream(x)), "fwn_transpose_shift")
     return dst
 
 
@@ -78,25 +79,29 @@ def reduce_splits(partial, scale=1.0):
     return out
 
 
-def weight_grad(x, dy, m, kx, n, *, shifts=(0,), ti=0, nsplit=None):
-    """``dW[tap*kx + i, j] = sum_r x[r + shift_tap, i] * dy[r, j]`` and ``db[j] = sum_r dy[r, j]`` (fp32).
+def weight_grad_partials(x, m, kx, dyt, n, *, shifts=(0,), ti=0, nsplit=None):
+    """Split-K partials of ``dW[tap*kx + i, j] = sum_r x[r + shift_tap, i] * dy[r, j]`` with the bias
+    gradient ``sum_r dy[r, j]`` as one more row: fp32 ``[S, len(shifts)*kx + 1, n]``.
 
-    x: bf16 [m, >=kx], dy: bf16 [m, >=n].  Returns (dW [len(shifts)*kx, n], db [n])."""
-    import torch
-    mp = (m + 63) // 64 * 64
+    x: bf16 [m, >=kx]; dyt: ``transpose_shift(dy, m, n)`` (shared by every weight gradient that
+    contracts with the same dy); shifts: an arithmetic progression."""
+    mp = int(dyt.shape[1])
     rows = len(shifts) * kx
-    xt = torch.empty(rows + 1, mp, dtype=torch.bfloat16, device=x.device)
-    lib = _lib.load()
-    for i, sh in enumerate(shifts):
-        last = i == len(shifts) - 1
-        _lib.check(lib.fwn_transpose_shift(x.data_ptr(), m, kx, int(x.stride(0)), int(sh), int(ti),
-                                           xt[i * kx:].data_ptr(), mp, int(last), _stream(x)), "fwn_transpose_shift")
-    dyt = transpose_shift(dy, m, n, ld_dst=mp)
+    dshift = shifts[1] - shifts[0] if len(shifts) > 1 else 0
+    xt = transpose_shift(x, m, kx, shift=shifts[0], dshift=dshift, ntap=len(shifts), ti=ti, ones_row=True, ld_dst=mp)
     if nsplit is None:
         tiles = ((rows + 1 + 63) // 64) * ((n + 127) // 128)
         nsplit = max(1, min(mp // 64, -(-256 // tiles)))
     part = gemm([(xt, mp, 0, 0)], dyt, n, rows + 1, out_f32=True, nsplit=nsplit)
-    full = reduce_splits(part) if nsplit > 1 else part
+    return part if nsplit > 1 else part[None]
+
+
+def weight_grad(x, dy, m, kx, n, *, shifts=(0,), ti=0, nsplit=None):
+    """``(dW [len(shifts)*kx, n], db [n])`` fp32: the partials of ``weight_grad_partials`` summed in a fixed order."""
+    dyt = transpose_shift(dy, m, n)
+    part = weight_grad_partials(x, m, kx, dyt, n, shifts=shifts, ti=ti, nsplit=nsplit)
+    full = reduce_splits(part) if part.shape[0] > 1 else part[0]
+    rows = len(shifts) * kx
     return full[:rows], full[rows]
 
 
@@ -133,6 +138,12 @@ class _TrainPack:
         self._idx = {}
         self._scale = torch.empty(512, dtype=torch.float32, device=self.dev)
         self.br = [self._i64(("br", i), packing.bitrev_table(i)) for i in range(hp.n_block)]
+        half_ = hp.num_mels // 2
+        # logical row of a weight gradient -> row of the GEMM that computed it in device channel order
+        self.cond_rows = [self._i32(("cond_rows", i), np.argsort(packing.cond_src_k(i, half_)[:half_ * (2 << i)]))
+                          for i in range(hp.n_block)]
+        self.front_rows = [self._i32(("front_rows", i), np.concatenate([tap * (1 << i) + packing.bitrev_table(i) for tap in range(3)]))
+                           for i in range(hp.n_block)]
         self.csrc64 = [self._i64(("csrc", i), packing.cond_src_k(i, hp.num_mels // 2)[:(hp.num_mels // 2) * (2 << i)])
                        for i in range(hp.n_block)]
         for i in range(hp.n_block):
@@ -458,33 +469,34 @@ class GradEngine:
             grads[wp + "/ZeroConv1d/kernel"] = g_wz.view(1, 256, 2 * ch)
             grads[wp + "/ZeroConv1d/bias"] = g_bz
             du = gemm([(dz, ldz, 0, 0)], t["WzT"], 256, m, mask=u_act)
-            self._wn(grads, params, wp + "/Conv_final", *weight_grad(s_act, du, m, 256, 256), (1, 256, 256))
+            self._wn(grads, wp + "/Conv_final", weight_grad_partials(s_act, m, 256, transpose_shift(du, m, 256), 256), 256, 0, (1, 256, 256))
             ds = gemm([(du, 256, 0, 0)], t["WfinT"], 256, m, mask=s_act)
+            dst_ = transpose_shift(ds, m, 256)                 # shared by the L skip convs
             d_o = []
             for l in range(L):
                 rp = "%s/ResBlock_%d" % (wp, l)
-                self._wn(grads, params, rp + "/skip_conv", *weight_grad(o[l], ds, m, 256, 256), (1, 256, 256))
+                self._wn(grads, rp + "/skip_conv", weight_grad_partials(o[l], m, 256, dst_, 256), 256, 0, (1, 256, 256))
                 d_o.append(gemm([(ds, 256, 0, 0)], t["WskipT"][l], 256, m))
             dh_next = None
             for l in range(L - 1, -1, -1):
                 rp = "%s/ResBlock_%d" % (wp, l)
                 dil = 3 ** l
                 if dh_next is not None:      # h_{l+1} = (h_l + res(o_l)) sqrt(1/2)
-                    dw, db = weight_grad(o[l], dh_next, m, 256, 256)
-                    self._wn(grads, params, rp + "/res_conv", dw * SQH, db * SQH, (1, 256, 256))
+                    self._wn(grads, rp + "/res_conv", weight_grad_partials(o[l], m, 256, transpose_shift(dh_next, m, 256), 256),
+                             256, 0, (1, 256, 256), scale=SQH)
                     d_o[l] = gemm([(dh_next, 256, 0, 0)], t["WresT"][l], 256, m, res=d_o[l], rscale=1.0 / SQH, oscale=SQH)
                 else:
                     for nm in ("kernel", "g", "bias"):      # dead res_conv of the last layer (modules.py:126-128)
                         grads["%s/res_conv/%s" % (rp, nm)] = torch.zeros(shp["%s/res_conv/%s" % (rp, nm)], dtype=torch.float32, device=dev)
                 dpre = b16(m, 512)
                 self._call("fwn_gate_bwd", d_o[l].data_ptr(), aux[l].data_ptr(), m, dpre.data_ptr(), st)
-                dw, db = weight_grad(h[l], dpre, m, 256, 512, shifts=(-dil, 0, dil), ti=ti)
-                self._wn(grads, params, rp + "/Conv_filter", dw[:, :256].contiguous(), db[:256], (3, 256, 256))
-                self._wn(grads, params, rp + "/Conv_gate", dw[:, 256:].contiguous(), db[256:], (3, 256, 256))
-                dwc, dbc = weight_grad(ca, dpre, m, cin, 512)
-                dwc_log = f32(cin, 512); dwc_log[tp.csrc64[i]] = dwc
-                self._wn(grads, params, rp + "/filter_conv_c", dwc_log[:, :256].contiguous(), dbc[:256], (1, cin, 256))
-                self._wn(grads, params, rp + "/gate_conv_c", dwc_log[:, 256:].contiguous(), dbc[256:], (1, cin, 256))
+                dpt = transpose_shift(dpre, m, 512)            # shared by the dilated and the conditioning convs
+                part = weight_grad_partials(h[l], m, 256, dpt, 512, shifts=(-dil, 0, dil), ti=ti)
+                self._wn(grads, rp + "/Conv_filter", part, 768, 0, (3, 256, 256))
+                self._wn(grads, rp + "/Conv_gate", part, 768, 256, (3, 256, 256))
+                part = weight_grad_partials(ca, m, cin, dpt, 512)
+                self._wn(grads, rp + "/filter_conv_c", part, cin, 0, (1, cin, 256), row_src=tp.cond_rows[i])
+                self._wn(grads, rp + "/gate_conv_c", part, cin, 256, (1, cin, 256), row_src=tp.cond_rows[i])
                 gemm([(dpre, 512, 0, 0)], t["WcT"][l], cin, m, out=dca, accumulate=True)
                 segs = [(dpre, 512, -(tap - 1) * dil, tap * 512) for tap in range(3)]
                 dh = gemm(segs, t["WdT"][l], 256, m, ti=ti, res=dh_next, rscale=SQH if dh_next is not None else 0.0,
@@ -492,9 +504,8 @@ class GradEngine:
                 dh_next = dh
             # front conv
             ya_bf = xa.to(torch.bfloat16)
-            dwf, dbf = weight_grad(ya_bf, dh_next, m, ch, 256, shifts=(-1, 0, 1), ti=ti)
-            dwf_log = f32(3, ch, 256); dwf_log[:, br] = dwf.view(3, ch, 256)
-            self._wn(grads, params, wp + "/Conv_front", dwf_log.view(3 * ch, 256), dbf, (3, ch, 256))
+            part = weight_grad_partials(ya_bf, m, ch, transpose_shift(dh_next, m, 256), 256, shifts=(-1, 0, 1), ti=ti)
+            self._wn(grads, wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
             segs = [(dh_next, 256, -(tap - 1), tap * 256) for tap in range(3)]
             gemm(segs, t["WfT"], ch, m, ti=ti, out=ga, accumulate=True)
             # ActNorm (both planes), back to the flow's inputs
@@ -524,7 +535,8 @@ class GradEngine:
             v = torch.as_tensor(params["upsample_%d/kernel" % n]).to(device=dev, dtype=torch.float32).reshape(2 * s_, 3).contiguous()
             g3 = torch.as_tensor(params["upsample_%d/g" % n]).to(device=dev, dtype=torch.float32).reshape(1).expand(3).contiguous()
             dv, dg3 = f32(2 * s_, 3), f32(3)
-            self._call("fwn_wn_backward", dwk.data_ptr(), v.data_ptr(), g3.data_ptr(), 2 * s_, 3, dv.data_ptr(), dg3.data_ptr(), st)
+            self._call("fwn_wn_backward", dwk.data_ptr(), 1, 0, 3, None, 0, -1, 1.0, v.data_ptr(), g3.data_ptr(), 2 * s_, 3,
+                       dv.data_ptr(), dg3.data_ptr(), None, st)
             grads["upsample_%d/kernel" % n] = dv.view(2 * s_, 3, 1, 1)
             grads["upsample_%d/g" % n] = dg3.sum().view(1)      # the three kw columns share one scalar g (convolutional.py:186)
             grads["upsample_%d/bias" % n] = dbias
@@ -532,22 +544,25 @@ class GradEngine:
         self.last_dcplanes = dcplanes
         return loss, log_p, logdet, grads
 
-    def _wn(self, grads, params, name, dw, db, shape):
-        """dW (fp32 [K][N], reference order) of a weight-normed conv -> grads of kernel, g, bias."""
+    def _wn(self, grads, name, part, k, col0, shape, scale=1.0, row_src=None):
+        """Split-K partials of a weight-gradient GEMM (fp32 [S][rows + 1][ncols], bias row last) -> gradients
+        of a weight-normed conv's kernel, g and bias (one launch, summing the partials in a fixed order)."""
         import torch
-        dev = dw.device
+        dev = part.device
         v, g = self._tp._f32(name + "/kernel"), self._tp._f32(name + "/g")
-        k, n = dw.shape
-        if self._gout is not None and self._gout[name + "/kernel"].is_contiguous():
-            dv, dg = self._gout[name + "/kernel"].view(k, n), self._gout[name + "/g"]
+        n = int(v.shape[-1])
+        go = self._gout
+        if go is not None and go[name + "/kernel"].is_contiguous():
+            dv, dg, db = go[name + "/kernel"].view(k, n), go[name + "/g"], go[name + "/bias"]
         else:
-            dv, dg = torch.empty(k, n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
-        dw = dw.contiguous()
-        self._call("fwn_wn_backward", dw.data_ptr(), v.data_ptr(), g.data_ptr(), k, n, dv.data_ptr(), dg.data_ptr(),
-                   torch.cuda.current_stream(dev).cuda_stream)
+            dv = torch.empty(k, n, dtype=torch.float32, device=dev)
+            dg, db = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+        self._call("fwn_wn_backward", part.data_ptr(), int(part.shape[0]), int(part.stride(0)), int(part.shape[2]),
+                   row_src.data_ptr() if row_src is not None else None, int(col0), int(part.shape[1]) - 1, float(scale),
+                   v.data_ptr(), g.data_ptr(), k, n, dv.data_ptr(), dg.data_ptr(), db.data_ptr(), _stream(part))
         grads[name + "/kernel"] = dv.view(shape)
         grads[name + "/g"] = dg
-        grads[name + "/bias"] = db.clone()
+        grads[name + "/bias"] = db
 
 
 class Trainer:
