@@ -90,8 +90,12 @@ def weight_grad_partials(x, m, kx, dyt, n, *, shifts=(0,), ti=0, nsplit=None):
     dshift = shifts[1] - shifts[0] if len(shifts) > 1 else 0
     xt = transpose_shift(x, m, kx, shift=shifts[0], dshift=dshift, ntap=len(shifts), ti=ti, ones_row=True, ld_dst=mp)
     if nsplit is None:
-        tiles = ((rows + 1 + 63) // 64) * ((n + 127) // 128)
-        nsplit = max(1, min(mp // 64, -(-256 // tiles)))
+        nchunks, n128 = mp // 64, (n + 127) // 128
+        t256 = ((rows + 1 + 255) // 256) * n128
+        if rows + 1 >= 512 and nchunks >= 64:      # long contraction: enough splits for the 256 x 128 tile to fill the chip
+            nsplit = max(1, min(nchunks // 8, -(-200 // t256)))
+        else:
+            nsplit = max(1, min(nchunks, -(-256 // (((rows + 1 + 63) // 64) * n128))))
     part = gemm([(xt, mp, 0, 0)], dyt, n, rows + 1, out_f32=True, nsplit=nsplit)
     return part if nsplit > 1 else part[None]
 
