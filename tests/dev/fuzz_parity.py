@@ -1,7 +1,7 @@
 """Developer fuzz (GPU box): random small configurations, forward + inverse through the model surface
-against the NumPy oracle.  usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+against the NumPy oracle.  usage: python tests/dev/fuzz_parity.py [n_cases] [seed]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import flowavenet_np as onp
 from tf_flowavenet_amd import weights as W

@@ -1,6 +1,6 @@
 """Developer diagnostic (runs on the GPU box): HIP path vs the fp64 oracle on small configs."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from tf_flowavenet_amd.hparams import default_hparams
 from tf_flowavenet_amd import weights as W

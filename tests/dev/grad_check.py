@@ -1,8 +1,8 @@
 """Developer check (GPU box): GradEngine against the autograd oracle on a tiny model; prints the
 relative error per parameter tensor."""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from conftest import small_hparams
 from oracle import grad_torch as G

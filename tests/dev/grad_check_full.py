@@ -1,7 +1,7 @@
 """Developer check (GPU box): full-size model (n_block=8, n_flow=6) gradients against the autograd
 oracle on a short clip.  Slow on the CPU side (fp64 autograd of 181 M parameters)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 torch.set_num_threads(32)
 from oracle import grad_torch as G

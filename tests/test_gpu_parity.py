@@ -428,7 +428,7 @@ def test_oversized_call_is_rejected_with_a_message(full_model):
 
 def test_random_small_configurations_match_oracle():
     """Seeded sweep over (n_block, n_flow, n_layer, up-sampling factors, num_mels, B, T, conditioning
-    mode) - the shapes nobody would write down by hand (tools/fuzz_parity.py is the open-ended version)."""
+    mode) - the shapes nobody would write down by hand (tests/dev/fuzz_parity.py is the open-ended version)."""
     rng = np.random.default_rng(2024)
     done = 0
     while done < 14:
