@@ -1,11 +1,12 @@
-"""Training side of the path - WORK IN PROGRESS.
+"""Training side of the path (train.py:35-83).
 
-What exists: thin wrappers over the generic GEMM / transpose / split-reduce primitives of
-``csrc/train_kernels.hip`` (``fwn_gemm``, ``fwn_transpose_shift``, ``fwn_reduce_splits``) from which the
-backward pass is being assembled (data gradients = GEMMs on transposed packed weights; weight
-gradients = GEMMs over transposed activation copies with K = rows, split over workgroups and summed
-in a fixed order).  The optimiser side (gradient all-reduce, clip, Adam) is ``optim.py``.
-All arithmetic runs in ``libfwn.so``; there is no fallback path.
+``GradEngine`` computes loss = -(log_p + logdet) and its gradient with respect to every trainable
+tensor of the reference, ``Trainer`` adds the data-parallel clip / Adam step of ``optim.py``.  The
+building blocks are thin wrappers over ``csrc/train_kernels.hip``: ``fwn_gemm`` (generic multi-segment
+GEMM on the LDS-DMA ring core: data gradients on transposed packed weights), ``fwn_transpose_shift`` +
+split-K ``fwn_gemm`` + ``fwn_wn_backward`` (weight gradients: K = rows, partials summed in a fixed
+order), and the element-wise ``fwn_*_bwd`` kernels.  The sequencing is Python; every activation-sized
+arithmetic step runs in ``libfwn.so`` and there is no fallback path.
 """
 from __future__ import annotations
 
