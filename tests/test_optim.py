@@ -124,3 +124,19 @@ def test_fused_clip_adam_matches_oracle_and_repacks():
     m_host = FloWaveNet(hp).load_params({k: t.cpu().numpy() for k, t in opt.master_views().items()})
     a, b = m_dev.forward(x, c), m_host.forward(x, c)
     assert float(a[0]) == float(b[0]) and float(a[1]) == float(b[1])
+
+
+def test_block_ranges_tile_the_flat_buffer_in_backward_friendly_order():
+    """The per-block all-reduce ranges of the training step: contiguous, exhaustive, one per block plus
+    the up-sampling convs, and every parameter of a block inside its range."""
+    hp = small_hparams(n_block=3, n_flow=2)
+    lay = optim.FlatLayout(hp)
+    fake = type("F", (), {"layout": lay, "block_ranges": optim.DataParallelAdam.block_ranges})()
+    rngs = fake.block_ranges()
+    assert [k for k, _, _ in rngs] == ["upsample", "Block_0", "Block_1", "Block_2"]
+    assert rngs[0][1] == 0 and rngs[-1][2] == lay.size
+    assert all(a[2] == b[1] for a, b in zip(rngs, rngs[1:]))
+    for name, (off, _, n) in lay.slots.items():
+        key = name.split("/")[0] if name.startswith("Block_") else "upsample"
+        lo, hi = next((lo, hi) for k, lo, hi in rngs if k == key)
+        assert lo <= off and off + n <= hi

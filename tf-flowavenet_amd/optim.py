@@ -104,13 +104,37 @@ class DataParallelAdam:
     def grad_views(self):
         return self.layout.views(self.g)
 
-    def step(self, loss_scale=1.0):
-        """``self.g`` holds this rank's gradient of (loss_scale * loss)."""
+    def block_ranges(self):
+        """[lo, hi) element ranges of the flat buffers: the up-sampling convs, then one per block, in
+        layout order (the backward pass finishes them last block first)."""
+        out, cur, lo = [], None, 0
+        for name, (off, _, n) in self.layout.slots.items():
+            head = name.split("/")[0]
+            key = head if head.startswith("Block_") else "upsample"
+            if key != cur:
+                if cur is not None:
+                    out.append((cur, lo, off))
+                cur, lo = key, off
+        out.append((cur, lo, self.layout.size))
+        return out
+
+    def allreduce_range(self, lo, hi):
+        """Start the all-reduce (sum) of ``g[lo:hi]`` now - called by the training step as soon as a
+        block's gradients are complete, so the exchange overlaps the rest of the backward pass."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return None
+        return dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True)
+
+    def step(self, loss_scale=1.0, works=None):
+        """``self.g`` holds this rank's gradient of (loss_scale * loss).  works: handles of all-reduces
+        already started over the whole buffer (``allreduce_range``); None: reduce everything here."""
         import torch
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
-        for w in allreduce_flat(self.g, self.group, self.bucket_elems):
-            w.wait()
+        for w in (allreduce_flat(self.g, self.group, self.bucket_elems) if works is None else works):
+            if w is not None:
+                w.wait()
         gscale = 1.0 / (world * float(loss_scale))
         st = torch.cuda.current_stream(torch.device(self.device)).cuda_stream
         n = self.w.numel()

@@ -341,20 +341,26 @@ class GradEngine:
         self.hp, self.device = hparams, device
         self.lib = _lib.load()
         self._gout = None
+        self._on_block = None
 
     # ------------------------------------------------------------------ helpers
     def _call(self, name, *args):
         _lib.check(getattr(self.lib, name)(*args), name)
 
-    def loss_and_grads(self, params, x, c, grad_out=None):
-        """grad_out: optional dict name -> fp32 tensor (e.g. views of a flat gradient buffer); the large
-        gradients (conv kernels) are then written in place and returned as those very tensors."""
+    def loss_and_grads(self, params, x, c, grad_out=None, on_block_done=None):
+        """grad_out: optional dict name -> fp32 tensor (e.g. views of a flat gradient buffer): gradients are
+        written there (the large ones in place) and returned as those very tensors.  on_block_done(i) is
+        called when every gradient of block i is in grad_out (blocks finish last to first; -1 = the
+        up-sampling convs, at the end) - the hook a data-parallel step uses to start that block's
+        all-reduce under the rest of the backward pass."""
         self._gout = grad_out
+        self._on_block = on_block_done
         try:
             return self._loss_and_grads(params, x, c)
         finally:
             _STREAMS.clear()
             self._gout = None
+            self._on_block = None
 
     def _loss_and_grads(self, params, x, c):
         import torch
@@ -524,6 +530,9 @@ class GradEngine:
                 self._call("fwn_actnorm_bwd", gg.data_ptr(), yy.data_ptr(), an[role].data_ptr(), m * ch, ch, st)
             grads[fp + "/ActNorm/b"] = g_b.view(1, 1, -1)
             grads[fp + "/ActNorm/logs"] = g_logs.view(1, 1, -1)
+            self._flush(grads, fp + "/")
+            if j == 0 and self._on_block is not None:
+                self._on_block(i)
         # up-sampling transposed convolutions (model.py:301-311), last stage first
         nmel = 2 * half
         dy = dcplanes.view(2, B, T, half).permute(1, 2, 0, 3).reshape(B, T, nmel).contiguous()
@@ -546,8 +555,21 @@ class GradEngine:
             grads["upsample_%d/g" % n] = dg3.sum().view(1)      # the three kw columns share one scalar g (convolutional.py:186)
             grads["upsample_%d/bias" % n] = dbias
             dy, y = dx, xin
+        self._flush(grads, "upsample_")
+        if self._on_block is not None:
+            self._on_block(-1)
         self.last_dcplanes = dcplanes
         return loss, log_p, logdet, grads
+
+    def _flush(self, grads, prefix):
+        """Copy the gradients under `prefix` that were not produced in place into grad_out."""
+        go = self._gout
+        if go is None:
+            return
+        for k in [k for k in grads if k.startswith(prefix)]:
+            if grads[k].data_ptr() != go[k].data_ptr():
+                go[k].copy_(grads[k].reshape(go[k].shape))
+                grads[k] = go[k]
 
     def _wn(self, grads, name, part, k, col0, shape, scale=1.0, row_src=None):
         """Split-K partials of a weight-gradient GEMM (fp32 [S][rows + 1][ncols], bias row last) -> gradients
@@ -603,9 +625,13 @@ class Trainer:
         """-> (loss, log_p, logdet, grad_norm) device scalars; the masters are updated in place."""
         params = self.opt.master_views()
         gv = self.opt.grad_views()
-        loss, log_p, logdet, grads = self.engine.loss_and_grads(params, x, c, grad_out=gv)
-        for k, g in grads.items():
-            if g.data_ptr() != gv[k].data_ptr():
-                gv[k].copy_(g.reshape(gv[k].shape))
-        gnorm = self.opt.step()
+        ranges = {("upsample" if key == "upsample" else int(key.split("_")[1])): (lo, hi) for key, lo, hi in self.opt.block_ranges()}
+        works = []
+
+        def block_done(i):      # block i's gradients are final: its all-reduce runs under the remaining backward
+            lo, hi = ranges["upsample" if i < 0 else i]
+            works.append(self.opt.allreduce_range(lo, hi))
+
+        loss, log_p, logdet, grads = self.engine.loss_and_grads(params, x, c, grad_out=gv, on_block_done=block_done)
+        gnorm = self.opt.step(works=works)
         return loss, log_p, logdet, gnorm
