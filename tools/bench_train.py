@@ -25,9 +25,12 @@ def main():
     from tf_flowavenet_amd import weights as W
     from tf_flowavenet_amd.training import Trainer
     world, rank = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0))
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    # FWN_BENCH_SHARE_GPU=1: plumbing check on a one-GPU box (every rank on cuda:0, exchanges over gloo)
+    share = os.environ.get("FWN_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share else int(os.environ.get("LOCAL_RANK", 0)))
     if world > 1:
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if share else "nccl")
     hp = default_hparams()
     inp = W.synthetic_inputs(hp, a.batch, a.samples)
     x = torch.from_numpy(np.roll(inp["x"], 997 * rank, axis=1)).reshape(a.batch, a.samples).cuda()
