@@ -248,6 +248,12 @@ int fwn_gemm(const fwn_gemm_desc* g, void* stream) {
         REQUIRE((int64_t)sg.rows * sg.ld * 2 < ((int64_t)1 << 31), "fwn_gemm: segment %d exceeds 2 GiB", s);
     }
     REQUIRE((int64_t)g->N * g->ldw * 2 < ((int64_t)1 << 31), "fwn_gemm: W exceeds 2 GiB");
+    REQUIRE((int64_t)g->M * g->ldy * (g->out_f32 ? 4 : 2) < ((int64_t)1 << 31) &&
+                (!g->R || (int64_t)g->M * g->ldr * 2 < ((int64_t)1 << 31)) &&
+                (!g->mask || (int64_t)g->M * g->ldmask * 2 < ((int64_t)1 << 31)),
+            "fwn_gemm: output / residual / mask exceed 2 GiB (32-bit buffer offsets)");
+    REQUIRE(!g->R || g->ldr >= g->N, "fwn_gemm: ldr < N");
+    REQUIRE(!g->mask || g->ldmask >= g->N, "fwn_gemm: ldmask < N");
     REQUIRE(g->nsplit >= 1 && g->nsplit <= 1024, "fwn_gemm: nsplit=%d", g->nsplit);
     REQUIRE(g->nsplit == 1 || (g->out_f32 && !g->bias && !g->R && !g->mask && !g->relu && !g->accumulate),
             "fwn_gemm: split-K writes plain fp32 partials");

@@ -47,30 +47,44 @@ struct LinProb {
     __device__ float acc_init(int) const { return 0.0f; }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
+        // Branch-free: rows past M and columns past N get an out-of-range buffer offset (loads read 0,
+        // stores are dropped), so the residual / mask / accumulate loads of a tile issue back to back
+        // instead of one dependent load per element.
         const int lr = lane & 31;
+        const int rbase = mrow0 + 4 * (lane >> 5);
+        const srd_t sR = make_srd(g.R ? g.R : g.W, g.R ? (uint32_t)((size_t)g.M * g.ldr * 2) : 0u);
+        const srd_t sM = make_srd(g.mask ? g.mask : g.W, g.mask ? (uint32_t)((size_t)g.M * g.ldmask * 2) : 0u);
+        const uint32_t ybytes = (uint32_t)((size_t)g.M * g.ldy * (g.out_f32 ? 4 : 2));
+        const srd_t sY = make_srd(g.out_f32 ? (const void*)y32 : (const void*)g.Y, ybytes);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = ncol0 + ni * 32 + lr;
-            if (col >= g.N) continue;
-            const float b = g.bias ? g.bias[col] : 0.0f;
+            const bool cok = col < g.N;
+            const float b = (g.bias && cok) ? g.bias[col] : 0.0f;
+            const uint32_t vR = cok ? (uint32_t)(rbase * g.ldr + col) * 2u : FWN_OOB;
+            const uint32_t vM = cok ? (uint32_t)(rbase * g.ldmask + col) * 2u : FWN_OOB;
+            const uint32_t vY = cok ? (uint32_t)(rbase * g.ldy + col) * (g.out_f32 ? 4u : 2u) : FWN_OOB;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+                float rv[16], mv[16], yv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = mrow0 + mi * 32 + acc_row_c(r) + 4 * (lane >> 5);
-                    if (row >= g.M) continue;
-                    float v = acc[mi][ni][r] + b;
-                    if (g.R) v += g.rscale * (float)((const bf16*)g.R)[(size_t)row * g.ldr + col];
-                    if (g.mask && !((float)((const bf16*)g.mask)[(size_t)row * g.ldmask + col] > 0.0f)) v = 0.0f;
-                    if (g.relu) v = fmaxf(v, 0.0f);
-                    v *= g.oscale;
-                    if (g.out_f32) {
-                        float* dst = y32 + (size_t)row * g.ldy + col;
-                        *dst = g.accumulate ? *dst + v : v;
-                    } else {
-                        ((bf16*)g.Y)[(size_t)row * g.ldy + col] = (bf16)v;
-                    }
+                    const int ro = mi * 32 + acc_row_c(r);
+                    rv[r] = g.R ? buf_load_bf16(sR, vR, (uint32_t)(ro * g.ldr * 2)) : 0.0f;
+                    mv[r] = g.mask ? buf_load_bf16(sM, vM, (uint32_t)(ro * g.ldmask * 2)) : 1.0f;
+                    yv[r] = (g.out_f32 && g.accumulate) ? buf_load_f32(sY, vY, (uint32_t)(ro * g.ldy * 4)) : 0.0f;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = mi * 32 + acc_row_c(r);
+                    float v = acc[mi][ni][r] + b + g.rscale * rv[r];
+                    v = mv[r] > 0.0f ? v : 0.0f;
+                    if (g.relu) v = fmaxf(v, 0.0f);
+                    v = v * g.oscale + yv[r];
+                    if (g.out_f32) buf_store_f32(sY, vY, (uint32_t)(ro * g.ldy * 4), v);
+                    else buf_store_bf16(sY, vY, (uint32_t)(ro * g.ldy * 2), v);
+                }
+            }
         }
     }
 };
