@@ -93,3 +93,24 @@ def test_plain_c_program_runs_kernels_on_the_gpu(lib, tmp_path):
     out = subprocess.run([exe, _lib.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "GPU round trip ok" in out.stdout
+
+
+def test_training_primitives_validate_their_arguments(lib):
+    """No launch happens for bad descriptors: error code + message (CPU-only check)."""
+    g = _lib.GemmDesc()
+    assert lib.fwn_gemm(C.byref(g), None) == -1 and b"fwn_gemm" in lib.fwn_last_error()
+    g.W, g.Y, g.nseg, g.M, g.N, g.ldw, g.ldy, g.nsplit = 1 << 20, 1 << 21, 1, 64, 64, 64, 64, 1
+    g.seg[0].x, g.seg[0].rows, g.seg[0].ld, g.seg[0].k, g.seg[0].koff = 1 << 22, 64, 64, 60, 0       # k not a multiple of 8
+    assert lib.fwn_gemm(C.byref(g), None) == -1 and b"multiples of 8" in lib.fwn_last_error()
+    g.seg[0].k = 64
+    g.nsplit = 4                                                                                     # split-K needs an fp32 output
+    assert lib.fwn_gemm(C.byref(g), None) == -1 and b"split-K" in lib.fwn_last_error()
+    assert lib.fwn_transpose_shift(None, 4, 4, 4, 0, 0, 1, 0, None, 64, 0, None) == -1
+    assert lib.fwn_reduce_splits(None, 2, 16, 16, 1.0, None, None) == -1
+    assert lib.fwn_coupling_bwd(None, None, None, None, 4, 1, 0.0, None, 8, None, None) == -1
+    assert lib.fwn_wn_backward(None, 1, 0, 4, None, 0, -1, 1.0, None, None, 4, 4, None, None, None, None) == -1
+    assert lib.fwn_upsample_bwd(1 << 20, 1 << 20, 1 << 20, 1, 4, 8, 3, 1 << 20, None, 1 << 20, 1 << 20, None) == -1   # odd s
+    assert lib.fwn_mel_spectrogram(1 << 20, 1, 4096, 1 << 20, 1 << 20, 1000, 256, 80, 20.0, -100.0, 1 << 20, None) == -1
+    assert b"power of two" in lib.fwn_last_error()
+    assert lib.fwn_pack_jobs(None, 1, None, 0, None, 512, None) == -1
+    assert lib.fwn_colsum_partials(1000, 8) > 0 and lib.fwn_upsample_bwd_partials(8, 25, 16) > 0
