@@ -9,7 +9,8 @@ Same flags as the reference (``--base_dir --input --restore --summary_interval -
 ``preprocessing.preprocess``: ``train.txt`` with ``audios/*.npy`` and ``mels/*.npy`` beside it.
 
 Differences (deliberate): the TFRecord round trip (tfrecord.py, dataset.py:20-44) is skipped - the
-``.npy`` files are read directly and cropped like ``Dataset._load_sample`` (dataset.py:70-76); the
+``.npy`` files are read directly and cropped like ``Dataset._load_sample`` (dataset.py:70-76)
+(``--input training_data/train.tfrecord`` reads the reference's TFRecords instead, ``tfrecord.py``); the
 train / test split is the reference's ``train_test_split(test_size, random_state)`` (tfrecord.py:81-82);
 summaries are JSON lines (``<log_dir>/train/summary.jsonl``, ``test/summary.jsonl``) and evaluation
 audio is written as wav files instead of TensorBoard events; checkpoints are ``.npz`` files that
@@ -50,6 +51,33 @@ class Dataset:
         base = hparams.shuffle_random_seed if seed is None else seed
         self._rng = np.random.RandomState(base + 7919 * rank)
         self._cache = {}
+
+    @classmethod
+    def from_tfrecords(cls, train_path, test_path, hparams, seed=None, rank=0):
+        """The reference's own data files (tfrecord.py:76-88): ``train.tfrecord`` / ``test.tfrecord``."""
+        from . import tfrecord
+        self = cls.__new__(cls)
+        self._hp, self._basedir = hparams, os.path.dirname(train_path)
+        self._frames = hparams.max_time_steps // hparams.hop_size
+        self._steps = self._frames * hparams.hop_size
+        self._cache = {}
+
+        def load(path, tag):
+            metas = []
+            for k, (audio, mel, spk) in enumerate(tfrecord.read_samples(path)):
+                if mel.shape[0] > self._frames:
+                    key = "%s-%d" % (tag, k)
+                    self._cache[key] = (audio, mel)
+                    metas.append([key, key, str(len(audio)), str(spk), ""])
+            return metas
+
+        self.train_meta = load(train_path, "train")
+        self.test_meta = load(test_path, "test") if test_path and os.path.exists(test_path) else self.train_meta
+        if not self.train_meta:
+            raise ValueError("no utterance longer than max_time_steps=%d in %s" % (hparams.max_time_steps, train_path))
+        base = hparams.shuffle_random_seed if seed is None else seed
+        self._rng = np.random.RandomState(base + 7919 * rank)
+        return self
 
     def _load(self, m):
         if m[0] not in self._cache:
@@ -135,7 +163,11 @@ def train(log_dir, args, hparams, input_path, device="cuda", params=None):
         print("Checkpoint_path: {}".format(checkpoint_path))
         print("Loading training data from: {}".format(metadata_filename))
     seed = getattr(args, "seed", None)
-    dataset = Dataset(metadata_filename, hparams, seed=seed, rank=rank)
+    if metadata_filename.endswith(".tfrecord"):       # the reference's own files (train.py:161-162)
+        dataset = Dataset.from_tfrecords(metadata_filename, os.path.join(os.path.dirname(metadata_filename), "test.tfrecord"),
+                                         hparams, seed=seed, rank=rank)
+    else:
+        dataset = Dataset(metadata_filename, hparams, seed=seed, rank=rank)
     if params is None:     # the reference's initialisers: he-uniform convs, g = 1, ZeroConv1d all zeros (modules.py:21-22,47-49)
         params = weights.synthetic_params(hparams, hparams.tf_random_seed if seed is None else seed, zero_conv="zeros")
     trainer = Trainer(hparams, params, device=device)
