@@ -233,3 +233,17 @@ def test_wav_writer_and_checkpoint_loader(tmp_path):
         S.load_checkpoint(str(tmp_path))
     np.savez(tmp_path / "m.npz", a=np.arange(3))
     assert list(S.load_checkpoint(str(tmp_path))) == ["a"]
+
+
+def test_reference_variable_names_map_onto_parameter_names():
+    from tf_flowavenet_amd.weights import from_reference_names, param_shapes, synthetic_params
+    hp = small_hparams()
+    p = synthetic_params(hp, 3)
+    dumped = {"vocoder/FloWaveNet/%s:0" % k: v for k, v in p.items()}
+    dumped["vocoder/FloWaveNet/Block_0/Flow_0/ActNorm/b/Adam:0"] = np.zeros(1)
+    dumped["vocoder/FloWaveNet/Block_0/Flow_0/ActNorm/b/Adam_1:0"] = np.zeros(1)
+    dumped["global_step:0"] = np.zeros(())
+    dumped["beta1_power:0"] = np.zeros(())
+    dumped["vocoder/FloWaveNet/Block_0/Flow_0/WaveNet/Conv_front/kernel/fp16_cast:0"] = np.zeros(1)
+    got = from_reference_names(dumped)
+    assert sorted(got) == sorted(param_shapes(hp)) and all(got[k] is p[k] for k in p)

@@ -4,8 +4,9 @@
 
 ``mels_dir/*.npy`` float32 [F, num_mels] in [0,1]  ->  ``output_dir/<name>.wav`` (16-bit mono PCM at
 ``hparams.sample_rate``).  Differences: the checkpoint is this package's own format (``*.npz`` /
-``*.safetensors`` holding the parameter names of ``weights.param_shapes``; TF checkpoints are out of
-scope), the wav writer is the stdlib ``wave`` module (librosa is not a dependency), ``z`` is
+``*.safetensors`` holding the parameter names of ``weights.param_shapes``, or the reference's own variable
+names ``vocoder/FloWaveNet/...:0`` as dumped from a TF checkpoint - ``weights.from_reference_names``; the TF
+tensor-bundle format itself is out of scope), the wav writer is the stdlib ``wave`` module (librosa is not a dependency), ``z`` is
 seedable (``--seed``; TF's Philox stream cannot be reproduced), and mels of equal length are
 batched into one launch.
 """
@@ -27,11 +28,12 @@ def load_checkpoint(saved_dir):
         raise FileNotFoundError("no *.npz / *.safetensors checkpoint in %r" % saved_dir)
     path = files[-1]
     print("Loading checkpoint {}".format(path))
+    from .weights import from_reference_names
     if path.endswith(".npz"):
         with np.load(path) as f:
-            return {k: f[k] for k in f.files}
+            return from_reference_names({k: f[k] for k in f.files})
     from safetensors.numpy import load_file
-    return load_file(path)
+    return from_reference_names(load_file(path))
 
 
 def write_wav(path, audio, sample_rate):

@@ -25,6 +25,25 @@ def flow_prefix(i: int, j: int) -> str:
     return "Block_%d/Flow_%d" % (i, j)
 
 
+def from_reference_names(variables: dict) -> dict:
+    """Variables dumped from one of the reference's TF checkpoints (``vocoder/FloWaveNet/<scope>/<var>[:0]``,
+    train.py:53 + model.py:283) -> this package's parameter names.  Optimiser slots (``.../Adam``,
+    ``.../Adam_1``, ``beta*_power``), ``global_step`` and the cached low-precision casts of
+    ``fp16_dtype_getter`` (utils.py:19-29) are dropped; names without the prefix pass through."""
+    out = {}
+    for name, value in variables.items():
+        n = name[:-2] if name.endswith(":0") else name
+        leaf = n.rsplit("/", 1)[-1]
+        if leaf in ("Adam", "Adam_1", "global_step") or leaf.startswith("beta") or "fp16_cast" in n or n.startswith("__opt/"):
+            continue
+        for prefix in ("vocoder/FloWaveNet/", "FloWaveNet/"):
+            if n.startswith(prefix):
+                n = n[len(prefix):]
+                break
+        out[n] = value
+    return out
+
+
 def param_shapes(hp) -> "OrderedDict[str, tuple]":
     """name -> shape in the reference's TF layouts (kernel = (k, C_in, C_out))."""
     s = OrderedDict()
