@@ -233,6 +233,15 @@ int fwn_upsample_bwd_partials(int B, int H, int s);
 int fwn_upsample_bwd(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
                      float* dx, float* dwk_bias, float* partial, void* stream);
 
+/* Weight-gradient GEMM without transposed copies: part[z][tap*Kx + i][j] = sum over the z-th share of the
+ * rows m of X[m + shift0 + tap*dshift][i] * dY[m][j]  (bf16 X [M][ldx], dY [M][ldy]; taps that leave their clip of
+ * Ti rows contribute zero; Ti == 0: matrix bounds only), fp32 partials [nsplit][ntap*Kx (+1)][N] for fwn_wn_backward /
+ * fwn_reduce_splits; bias_row != 0 appends the column sums of dY (the bias gradient) as row ntap*Kx.  The operands are read transposed out of LDS (ds_read_b64_tr_b16).
+ * fwn_colsum_bf16: out[c] = scale * sum_m dY[m][c] (bias gradients), scratch fwn_colsum_partials(M, C) floats. */
+int fwn_tn_gemm(const void* x, int ldx, int Kx, int ntap, int shift0, int dshift, const void* dy, int ldy, int N, int M,
+                int Ti, int nsplit, float* part, int64_t split_stride, int bias_row, void* stream);
+int fwn_colsum_bf16(const void* dy, int64_t M, int C, int ld, float scale, float* partial, float* out, void* stream);
+
 /* ---- whole model (replaces FloWaveNet.forward / .reverse, model.py:317-396) ---- */
 typedef struct fwn_model_desc {
     int32_t n_block, n_flow, n_layer, num_mels;

@@ -273,3 +273,23 @@ def test_recorded_packing_matches_immediate_packing():
             assert torch.equal(g_d[k].reshape(-1), g_n[k].reshape(-1)), k
         for k, v in pd.items():          # "an optimiser step": every parameter moves, in place
             v.mul_(1.01)
+
+
+@pytest.mark.parametrize("m,ti,kx,n,shifts", [(333, 111, 256, 512, (0,)), (6000, 1000, 256, 512, (-1, 0, 1)),
+                                              (25600, 3200, 256, 256, (-3, 0, 3)), (200, 25, 80, 512, (0,)), (4000, 500, 640, 512, (0,))])
+def test_tn_gemm_reads_operands_transposed_from_lds(m, ti, kx, n, shifts):
+    """fwn_tn_gemm (ds_read_b64_tr_b16 operands, no transposed copies) against fp64, ragged M / Kx, taps with
+    clip edges, and the bias column sums."""
+    rng = np.random.default_rng(m + kx)
+    x, dy = bf(rng.standard_normal((m, kx)) * 0.5), bf(rng.standard_normal((m, n)) * 0.1)
+    part = TR.tn_weight_grad_partials(x, dy, m, kx, n, shifts=shifts, ti=ti)
+    part2 = TR.tn_weight_grad_partials(x, dy, m, kx, n, shifts=shifts, ti=ti)
+    assert torch.equal(part, part2)
+    full = TR.reduce_splits(part).cpu().numpy() if part.shape[0] > 1 else part[0].cpu().numpy()
+    got, got_b = full[:-1], full[-1]
+    xw, dyw = f64(x), f64(dy)
+    want = np.concatenate([shifted(xw, sh, ti).T @ dyw for sh in shifts])
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-3 * np.abs(want).max()
+    np.testing.assert_allclose(got_b, dyw.sum(0), atol=2e-3 * np.abs(dyw.sum(0)).max())     # the bias row
+    np.testing.assert_allclose(TR.colsum_bf16(dy, m, n, scale=0.5).cpu().numpy(), 0.5 * dyw.sum(0), atol=2e-3 * np.abs(dyw.sum(0)).max())

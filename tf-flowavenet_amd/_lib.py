@@ -98,6 +98,8 @@ SIGNATURES = {
                                C.c_int, vp]),
     "fwn_prior_logp": (C.c_int, [vp, i64, vp, C.c_int, vp, vp]),
     "fwn_pack_jobs": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),
+    "fwn_tn_gemm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
+    "fwn_colsum_bf16": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
     "fwn_gemm": (C.c_int, [C.POINTER(GemmDesc), vp]),
     "fwn_upsample_bwd_partials": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "fwn_upsample_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),

@@ -328,6 +328,24 @@ int fwn_upsample_bwd(float* dy, const float* y, const float* x, int B, int H, in
     return check_launch("fwn_upsample_bwd");
 }
 
+int fwn_tn_gemm(const void* x, int ldx, int Kx, int ntap, int shift0, int dshift, const void* dy, int ldy, int N, int M,
+                int Ti, int nsplit, float* part, int64_t split_stride, int bias_row, void* stream) {
+    REQUIRE(x && dy && part && M > 0 && Kx > 0 && N > 0 && ntap >= 1 && nsplit >= 1 && Ti >= 0, "fwn_tn_gemm: bad argument");
+    REQUIRE(ldx >= Kx && ldy >= N && ldx % 8 == 0 && ldy % 8 == 0 && Kx % 8 == 0 && N % 8 == 0 && ALIGNED16(x) && ALIGNED16(dy),
+            "fwn_tn_gemm: rows must be 16-byte aligned and Kx, N multiples of 8");
+    REQUIRE((int64_t)M * ldx * 2 < ((int64_t)1 << 31) && (int64_t)M * ldy * 2 < ((int64_t)1 << 31) &&
+                (int64_t)ntap * Kx * N * 4 < ((int64_t)1 << 31), "fwn_tn_gemm: operand exceeds 2 GiB");
+    REQUIRE(nsplit == 1 || split_stride >= ((int64_t)ntap * Kx + (bias_row ? 1 : 0)) * N, "fwn_tn_gemm: split_stride too small");
+    fwn_tn_gemm_launch(x, ldx, Kx, ntap, shift0, dshift, dy, ldy, N, M, Ti, nsplit, part, (long)split_stride, bias_row,
+                       (hipStream_t)stream);
+    return check_launch("fwn_tn_gemm");
+}
+int fwn_colsum_bf16(const void* dy, int64_t M, int C_, int ld, float scale, float* partial, float* out, void* stream) {
+    REQUIRE(dy && partial && out && M > 0 && C_ > 0 && ld >= C_, "fwn_colsum_bf16: bad argument");
+    fwn_colsum_bf16_launch(dy, (long)M, C_, ld, scale, partial, out, (hipStream_t)stream);
+    return check_launch("fwn_colsum_bf16");
+}
+
 // ---- data-parallel optimiser step -------------------------------------------------------------
 int fwn_grad_norm_partials(int64_t n) { return fwn_sqnorm_blocks((long)n); }
 

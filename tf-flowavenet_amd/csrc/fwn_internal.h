@@ -63,3 +63,6 @@ struct fwn_scale_job;
 struct fwn_pack_job;
 void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack_job* jobs, int njobs, float* scales,
                           int scale_ld, hipStream_t st);
+void fwn_tn_gemm_launch(const void* x, int ldx, int Kx, int ntap, int shift0, int dshift, const void* dy, int ldy, int N,
+                        int M, int Ti, int nsplit, float* part, long split_stride, int bias_row, hipStream_t st);
+void fwn_colsum_bf16_launch(const void* dy, long M, int C, int ld, float scale, float* partial, float* out, hipStream_t st);

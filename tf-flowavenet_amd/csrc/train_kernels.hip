@@ -426,3 +426,166 @@ void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, 
     hipLaunchKernelGGL(up_dw_kernel, dim3(6 * s + 1, nc), dim3(256), 0, st, dy, x, B, H, W, s, partial);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((6 * s + 1 + 255) / 256), dim3(256), 0, st, partial, nc, 6 * s + 1, 1.0f, dwk_bias);
 }
+
+// ---------------------------------------------------------------------------------------------
+// TN GEMM for weight gradients: dW[tap*Kx + i][j] = sum_m X[m + shift_tap][i] * dY[m][j], both operands
+// read as they lie in memory (rows = m) - no transposed copies.  The contraction index is the ROW of
+// both LDS tiles, so the MFMA fragments come from ds_read_b64_tr_b16 (4 rows x 16 columns delivered
+// column-major): lane i of a 16-lane group receives column i of 4 consecutive rows; two such reads
+// give the 8 consecutive k of a v_mfma_f32_32x32x16_bf16 operand.  Tile 128 (i) x 128 (j), 4 waves
+// (wave tile 64 x 64), chunks of 64 rows through a 3-slot LDS-DMA ring; LDS image (b) of the
+// programming guide (256-byte rows, chunk XOR ((row&3)<<2 | (row>>2)&3)) - conflict-free for the
+// transposed reads.  blockIdx.z = split of the row range; partials fp32 [S][R][N] for fwn_wn_backward.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+struct TnArgs {
+    const bf16* x;   int ldx, Kx, ntap, shift0, dshift;
+    const bf16* dy;  int ldy, N;
+    int M, Ti, nsplit;
+    float* part;     long split_stride;      // [S][ntap*Kx (+1)][N]
+    int bias_row;                            // != 0: row ntap*Kx of every partial = column sums of dY (bias gradient)
+};
+__device__ __forceinline__ int tn_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
+    constexpr int D = 3, TILE = 64 * 256, SLOT = 2 * TILE;       // X tile + dY tile, 16 KB each
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int kxt = (a.Kx + 127) / 128;                            // row tiles per tap
+    const int tap = blockIdx.x / kxt, kx0 = (blockIdx.x % kxt) * 128, n0 = blockIdx.y * 128;
+    const int shift = a.shift0 + tap * a.dshift;
+    const int nchunk_all = (a.M + 63) / 64, per = (nchunk_all + a.nsplit - 1) / a.nsplit;
+    const int c0 = blockIdx.z * per, nq = max(0, min(per, nchunk_all - c0));
+    // DMA: a 1 KB piece = 4 rows x 256 B; wave w issues pieces w, w+4, .. (16 per tile)
+    const int prow = lane >> 4, pch = lane & 15;
+    const srd_t sx = make_srd(a.x, (uint32_t)((size_t)a.M * a.ldx * 2)), sy = make_srd(a.dy, (uint32_t)((size_t)a.M * a.ldy * 2));
+    auto issue = [&](int q) {
+        unsigned char* base = lds + (q % D) * SLOT;
+        const int m0 = (c0 + q) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 4 * (wave + 4 * j) + prow;               // tile row 0..63
+            const int ch = pch ^ (((row & 3) << 2) | ((row >> 2) & 3));   // source chunk for this lane's linear slot
+            const int m = m0 + row;
+            const int t = a.Ti > 0 ? m % a.Ti : m;
+            const bool okx = m < a.M && (unsigned)(t + shift) < (unsigned)(a.Ti > 0 ? a.Ti : a.M) && kx0 + ch * 8 < a.Kx;
+            buf_load16_lds(sx, okx ? (uint32_t)((m + shift) * a.ldx + kx0 + ch * 8) * 2u : FWN_OOB, base + (wave + 4 * j) * 1024);
+            const bool oky = m < a.M && n0 + ch * 8 < a.N;
+            buf_load16_lds(sy, oky ? (uint32_t)(m * a.ldy + n0 + ch * 8) * 2u : FWN_OOB, base + TILE + (wave + 4 * j) * 1024);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // bias gradient = column sums of dY: one more MFMA per k-step against an all-ones operand, in the
+    // first row tile's wi == 0 waves only
+    const bool do_bias = a.bias_row && blockIdx.x == 0 && wi == 0;
+    f32x16 accb[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[j][r] = 0.0f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    // transposed-read addresses: group g = lane>>4 = (khalf, chalf); lane 4q+p of a group supplies row q,
+    // 8-byte half (p&1) of chunk c0 + (p>>1)
+    const int kh = lane >> 5, chalf = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    auto tr_addr = [&](int rbase, int cblk) {      // rows rbase + q4, columns 16*cblk ..: chunks 2*cblk + (p4>>1)
+        return tn_off(rbase + q4, 2 * cblk + (p4 >> 1)) + 8 * (p4 & 1);
+    };
+    for (int q = 0; q < D - 1; ++q)
+        if (q < nq) issue(q);
+    for (int q = 0; q < nq; ++q) {
+        const int pending = min(nq, q + D - 1) - (q + 1);
+        if (pending >= 1) FWN_WAIT_VMCNT(8); else FWN_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+        if (q + D - 1 < nq) issue(q + D - 1);
+        const unsigned char* xa = lds + (q % D) * SLOT;
+        const unsigned char* ya = xa + TILE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                 // k-steps of 16 rows
+            const int rb = 16 * s + 8 * kh;
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {          // operand columns: 32*(2*wi + ib) + 16*chalf + lane-in-group
+                const int cb = 2 * (2 * wi + ib) + chalf;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xa + tr_addr(rb, cb)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xa + tr_addr(rb + 4, cb)));
+                const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                af[ib] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                const int cb = 2 * (2 * wj + jb) + chalf;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ya + tr_addr(rb, cb)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ya + tr_addr(rb + 4, cb)));
+                const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[jb] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = mfma32(af[ib], bfr[jb], acc[ib][jb]);
+            if (do_bias) {
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) accb[jb] = mfma32(ones, bfr[jb], accb[jb]);
+            }
+        }
+    }
+    // C layout: col = lane & 31 (j), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (i)
+    float* out = a.part + (size_t)blockIdx.z * a.split_stride;
+    const int R = a.ntap * a.Kx;
+    const uint32_t obytes = (uint32_t)((size_t)(R + (a.bias_row ? 1 : 0)) * a.N * 4);
+    const srd_t so = make_srd(out, obytes);
+    if (do_bias && lane < 32) {        // every row of accb holds the column sums: row 0 = register 0 of lanes 0..31
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int col = n0 + 64 * wj + 32 * jb + lane;
+            buf_store_f32(so, col < a.N ? (uint32_t)(R * a.N + col) * 4u : FWN_OOB, 0, accb[jb][0]);
+        }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int col = n0 + 64 * wj + 32 * jb + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kx = kx0 + 64 * wi + 32 * ib + acc_row(r, lane);
+                const bool ok = kx < a.Kx && col < a.N;
+                buf_store_f32(so, ok ? (uint32_t)((tap * a.Kx + kx) * a.N + col) * 4u : FWN_OOB, 0, acc[ib][jb][r]);
+            }
+        }
+}
+// column sums of a bf16 matrix (bias gradients): out[c] = scale * sum_m dy[m][c]; two fixed-order passes
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ dy, long M, int C, int ld,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const long per = (M + gridDim.y - 1) / gridDim.y;
+    const long m0 = (long)blockIdx.y * per, m1 = min(M, m0 + per);
+    float acc = 0.0f;
+    if (c < C)
+        for (long m = m0 + part; m < m1; m += 4) acc += (float)dy[m * ld + c];
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && c < C)
+        partial[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+void fwn_tn_gemm_launch(const void* x, int ldx, int Kx, int ntap, int shift0, int dshift, const void* dy, int ldy, int N,
+                        int M, int Ti, int nsplit, float* part, long split_stride, int bias_row, hipStream_t st) {
+    TnArgs a{(const bf16*)x, ldx, Kx, ntap, shift0, dshift, (const bf16*)dy, ldy, N, M, Ti, nsplit, part, split_stride, bias_row};
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3(ntap * ((Kx + 127) / 128), (N + 127) / 128, nsplit), dim3(256), 0, st, a);
+}
+void fwn_colsum_bf16_launch(const void* dy, long M, int C, int ld, float scale, float* partial, float* out, hipStream_t st) {
+    const int nb = fwn_colsum_blocks(M, C);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((C + 63) / 64, nb), dim3(256), 0, st, (const bf16*)dy, M, C, ld, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nb, C, scale, out);
+}

@@ -101,6 +101,35 @@ def weight_grad_partials(x, m, kx, dyt, n, *, shifts=(0,), ti=0, nsplit=None):
     return part if nsplit > 1 else part[None]
 
 
+def tn_weight_grad_partials(x, dy, m, kx, n, *, shifts=(0,), ti=0, nsplit=None, bias_row=True):
+    """The same partials (bias row = column sums of dy, last) straight from x and dy as they lie in memory
+    (``fwn_tn_gemm``: operands read transposed out of LDS): fp32 ``[S, len(shifts)*kx (+ 1), n]``.
+    Needs 16-byte aligned rows: kx, n and both row strides multiples of 8."""
+    import torch
+    lib = _lib.load()
+    rows = len(shifts) * kx
+    dshift = shifts[1] - shifts[0] if len(shifts) > 1 else 0
+    if nsplit is None:
+        tiles = len(shifts) * ((kx + 127) // 128) * ((n + 127) // 128)
+        nsplit = max(1, min((m + 63) // 64 // 4 or 1, -(-256 // tiles)))
+    part = torch.empty(nsplit, rows + (1 if bias_row else 0), n, dtype=torch.float32, device=x.device)
+    _lib.check(lib.fwn_tn_gemm(x.data_ptr(), int(x.stride(0)), int(kx), len(shifts), int(shifts[0]), int(dshift),
+                               dy.data_ptr(), int(dy.stride(0)), int(n), int(m), int(ti), int(nsplit), part.data_ptr(),
+                               int(part.stride(0)), int(bool(bias_row)), _stream(x)), "fwn_tn_gemm")
+    return part
+
+
+def colsum_bf16(dy, m, n, scale=1.0, out=None):
+    """``out[j] = scale * sum_r dy[r, j]`` (bias gradient), fp32 [n], fixed summation order."""
+    import torch
+    lib = _lib.load()
+    out = torch.empty(n, dtype=torch.float32, device=dy.device) if out is None else out
+    scr = torch.empty(lib.fwn_colsum_partials(m, n), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.fwn_colsum_bf16(dy.data_ptr(), int(m), int(n), int(dy.stride(0)), float(scale), scr.data_ptr(),
+                                   out.data_ptr(), _stream(dy)), "fwn_colsum_bf16")
+    return out
+
+
 def weight_grad(x, dy, m, kx, n, *, shifts=(0,), ti=0, nsplit=None):
     """``(dW [len(shifts)*kx, n], db [n])`` fp32: the partials of ``weight_grad_partials`` summed in a fixed order."""
     dyt = transpose_shift(dy, m, n)
@@ -480,32 +509,30 @@ class GradEngine:
             grads[wp + "/ZeroConv1d/kernel"] = g_wz.view(1, 256, 2 * ch)
             grads[wp + "/ZeroConv1d/bias"] = g_bz
             du = gemm([(dz, ldz, 0, 0)], t["WzT"], 256, m, mask=u_act)
-            self._wn(grads, wp + "/Conv_final", weight_grad_partials(s_act, m, 256, transpose_shift(du, m, 256), 256), 256, 0, (1, 256, 256))
+            self._wn(grads, wp + "/Conv_final", tn_weight_grad_partials(s_act, du, m, 256, 256), 256, 0, (1, 256, 256))
             ds = gemm([(du, 256, 0, 0)], t["WfinT"], 256, m, mask=s_act)
-            dst_ = transpose_shift(ds, m, 256)                 # shared by the L skip convs
             d_o = []
             for l in range(L):
                 rp = "%s/ResBlock_%d" % (wp, l)
-                self._wn(grads, rp + "/skip_conv", weight_grad_partials(o[l], m, 256, dst_, 256), 256, 0, (1, 256, 256))
+                self._wn(grads, rp + "/skip_conv", tn_weight_grad_partials(o[l], ds, m, 256, 256), 256, 0, (1, 256, 256))
                 d_o.append(gemm([(ds, 256, 0, 0)], t["WskipT"][l], 256, m))
             dh_next = None
             for l in range(L - 1, -1, -1):
                 rp = "%s/ResBlock_%d" % (wp, l)
                 dil = 3 ** l
                 if dh_next is not None:      # h_{l+1} = (h_l + res(o_l)) sqrt(1/2)
-                    self._wn(grads, rp + "/res_conv", weight_grad_partials(o[l], m, 256, transpose_shift(dh_next, m, 256), 256),
-                             256, 0, (1, 256, 256), scale=SQH)
+                    self._wn(grads, rp + "/res_conv", tn_weight_grad_partials(o[l], dh_next, m, 256, 256), 256, 0, (1, 256, 256),
+                             scale=SQH)
                     d_o[l] = gemm([(dh_next, 256, 0, 0)], t["WresT"][l], 256, m, res=d_o[l], rscale=1.0 / SQH, oscale=SQH)
                 else:
                     for nm in ("kernel", "g", "bias"):      # dead res_conv of the last layer (modules.py:126-128)
                         grads["%s/res_conv/%s" % (rp, nm)] = torch.zeros(shp["%s/res_conv/%s" % (rp, nm)], dtype=torch.float32, device=dev)
                 dpre = b16(m, 512)
                 self._call("fwn_gate_bwd", d_o[l].data_ptr(), aux[l].data_ptr(), m, dpre.data_ptr(), st)
-                dpt = transpose_shift(dpre, m, 512)            # shared by the dilated and the conditioning convs
-                part = weight_grad_partials(h[l], m, 256, dpt, 512, shifts=(-dil, 0, dil), ti=ti)
+                part = tn_weight_grad_partials(h[l], dpre, m, 256, 512, shifts=(-dil, 0, dil), ti=ti)
                 self._wn(grads, rp + "/Conv_filter", part, 768, 0, (3, 256, 256))
                 self._wn(grads, rp + "/Conv_gate", part, 768, 256, (3, 256, 256))
-                part = weight_grad_partials(ca, m, cin, dpt, 512)
+                part = tn_weight_grad_partials(ca, dpre, m, cin, 512)
                 self._wn(grads, rp + "/filter_conv_c", part, cin, 0, (1, cin, 256), row_src=tp.cond_rows[i])
                 self._wn(grads, rp + "/gate_conv_c", part, cin, 256, (1, cin, 256), row_src=tp.cond_rows[i])
                 gemm([(dpre, 512, 0, 0)], t["WcT"][l], cin, m, out=dca, accumulate=True)
@@ -515,8 +542,12 @@ class GradEngine:
                 dh_next = dh
             # front conv
             ya_bf = xa.to(torch.bfloat16)
-            part = weight_grad_partials(ya_bf, m, ch, transpose_shift(dh_next, m, 256), 256, shifts=(-1, 0, 1), ti=ti)
-            self._wn(grads, wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
+            if ch % 8 == 0:
+                part = tn_weight_grad_partials(ya_bf, dh_next, m, ch, 256, shifts=(-1, 0, 1), ti=ti)
+                self._wn(grads, wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
+            else:       # rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
+                part = weight_grad_partials(ya_bf, m, ch, transpose_shift(dh_next, m, 256), 256, shifts=(-1, 0, 1), ti=ti)
+                self._wn(grads, wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
             segs = [(dh_next, 256, -(tap - 1), tap * 256) for tap in range(3)]
             gemm(segs, t["WfT"], ch, m, ti=ti, out=ga, accumulate=True)
             # ActNorm (both planes), back to the flow's inputs
@@ -571,25 +602,29 @@ class GradEngine:
                 go[k].copy_(grads[k].reshape(go[k].shape))
                 grads[k] = go[k]
 
-    def _wn(self, grads, name, part, k, col0, shape, scale=1.0, row_src=None):
-        """Split-K partials of a weight-gradient GEMM (fp32 [S][rows + 1][ncols], bias row last) -> gradients
-        of a weight-normed conv's kernel, g and bias (one launch, summing the partials in a fixed order)."""
+    def _wn(self, grads, name, part, k, col0, shape, scale=1.0, row_src=None, db=None):
+        """Split-K partials of a weight-gradient GEMM (fp32 [S][rows (+ 1)][ncols]) -> gradients of a weight-normed
+        conv's kernel, g and bias (one launch, summing the partials in a fixed order).  db None: the bias gradient is
+        the partials' last row (the ones row of the transposed-copy path); else the given column sums."""
         import torch
         dev = part.device
         v, g = self._tp._f32(name + "/kernel"), self._tp._f32(name + "/g")
         n = int(v.shape[-1])
         go = self._gout
         if go is not None and go[name + "/kernel"].is_contiguous():
-            dv, dg, db = go[name + "/kernel"].view(k, n), go[name + "/g"], go[name + "/bias"]
+            dv, dg, dbo = go[name + "/kernel"].view(k, n), go[name + "/g"], go[name + "/bias"]
         else:
             dv = torch.empty(k, n, dtype=torch.float32, device=dev)
-            dg, db = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+            dg, dbo = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
         self._call("fwn_wn_backward", part.data_ptr(), int(part.shape[0]), int(part.stride(0)), int(part.shape[2]),
-                   row_src.data_ptr() if row_src is not None else None, int(col0), int(part.shape[1]) - 1, float(scale),
-                   v.data_ptr(), g.data_ptr(), k, n, dv.data_ptr(), dg.data_ptr(), db.data_ptr(), _stream(part))
+                   row_src.data_ptr() if row_src is not None else None, int(col0), int(part.shape[1]) - 1 if db is None else -1,
+                   float(scale), v.data_ptr(), g.data_ptr(), k, n, dv.data_ptr(), dg.data_ptr(),
+                   dbo.data_ptr() if db is None else None, _stream(part))
+        if db is not None:
+            dbo.copy_(db)
         grads[name + "/kernel"] = dv.view(shape)
         grads[name + "/g"] = dg
-        grads[name + "/bias"] = db
+        grads[name + "/bias"] = dbo
 
 
 class Trainer:
