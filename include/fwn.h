@@ -69,6 +69,10 @@ int fwn_pack_jobs(const fwn_scale_job* scale_jobs, int n_scale_jobs, const fwn_p
  * Exactly one of out_f32 ([B][H*s][W]) / out_cplanes (bf16 [2][B][H*s][W/2]) may be NULL. */
 int fwn_upsample_stage(const float* in, int B, int H, int W, const float* wk, float bias, int s,
                        float* out_f32, void* out_cplanes, void* stream);
+/* The same stage with the bias read from device memory (one float, e.g. the fp32 master itself): the launch
+ * carries no parameter value and can be replayed from a hipGraph after the parameter changed. */
+int fwn_upsample_stage_dev(const float* in, int B, int H, int W, const float* wk, const float* bias, int s,
+                           float* out_f32, void* out_cplanes, void* stream);
 
 /* ---- K2: x[B][T] <-> planes[2][B][T/2] (squeeze / unsqueeze entry and exit) ---- */
 int fwn_split_planes(const float* x, int64_t B, int64_t T, float* planes, void* stream);
@@ -158,6 +162,11 @@ int fwn_grad_norm_partials(int64_t n);
 int fwn_grad_norm(const float* g, int64_t n, float gscale, double* partial, float* gnorm_out, void* stream);
 int fwn_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const float* gnorm, float gscale,
                   float clip, float lr, int64_t step, float beta1, float beta2, float eps, void* stream);
+/* The same update with the bias-corrected rate lr_t = fwn_adam_rate(lr, step, b1, b2) read from DEVICE memory
+ * (one float), so that the launch can be recorded in a hipGraph and replayed while the rate changes. */
+double fwn_adam_rate(float lr, int64_t step, float beta1, float beta2);
+int fwn_clip_adam_dev(float* w, const float* g, float* m, float* v, int64_t n, const float* gnorm, float gscale,
+                      float clip, const float* lr_t, float beta1, float beta2, float eps, void* stream);
 
 /* ---- training-side primitives (work in progress: the backward pass) ----
  * Generic multi-segment GEMM on the LDS-DMA ring core:

@@ -143,6 +143,29 @@ def test_trainer_steps_reduce_the_loss_on_a_fixed_batch():
     assert min(losses[-5:]) < losses[0] - 0.05, losses
 
 
+def test_recorded_step_replays_the_eager_step_bit_for_bit():
+    """Trainer(graph=True): eager first step, hipGraph recording on the second, replays after - weights, loss and
+    gradient norm equal the eager trainer's on changing batches, and the Adam rate follows the step count."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import Trainer
+    hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
+    inp = W.synthetic_inputs(hp, 4, 256)
+    x0, c0 = torch.from_numpy(inp["x"]).reshape(4, 256).cuda(), torch.from_numpy(inp["c"]).cuda()
+    batches = [(x0.roll(k, 0) * (1.0 - 0.05 * k), c0.roll(k, 0)) for k in range(5)]
+    runs = {}
+    for graph in (False, True):
+        tr = Trainer(hp, W.synthetic_params(hp, 11), graph=graph)
+        tr.ddi(*batches[0])
+        outs = [tuple(float(v) for v in tr.step(x, c)) for x, c in batches]
+        runs[graph] = (outs, tr.opt.w.clone(), tr.opt.global_step)
+    assert runs[True][2] == runs[False][2] == 5
+    assert runs[True][0] == runs[False][0]
+    assert torch.equal(runs[True][1], runs[False][1])
+
+
 def test_train_cli_loop_checkpoint_resume_and_synthesis(tmp_path):
     """preprocess -> train (DDI, steps, summaries, checkpoint) -> resume -> synthesize from the checkpoint."""
     import json, os, sys, wave
@@ -209,8 +232,10 @@ def _dp_worker(rank, world, port, out_dir):
     tr.ddi(x, c)
     w0 = tr.opt.w.clone()
     tr.step(x, c)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), w0=w0.cpu().numpy(), g=tr.opt.g.cpu().numpy(),
-             w1=tr.opt.w.cpu().numpy())
+    g1, w1 = tr.opt.g.cpu().numpy(), tr.opt.w.cpu().numpy()
+    tr.step(x, c)               # with FWN_TRAIN_GRAPH=1: recorded (a chain of hipGraphs cut at the all-reduces) ...
+    tr.step(x, c)               # ... and replayed
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), w0=w0.cpu().numpy(), g=g1, w1=w1, w3=tr.opt.w.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -227,14 +252,25 @@ def test_two_rank_data_parallel_step_matches_one_process_on_the_whole_batch(tmp_
     from tf_flowavenet_amd.training import Trainer
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=300)
-        assert p.exitcode == 0
-    r0, r1 = (np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2))
-    assert np.array_equal(r0["w0"], r1["w0"]) and np.array_equal(r0["g"], r1["g"]) and np.array_equal(r0["w1"], r1["w1"])
+    w3 = {}
+    for mode in ("1", "0"):     # recorded step, then the eager step: same bits after three steps
+        os.environ["FWN_TRAIN_GRAPH"] = mode
+        out = tmp_path / ("graph" + mode)
+        out.mkdir()
+        try:
+            procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(out))) for r in range(2)]
+            for p in procs:
+                p.start()
+            for p in procs:
+                p.join(timeout=300)
+                assert p.exitcode == 0
+        finally:
+            os.environ.pop("FWN_TRAIN_GRAPH")
+        r0, r1 = (np.load(out / ("rank%d.npz" % r)) for r in range(2))
+        assert np.array_equal(r0["w0"], r1["w0"]) and np.array_equal(r0["g"], r1["g"]) and np.array_equal(r0["w1"], r1["w1"])
+        assert np.array_equal(r0["w3"], r1["w3"])
+        w3[mode] = r0["w3"]
+    assert np.array_equal(w3["1"], w3["0"])
     # one process, the whole batch, same initial weights
     hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
     inp = W.synthetic_inputs(hp, 4, 256)

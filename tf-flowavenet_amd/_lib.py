@@ -84,6 +84,7 @@ SIGNATURES = {
     "fwn_wn_scale": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_pack_bf16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, i64, vp, vp]),
     "fwn_upsample_stage": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp]),
+    "fwn_upsample_stage_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]),
     "fwn_split_planes": (C.c_int, [vp, i64, i64, vp, vp]),
     "fwn_merge_planes": (C.c_int, [vp, i64, i64, vp, vp]),
     "fwn_actnorm_ddi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
@@ -119,6 +120,8 @@ SIGNATURES = {
     "fwn_grad_norm": (C.c_int, [vp, i64, C.c_float, vp, vp, vp]),
     "fwn_clip_adam": (C.c_int, [vp, vp, vp, vp, i64, vp, C.c_float, C.c_float, C.c_float, i64, C.c_float,
                                 C.c_float, C.c_float, vp]),
+    "fwn_adam_rate": (C.c_double, [C.c_float, i64, C.c_float, C.c_float]),
+    "fwn_clip_adam_dev": (C.c_int, [vp, vp, vp, vp, i64, vp, C.c_float, C.c_float, vp, C.c_float, C.c_float, C.c_float, vp]),
     "fwn_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), i64, i64]),
     "fwn_model_forward": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp,
                                     C.c_int, vp]),

@@ -61,8 +61,17 @@ int fwn_upsample_stage(const float* in, int B, int H, int W, const float* wk, fl
     REQUIRE((out_f32 != nullptr) != (out_cplanes != nullptr), "fwn_upsample_stage: exactly one output");
     REQUIRE(B > 0 && H > 0 && W > 0 && s > 0 && (s % 2) == 0, "fwn_upsample_stage: bad shape (s must be even)");
     REQUIRE(!out_cplanes || (W % 2) == 0, "fwn_upsample_stage: W must be even for planes");
-    fwn_launch_upsample(in, B, H, W, wk, bias, s, out_f32, out_cplanes, (hipStream_t)stream);
+    fwn_launch_upsample(in, B, H, W, wk, bias, nullptr, s, out_f32, out_cplanes, (hipStream_t)stream);
     return check_launch("fwn_upsample_stage");
+}
+int fwn_upsample_stage_dev(const float* in, int B, int H, int W, const float* wk, const float* bias, int s,
+                           float* out_f32, void* out_cplanes, void* stream) {
+    REQUIRE(in && wk && bias, "fwn_upsample_stage_dev: null pointer");
+    REQUIRE((out_f32 != nullptr) != (out_cplanes != nullptr), "fwn_upsample_stage_dev: exactly one output");
+    REQUIRE(B > 0 && H > 0 && W > 0 && s > 0 && (s % 2) == 0, "fwn_upsample_stage_dev: bad shape (s must be even)");
+    REQUIRE(!out_cplanes || (W % 2) == 0, "fwn_upsample_stage_dev: W must be even for planes");
+    fwn_launch_upsample(in, B, H, W, wk, 0.0f, bias, s, out_f32, out_cplanes, (hipStream_t)stream);
+    return check_launch("fwn_upsample_stage_dev");
 }
 
 int fwn_split_planes(const float* x, int64_t B, int64_t T, float* planes, void* stream) {
@@ -362,8 +371,19 @@ int fwn_clip_adam(float* w, const float* g, float* m, float* v, int64_t n, const
     REQUIRE(ALIGNED16(w) && ALIGNED16(g) && ALIGNED16(m) && ALIGNED16(v), "fwn_clip_adam: buffers must be 16-byte aligned");
     REQUIRE(step >= 1 && clip > 0.0f && lr > 0.0f, "fwn_clip_adam: step must be >= 1, clip and lr positive");
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
-    fwn_launch_adam(w, g, m, v, (long)n, gnorm, gscale, clip, (float)lr_t, beta1, beta2, eps, (hipStream_t)stream);
+    fwn_launch_adam(w, g, m, v, (long)n, gnorm, gscale, clip, (float)lr_t, nullptr, beta1, beta2, eps, (hipStream_t)stream);
     return check_launch("fwn_clip_adam");
+}
+double fwn_adam_rate(float lr, int64_t step, float beta1, float beta2) {
+    return (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+}
+int fwn_clip_adam_dev(float* w, const float* g, float* m, float* v, int64_t n, const float* gnorm, float gscale,
+                      float clip, const float* lr_t, float beta1, float beta2, float eps, void* stream) {
+    REQUIRE(w && g && m && v && gnorm && lr_t && n > 0, "fwn_clip_adam_dev: bad argument");
+    REQUIRE(ALIGNED16(w) && ALIGNED16(g) && ALIGNED16(m) && ALIGNED16(v), "fwn_clip_adam_dev: buffers must be 16-byte aligned");
+    REQUIRE(clip > 0.0f, "fwn_clip_adam_dev: clip must be positive");
+    fwn_launch_adam(w, g, m, v, (long)n, gnorm, gscale, clip, 0.0f, lr_t, beta1, beta2, eps, (hipStream_t)stream);
+    return check_launch("fwn_clip_adam_dev");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,7 +477,7 @@ static void run_upsample(const fwn_model_desc* m, int64_t B, int64_t T, const fl
     for (int i = 0; i < m->n_up; ++i) {
         const bool last = (i == m->n_up - 1);
         float* outf = last ? nullptr : (float*)(ws + ((i & 1) ? c.up1 : c.up0));
-        fwn_launch_upsample(in, (int)B, H, m->num_mels, m->up_w[i], m->up_bias[i], m->up_scale[i], outf,
+        fwn_launch_upsample(in, (int)B, H, m->num_mels, m->up_w[i], m->up_bias[i], nullptr, m->up_scale[i], outf,
                             last ? (void*)(ws + c.cplanes) : nullptr, st);
         H *= m->up_scale[i];
         in = outf;

@@ -104,10 +104,12 @@ void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack
 // Gather form of SURVEY Appendix A: y[tau, w] = bias + sum over (i,k) with i*s + k - s/2 = tau
 // and kw of x[i, w - kw + 1] * wk[k][kw].
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, int B, int H, int W,
-                                                       const float* __restrict__ wk, float bias, int s,
+                                                       const float* __restrict__ wk, float bias_host,
+                                                       const float* __restrict__ bias_dev, int s,
                                                        float* __restrict__ out_f32, bf16* __restrict__ out_planes) {
     const long total = (long)B * H * s * W;
     const int half = W >> 1;
+    const float bias = bias_dev ? bias_dev[0] : bias_host;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int w = (int)(idx % W);
         const long rt = idx / W;
@@ -264,7 +266,9 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const double* __restr
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, long n,
                                                         const float* __restrict__ gnorm, float gscale, float clip,
-                                                        float lr_t, float b1, float b2, float eps) {
+                                                        float lr_host, const float* __restrict__ lr_dev, float b1,
+                                                        float b2, float eps) {
+    const float lr_t = lr_dev ? lr_dev[0] : lr_host;     // device-resident rate: the launch can live in a hipGraph
     const float sc = gscale / fmaxf(gnorm[0], clip);     // tf.clip_by_global_norm: g / max(gn, clip)*clip, clip=1
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
         if (i + 3 < n) {
@@ -304,10 +308,10 @@ void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, st, v, scale, src_k, src_n, n_src,
                        k_dst, ld_dst, total, (bf16*)out);
 }
-void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, float bias, int s,
+void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, float bias, const float* bias_dev, int s,
                          float* out_f32, void* out_planes, hipStream_t st) {
     const long total = (long)B * H * s * W;
-    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, B, H, W, wk, bias, s,
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, B, H, W, wk, bias, bias_dev, s,
                        out_f32, (bf16*)out_planes);
 }
 void fwn_launch_split(const float* x, long B, long T, float* planes, hipStream_t st) {
@@ -385,7 +389,7 @@ void fwn_launch_grad_norm(const float* g, long n, float gscale, double* partial,
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, gscale, out);
 }
 void fwn_launch_adam(float* w, const float* g, float* m, float* v, long n, const float* gnorm, float gscale,
-                     float clip, float lr_t, float b1, float b2, float eps, hipStream_t st) {
+                     float clip, float lr_t, const float* lr_dev, float b1, float b2, float eps, hipStream_t st) {
     hipLaunchKernelGGL(adam_clip_kernel, dim3(fwn_sqnorm_blocks(n)), dim3(256), 0, st, w, g, m, v, n, gnorm, gscale,
-                       clip, lr_t, b1, b2, eps);
+                       clip, lr_t, lr_dev, b1, b2, eps);
 }

@@ -21,7 +21,7 @@ int fwn_tail_rows(int M);   // rows per tail workgroup (sizes the log-det partia
 void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st);
 void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,
                      int k_dst, int n_dst, long ld_dst, void* out, hipStream_t st);
-void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, float bias, int s,
+void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, float bias, const float* bias_dev, int s,
                          float* out_f32, void* out_planes, hipStream_t st);
 void fwn_launch_split(const float* x, long B, long T, float* planes, hipStream_t st);
 void fwn_launch_merge(const float* planes, long B, long T, float* x, hipStream_t st);
@@ -34,7 +34,7 @@ void fwn_launch_mel(const float* wav, long B, long T, const float* window, const
                     int n_mels, float ref_db, float min_db, float* mel, hipStream_t st);
 void fwn_launch_grad_norm(const float* g, long n, float gscale, double* partial, float* out, hipStream_t st);
 void fwn_launch_adam(float* w, const float* g, float* m, float* v, long n, const float* gnorm, float gscale,
-                     float clip, float lr_t, float b1, float b2, float eps, hipStream_t st);
+                     float clip, float lr_t, const float* lr_dev, float b1, float b2, float eps, hipStream_t st);
 
 // train_kernels.hip
 struct fwn_gemm_desc;

@@ -97,6 +97,7 @@ class DataParallelAdam:
         self._lib = _lib.load()
         self._partial = torch.empty(self._lib.fwn_grad_norm_partials(self.w.numel()), dtype=torch.float64, device=device)
         self._gnorm = torch.empty(1, dtype=torch.float32, device=device)
+        self._rate = torch.zeros(1, dtype=torch.float32, device=device)     # lr_t of a recorded (hipGraph) update
 
     def master_views(self):
         return self.layout.views(self.w)
@@ -146,3 +147,25 @@ class DataParallelAdam:
                                            n, self._gnorm.data_ptr(), gscale, self.clip, lr, self.global_step,
                                            self.b1, self.b2, self.eps, st), "fwn_clip_adam")
         return self._gnorm
+
+    # -- the same update split for a recorded step: ``record_update`` puts the two launches on the current
+    # (capturing) stream with the rate read from device memory; ``advance`` is called before every replay.
+    def record_update(self, loss_scale=1.0):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        gscale = 1.0 / (world * float(loss_scale))
+        st = torch.cuda.current_stream(torch.device(self.device)).cuda_stream
+        n = self.w.numel()
+        _lib.check(self._lib.fwn_grad_norm(self.g.data_ptr(), n, gscale, self._partial.data_ptr(),
+                                           self._gnorm.data_ptr(), st), "fwn_grad_norm")
+        _lib.check(self._lib.fwn_clip_adam_dev(self.w.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                               n, self._gnorm.data_ptr(), gscale, self.clip, self._rate.data_ptr(),
+                                               self.b1, self.b2, self.eps, st), "fwn_clip_adam_dev")
+        return self._gnorm
+
+    def advance(self):
+        """global_step += 1 and the device-resident rate of that step (same arithmetic as fwn_clip_adam)."""
+        lr = learning_rate(self.global_step)
+        self.global_step += 1
+        self._rate.fill_(float(self._lib.fwn_adam_rate(lr, self.global_step, self.b1, self.b2)))

@@ -371,6 +371,17 @@ class GradEngine:
         self.lib = _lib.load()
         self._gout = None
         self._on_block = None
+        self._consts = {}
+        # True: the caller refreshes the host-computed tables itself (``refresh_host_tables``) - a recorded
+        # step keeps that device -> host -> device round trip outside its hipGraph
+        self.external_host_tables = False
+
+    def refresh_host_tables(self):
+        tp = getattr(self, "_tp", None)
+        if tp is None or tp.plan is None:
+            raise RuntimeError("no recorded packing plan: run one eager step on device-resident parameters first")
+        tp.plan.hostview.reset()
+        tp.plan.upload_tables()
 
     # ------------------------------------------------------------------ helpers
     def _call(self, name, *args):
@@ -403,7 +414,10 @@ class GradEngine:
         tp = getattr(self, "_tp", None)
         if tp is not None and tp.plan is not None and key is not None and getattr(self, "_tp_key", None) == key:
             tp.params = params
-            tp.refresh()
+            if not self.external_host_tables:
+                self.refresh_host_tables()
+            tp.plan.run_kernels()
+            tp._small_tables()
         else:
             tp = self._tp = _TrainPack(params, hp, self.device)
             self._tp_key = key if tp.plan is not None else None
@@ -424,7 +438,8 @@ class GradEngine:
             last = n == len(hp.upsample_scales) - 1
             bb, hh, ww = cur.shape
             out = None if last else f32(bb, hh * s_, ww)
-            self._call("fwn_upsample_stage", cur.data_ptr(), bb, hh, ww, md.up_w[n], md.up_bias[n], int(s_),
+            ub = tp._f32("upsample_%d/bias" % n)          # read on the device: nothing of the parameters rides in launch arguments
+            self._call("fwn_upsample_stage_dev", cur.data_ptr(), bb, hh, ww, md.up_w[n], ub.data_ptr(), int(s_),
                        None if last else out.data_ptr(), cplanes.data_ptr() if last else None, st)
             ups.append(cur)
             cur = out
@@ -474,7 +489,9 @@ class GradEngine:
         grads = {}
         # d loss / d z = z / (B T)   (log_p = mean 0.5(-log 2pi - z^2)): a copy, scaled by the ActNorm kernel
         gplanes = planes.clone()
-        inv = torch.tensor([0.0, 1.0 / (B * T), 0.0, 0.0], dtype=torch.float32, device=dev)
+        if (dev, B * T) not in self._consts:
+            self._consts[(dev, B * T)] = torch.tensor([0.0, 1.0 / (B * T), 0.0, 0.0], dtype=torch.float32, device=dev)
+        inv = self._consts[(dev, B * T)]
         self._call("fwn_actnorm_apply", gplanes.data_ptr(), inv.data_ptr(), B * T, 1, st)
         dcplanes = torch.zeros(2, B * T * half, dtype=torch.float32, device=dev)
         for (i, j, p, h, o, aux, s_act, u_act, z) in reversed(saved):
@@ -634,11 +651,19 @@ class Trainer:
     fp32 masters.  ``ddi`` performs the ActNorm data-dependent init of the first step
     (train.py:221,229 with init=True)."""
 
-    def __init__(self, hparams, params, device="cuda", group=None):
+    def __init__(self, hparams, params, device="cuda", group=None, graph=None):
+        """graph: record the step into hipGraphs after one eager step per input shape and replay it from then on
+        (the step is ~5700 launches; replaying removes their host cost).  Default: on for GPU devices, off if
+        FWN_TRAIN_GRAPH=0."""
+        import os
         from .optim import DataParallelAdam
         self.hp, self.device = hparams, device
         self.opt = DataParallelAdam(hparams, params, device, group=group)
         self.engine = GradEngine(hparams, device)
+        if graph is None:
+            graph = os.environ.get("FWN_TRAIN_GRAPH", "1") != "0"
+        self.graph = bool(graph)
+        self._recorded = {}
 
     def ddi(self, x, c):
         from .model import FloWaveNet
@@ -658,6 +683,75 @@ class Trainer:
 
     def step(self, x, c):
         """-> (loss, log_p, logdet, grad_norm) device scalars; the masters are updated in place."""
+        if self.graph:
+            return self._step_recorded(x, c)
+        return self._step_eager(x, c)
+
+    def _ranges(self):
+        return {("upsample" if key == "upsample" else int(key.split("_")[1])): (lo, hi) for key, lo, hi in self.opt.block_ranges()}
+
+    def _step_recorded(self, x, c):
+        """First call at a shape: eager (creates the packing plan, fills every cache).  Second: record.  The
+        recording is a chain of hipGraphs cut where a block's gradients are final, so that with more than one
+        rank each block's all-reduce still starts between two replays, under the rest of the backward pass;
+        the host-computed tables and the Adam rate are refreshed before the replay."""
+        import torch
+        import torch.distributed as dist
+        dev = torch.device(self.device)
+        x = torch.as_tensor(x)
+        c = torch.as_tensor(c)
+        key = (tuple(x.shape), tuple(c.shape))
+        rec = self._recorded.get(key)
+        if rec is None:
+            self._recorded[key] = "warm"
+            return self._step_eager(x, c)
+        world = dist.get_world_size(self.opt.group) if dist.is_available() and dist.is_initialized() else 1
+        if rec == "warm":
+            xs = torch.empty(tuple(x.shape), dtype=torch.float32, device=dev)
+            cs = torch.empty(tuple(c.shape), dtype=torch.float32, device=dev)
+            params, gv = self.opt.master_views(), self.opt.grad_views()
+            segs, pool = [], torch.cuda.graph_pool_handle()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            self.engine.external_host_tables = True
+            try:
+                with torch.cuda.stream(side):
+                    cur = [torch.cuda.CUDAGraph()]
+                    cur[0].capture_begin(pool=pool)
+
+                    def cut(i):
+                        if world == 1 and i >= 0:
+                            return
+                        cur[0].capture_end()
+                        segs.append((cur[0], i))
+                        cur[0] = torch.cuda.CUDAGraph()
+                        cur[0].capture_begin(pool=pool)
+
+                    loss, log_p, logdet, _ = self.engine.loss_and_grads(params, xs, cs, grad_out=gv, on_block_done=cut)
+                    gnorm = self.opt.record_update()
+                    cur[0].capture_end()
+                    segs.append((cur[0], None))
+            finally:
+                self.engine.external_host_tables = False
+            torch.cuda.current_stream(dev).wait_stream(side)
+            rec = self._recorded[key] = dict(xs=xs, cs=cs, segs=segs, out=(loss, log_p, logdet, gnorm))
+        rec["xs"].copy_(x.reshape(rec["xs"].shape), non_blocking=True)
+        rec["cs"].copy_(c, non_blocking=True)
+        self.engine.refresh_host_tables()
+        self.opt.advance()
+        ranges, works = self._ranges(), []
+        for g, i in rec["segs"]:
+            if i is None:                       # the optimiser: every exchange must have landed
+                for w in works:
+                    if w is not None:
+                        w.wait()
+            g.replay()
+            if i is not None:
+                lo, hi = ranges["upsample" if i < 0 else i]
+                works.append(self.opt.allreduce_range(lo, hi))
+        return rec["out"]
+
+    def _step_eager(self, x, c):
         params = self.opt.master_views()
         gv = self.opt.grad_views()
         ranges = {("upsample" if key == "upsample" else int(key.split("_")[1])): (lo, hi) for key, lo, hi in self.opt.block_ranges()}
