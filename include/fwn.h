@@ -216,10 +216,11 @@ int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void*
  * fwn_colsum_prod  : out[c] <- scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C], fixed order;
  *                    partial: scratch of fwn_colsum_partials(M, C) floats
  * fwn_actnorm_bwd  : dy <- dy * scale; y <- y / scale - shift (the plane before ActNorm)
- * fwn_wn_backward  : weight-norm backward per output column, straight from the split-K partials of the
- *                    weight-gradient GEMM: dW[k][n] = scale * sum_s part[s][row_src ? row_src[k] : k][col0 + n]
- *                    (part rows have ldp columns), db[n] = the same sum over row bias_row (< 0 / NULL: none);
- *                    V fp32 [K][N], g [N] -> dV, dg; g == NULL: dV = dW (no weight norm)   (convolutional.py:73-80) */
+ * fwn_wn_backward_group (below, with the grouped weight-gradient GEMM): weight-norm backward straight from
+ *                    the split-K partials of the weight-gradient GEMM: dW[k][n] = scale * sum_s part[s][row_src ?
+ *                    row_src[k] : k][col0 + n] (part rows have ldp columns), db[n] = the same sum over row
+ *                    bias_row (< 0 / NULL: none); V fp32 [K][N], g [N] -> dV, dg; g == NULL: dV = dW (no
+ *                    weight norm)   (convolutional.py:73-80) */
 int fwn_actnorm_apply(float* x, const float* an, int64_t n, int Ch, void* stream);
 int fwn_coupling_fwd(float* yb, const float* Z, const float* ez, int64_t M, int Ch, float* partial, int nblocks,
                      void* stream);
@@ -230,9 +231,6 @@ int fwn_colsum_partials(int64_t M, int C);
 int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C, float scale, float* partial, float* out,
                     void* stream);
 int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, void* stream);
-int fwn_wn_backward(const float* part, int nsplit, int64_t split_stride, int ldp, const int32_t* row_src, int col0,
-                    int bias_row, float scale, const float* V, const float* g, int K, int N, float* dV, float* dg,
-                    float* db, void* stream);
 
 /* Backward of one up-sampling stage (fwn_upsample_stage with fp32 output): y, dy [B][H*s][W], x [B][H][W].
  * dy <- dy * LeakyReLU'(y) in place; dx (may be NULL) <- gradient wrt x; dwk_bias [6s + 1] <- gradients of
@@ -249,6 +247,23 @@ int fwn_upsample_bwd(float* dy, const float* y, const float* x, int B, int H, in
  * fwn_colsum_bf16: out[c] = scale * sum_m dY[m][c] (bias gradients), scratch fwn_colsum_partials(M, C) floats. */
 int fwn_tn_gemm(const void* x, int ldx, int Kx, int ntap, int shift0, int dshift, const void* dy, int ldy, int N, int M,
                 int Ti, int nsplit, float* part, int64_t split_stride, int bias_row, void* stream);
+
+/* Grouped forms: the weight gradients of one flow (same M, Ti) in ONE launch each - the job table travels in the
+ * kernel arguments (at most FWN_MAX_GROUP jobs), every job needs only a few splits for the group to fill the chip. */
+#define FWN_MAX_GROUP 16
+typedef struct fwn_tn_job {
+    const void* x; const void* dy; float* part; int64_t split_stride;
+    int32_t ldx, Kx, ntap, shift0, dshift, ldy, N, nsplit, bias_row, reserved;
+} fwn_tn_job;
+int fwn_tn_gemm_group(const fwn_tn_job* jobs, int njobs, int M, int Ti, void* stream);
+typedef struct fwn_wn_job {
+    const float* part; const int32_t* row_src; const float* V; const float* g; float* dV; float* dg; float* db;
+    int64_t split_stride;
+    int32_t nsplit, ldp, col0, bias_row, K, N; float scale; int32_t reserved;
+} fwn_wn_job;
+/* fwn_wn_backward for every job of the group (two launches); scratch: fwn_wn_group_scratch(jobs, njobs) doubles. */
+int64_t fwn_wn_group_scratch(const fwn_wn_job* jobs, int njobs);
+int fwn_wn_backward_group(const fwn_wn_job* jobs, int njobs, double* scratch, void* stream);
 int fwn_colsum_bf16(const void* dy, int64_t M, int C, int ld, float scale, float* partial, float* out, void* stream);
 
 /* ---- whole model (replaces FloWaveNet.forward / .reverse, model.py:317-396) ---- */

@@ -108,7 +108,13 @@ def test_training_primitives_validate_their_arguments(lib):
     assert lib.fwn_transpose_shift(None, 4, 4, 4, 0, 0, 1, 0, None, 64, 0, None) == -1
     assert lib.fwn_reduce_splits(None, 2, 16, 16, 1.0, None, None) == -1
     assert lib.fwn_coupling_bwd(None, None, None, None, 4, 1, 0.0, None, 8, None, None) == -1
-    assert lib.fwn_wn_backward(None, 1, 0, 4, None, 0, -1, 1.0, None, None, 4, 4, None, None, None, None) == -1
+    assert lib.fwn_wn_backward_group(None, 1, None, None) == -1
+    wj = (_lib.WnJob * 1)()
+    assert lib.fwn_wn_backward_group(wj, 1, None, None) == -1 and b"bad job" in lib.fwn_last_error()
+    assert lib.fwn_wn_backward_group(wj, _lib.FWN_MAX_GROUP + 1, None, None) == -1
+    tj = (_lib.TnJob * 1)()
+    assert lib.fwn_tn_gemm_group(tj, 1, 64, 0, None) == -1 and b"job 0" in lib.fwn_last_error()
+    assert C.sizeof(_lib.TnJob) == 72 and C.sizeof(_lib.WnJob) == 96
     assert lib.fwn_upsample_bwd(1 << 20, 1 << 20, 1 << 20, 1, 4, 8, 3, 1 << 20, None, 1 << 20, 1 << 20, None) == -1   # odd s
     assert lib.fwn_mel_spectrogram(1 << 20, 1, 4096, 1 << 20, 1 << 20, 1000, 256, 80, 20.0, -100.0, 1 << 20, None) == -1
     assert b"power of two" in lib.fwn_last_error()

@@ -329,3 +329,55 @@ def test_tn_gemm_reads_operands_transposed_from_lds(m, ti, kx, n, shifts):
     assert np.abs(got - want).max() < 2e-3 * np.abs(want).max()
     np.testing.assert_allclose(got_b, dyw.sum(0), atol=2e-3 * np.abs(dyw.sum(0)).max())     # the bias row
     np.testing.assert_allclose(TR.colsum_bf16(dy, m, n, scale=0.5).cpu().numpy(), 0.5 * dyw.sum(0), atol=2e-3 * np.abs(dyw.sum(0)).max())
+
+
+def test_grouped_weight_gradients_and_weight_norm_backward():
+    """One grouped TN GEMM over jobs of different shapes, then the grouped split reduction + weight-norm backward
+    (convolutional.py:73-80: W = V g / ||V||_col) against float64."""
+    torch.manual_seed(3)
+    m, ti = 5000, 1000
+    f64 = lambda t: t.float().cpu().numpy().astype(np.float64)
+    xs = [torch.randn(m, k, device="cuda").to(torch.bfloat16) for k in (256, 256, 80)]
+    dys = [(torch.randn(m, n, device="cuda") * 0.1).to(torch.bfloat16) for n in (256, 512, 512)]
+    shifts = [(0,), (-3, 0, 3), (0,)]
+    jobs = [(xs[i], dys[i], xs[i].shape[1], dys[i].shape[1], shifts[i]) for i in range(3)]
+    parts = TR.tn_weight_grad_group(jobs, m, ti)
+    assert parts[0].shape[0] == TR.tn_group_splits([(256, 256, 1), (256, 512, 3), (80, 512, 1)], m)
+
+    def shifted(a, sh):
+        out = np.zeros_like(a)
+        for r in range(a.shape[0]):
+            if 0 <= r % ti + sh < ti:
+                out[r] = a[r + sh]
+        return out
+
+    want = [np.concatenate([shifted(f64(xs[i]), sh).T @ f64(dys[i]) for sh in shifts[i]] + [f64(dys[i]).sum(0, keepdims=True)])
+            for i in range(3)]
+    for i in range(3):
+        got = parts[i].sum(0).cpu().numpy()
+        assert np.abs(got - want[i]).max() < 2e-3 * np.abs(want[i]).max()
+    # weight-norm backward of the two column halves of job 1 (K = 768) and of job 2 through a row map
+    perm = torch.randperm(80, device="cuda").to(torch.int32)
+    specs = [(parts[1], 768, 0, None, 0.7), (parts[1], 768, 256, None, 1.0), (parts[2], 80, 256, perm, 1.0), (parts[0], 256, 0, None, 1.0)]
+    wn_jobs, keep = [], []
+    for part, k, col0, row_src, scale in specs:
+        v, g = torch.randn(k, 256, device="cuda"), torch.rand(256, device="cuda") + 0.5
+        out = dict(dv=torch.empty(k, 256, device="cuda"), dg=torch.empty(256, device="cuda"), db=torch.empty(256, device="cuda"))
+        wn_jobs.append(dict(part=part, k=k, n=256, col0=col0, bias_row=int(part.shape[1]) - 1, scale=scale, row_src=row_src, v=v, g=g, **out))
+        keep.append((v, g, out))
+    wn_jobs[3]["g"] = wn_jobs[3]["v"] = None                  # no weight norm: dV = dW
+    TR.wn_backward_group(wn_jobs)
+    for (part, k, col0, row_src, scale), (v, g, out), wj in zip(specs, keep, wn_jobs):
+        full = f64(part.sum(0)) * scale
+        rows = np.arange(k) if row_src is None else row_src.cpu().numpy()
+        dw, db = full[rows][:, col0:col0 + 256], full[-1, col0:col0 + 256]
+        np.testing.assert_allclose(out["db"].cpu().numpy(), db, rtol=1e-4, atol=1e-4 * np.abs(db).max())
+        if wj["g"] is None:
+            np.testing.assert_allclose(out["dv"].cpu().numpy(), dw, rtol=1e-4, atol=1e-5 * np.abs(dw).max())
+            continue
+        vv, gg = f64(v), f64(g)
+        nrm = np.sqrt((vv * vv).sum(0))
+        dg = (dw * vv).sum(0) / nrm
+        dv = gg / nrm * (dw - vv * dg / nrm)
+        np.testing.assert_allclose(out["dg"].cpu().numpy(), dg, rtol=1e-4, atol=1e-4 * np.abs(dg).max())
+        np.testing.assert_allclose(out["dv"].cpu().numpy(), dv, rtol=1e-4, atol=1e-4 * np.abs(dv).max())

@@ -64,6 +64,24 @@ class GemmSeg(C.Structure):
 FWN_GEMM_MAXSEG = 8
 
 
+FWN_MAX_GROUP = 16
+
+
+class TnJob(C.Structure):
+    """fwn_tn_job (include/fwn.h)."""
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("part", C.c_void_p), ("split_stride", C.c_int64),
+                ("ldx", C.c_int32), ("Kx", C.c_int32), ("ntap", C.c_int32), ("shift0", C.c_int32), ("dshift", C.c_int32),
+                ("ldy", C.c_int32), ("N", C.c_int32), ("nsplit", C.c_int32), ("bias_row", C.c_int32), ("reserved", C.c_int32)]
+
+
+class WnJob(C.Structure):
+    """fwn_wn_job (include/fwn.h)."""
+    _fields_ = [("part", C.c_void_p), ("row_src", C.c_void_p), ("V", C.c_void_p), ("g", C.c_void_p), ("dV", C.c_void_p),
+                ("dg", C.c_void_p), ("db", C.c_void_p), ("split_stride", C.c_int64),
+                ("nsplit", C.c_int32), ("ldp", C.c_int32), ("col0", C.c_int32), ("bias_row", C.c_int32), ("K", C.c_int32),
+                ("N", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     """include/fwn.h fwn_gemm_desc."""
     _fields_ = [("seg", GemmSeg * FWN_GEMM_MAXSEG),
@@ -112,7 +130,9 @@ SIGNATURES = {
     "fwn_colsum_partials": (C.c_int, [i64, C.c_int]),
     "fwn_colsum_prod": (C.c_int, [vp, vp, i64, C.c_int, C.c_float, vp, vp, vp]),
     "fwn_actnorm_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
-    "fwn_wn_backward": (C.c_int, [vp, C.c_int, i64, C.c_int, vp, C.c_int, C.c_int, C.c_float, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "fwn_tn_gemm_group": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
+    "fwn_wn_group_scratch": (i64, [vp, C.c_int]),
+    "fwn_wn_backward_group": (C.c_int, [vp, C.c_int, vp, vp]),
     "fwn_transpose_shift": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp]),
     "fwn_reduce_splits": (C.c_int, [vp, C.c_int, i64, i64, C.c_float, vp, vp]),
     "fwn_mel_spectrogram": (C.c_int, [vp, i64, i64, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),

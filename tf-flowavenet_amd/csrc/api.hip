@@ -318,14 +318,23 @@ int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, voi
     fwn_ew_actnorm_bwd(dy, y, an, (long)n, Ch, (hipStream_t)stream);
     return check_launch("fwn_actnorm_bwd");
 }
-int fwn_wn_backward(const float* part, int nsplit, int64_t split_stride, int ldp, const int32_t* row_src, int col0,
-                    int bias_row, float scale, const float* V, const float* g, int K, int N, float* dV, float* dg,
-                    float* db, void* stream) {
-    REQUIRE(part && dV && K > 0 && N > 0 && nsplit >= 1 && ldp >= col0 + N && col0 >= 0, "fwn_wn_backward: bad argument");
-    REQUIRE(!g || (V && dg), "fwn_wn_backward: weight norm needs V and dg");
-    fwn_ew_wn_backward(part, nsplit, (long)split_stride, ldp, row_src, col0, bias_row, scale, V, g, K, N, dV, dg, db,
-                       (hipStream_t)stream);
-    return check_launch("fwn_wn_backward");
+static bool wn_job_ok(const fwn_wn_job& q) {
+    return q.part && q.dV && q.K > 0 && q.N > 0 && q.nsplit >= 1 && q.col0 >= 0 && q.ldp >= q.col0 + q.N && (!q.g || (q.V && q.dg));
+}
+int64_t fwn_wn_group_scratch(const fwn_wn_job* jobs, int njobs) {
+    if (!jobs || njobs < 1 || njobs > FWN_MAX_GROUP) return 0;
+    return (int64_t)fwn_wn_group_scratch_doubles(jobs, njobs);
+}
+int fwn_wn_backward_group(const fwn_wn_job* jobs, int njobs, double* scratch, void* stream) {
+    REQUIRE(jobs && njobs >= 1 && njobs <= FWN_MAX_GROUP, "fwn_wn_backward_group: 1..FWN_MAX_GROUP jobs");
+    bool any_g = false;
+    for (int j = 0; j < njobs; ++j) {
+        REQUIRE(wn_job_ok(jobs[j]), "fwn_wn_backward_group: bad job (null pointer, shape, or weight norm without V / dg)");
+        any_g = any_g || jobs[j].g;
+    }
+    REQUIRE(!any_g || scratch, "fwn_wn_backward_group: weight norm needs the scratch buffer");
+    fwn_wn_group_launch(jobs, njobs, scratch, (hipStream_t)stream);
+    return check_launch("fwn_wn_backward_group");
 }
 
 int fwn_upsample_bwd_partials(int B, int H, int s) { return fwn_up_bwd_chunks(B, H) * (6 * s + 1); }
@@ -337,16 +346,33 @@ int fwn_upsample_bwd(float* dy, const float* y, const float* x, int B, int H, in
     return check_launch("fwn_upsample_bwd");
 }
 
+static const char* tn_job_error(const fwn_tn_job& q, int M) {
+    if (!(q.x && q.dy && q.part && q.Kx > 0 && q.N > 0 && q.ntap >= 1 && q.nsplit >= 1)) return "bad argument";
+    if (!(q.ldx >= q.Kx && q.ldy >= q.N && q.ldx % 8 == 0 && q.ldy % 8 == 0 && q.Kx % 8 == 0 && q.N % 8 == 0 && ALIGNED16(q.x) &&
+          ALIGNED16(q.dy)))
+        return "rows must be 16-byte aligned and Kx, N multiples of 8";
+    if (!((int64_t)M * q.ldx * 2 < ((int64_t)1 << 31) && (int64_t)M * q.ldy * 2 < ((int64_t)1 << 31) &&
+          (int64_t)q.ntap * q.Kx * q.N * 4 < ((int64_t)1 << 31)))
+        return "operand exceeds 2 GiB";
+    if (!(q.nsplit == 1 || q.split_stride >= ((int64_t)q.ntap * q.Kx + (q.bias_row ? 1 : 0)) * q.N)) return "split_stride too small";
+    return nullptr;
+}
+int fwn_tn_gemm_group(const fwn_tn_job* jobs, int njobs, int M, int Ti, void* stream) {
+    REQUIRE(jobs && njobs >= 1 && njobs <= FWN_MAX_GROUP && M > 0 && Ti >= 0, "fwn_tn_gemm_group: 1..FWN_MAX_GROUP jobs, M > 0");
+    for (int j = 0; j < njobs; ++j) {
+        const char* e = tn_job_error(jobs[j], M);
+        if (e) return fail(FWN_ERR_ARG, "fwn_tn_gemm_group: job %d: %s", j, e);
+    }
+    fwn_tn_group_launch(jobs, njobs, M, Ti, (hipStream_t)stream);
+    return check_launch("fwn_tn_gemm_group");
+}
 int fwn_tn_gemm(const void* x, int ldx, int Kx, int ntap, int shift0, int dshift, const void* dy, int ldy, int N, int M,
                 int Ti, int nsplit, float* part, int64_t split_stride, int bias_row, void* stream) {
-    REQUIRE(x && dy && part && M > 0 && Kx > 0 && N > 0 && ntap >= 1 && nsplit >= 1 && Ti >= 0, "fwn_tn_gemm: bad argument");
-    REQUIRE(ldx >= Kx && ldy >= N && ldx % 8 == 0 && ldy % 8 == 0 && Kx % 8 == 0 && N % 8 == 0 && ALIGNED16(x) && ALIGNED16(dy),
-            "fwn_tn_gemm: rows must be 16-byte aligned and Kx, N multiples of 8");
-    REQUIRE((int64_t)M * ldx * 2 < ((int64_t)1 << 31) && (int64_t)M * ldy * 2 < ((int64_t)1 << 31) &&
-                (int64_t)ntap * Kx * N * 4 < ((int64_t)1 << 31), "fwn_tn_gemm: operand exceeds 2 GiB");
-    REQUIRE(nsplit == 1 || split_stride >= ((int64_t)ntap * Kx + (bias_row ? 1 : 0)) * N, "fwn_tn_gemm: split_stride too small");
-    fwn_tn_gemm_launch(x, ldx, Kx, ntap, shift0, dshift, dy, ldy, N, M, Ti, nsplit, part, (long)split_stride, bias_row,
-                       (hipStream_t)stream);
+    const fwn_tn_job q{x, dy, part, split_stride, ldx, Kx, ntap, shift0, dshift, ldy, N, nsplit, bias_row, 0};
+    REQUIRE(M > 0 && Ti >= 0, "fwn_tn_gemm: bad argument");
+    const char* e = tn_job_error(q, M);
+    if (e) return fail(FWN_ERR_ARG, "fwn_tn_gemm: %s", e);
+    fwn_tn_group_launch(&q, 1, M, Ti, (hipStream_t)stream);
     return check_launch("fwn_tn_gemm");
 }
 int fwn_colsum_bf16(const void* dy, int64_t M, int C_, int ld, float scale, float* partial, float* out, void* stream) {

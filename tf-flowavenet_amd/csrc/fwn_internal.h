@@ -53,9 +53,10 @@ int fwn_colsum_blocks(long M, int C);
 void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* partial, float* out,
                         hipStream_t st);
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st);
-void fwn_ew_wn_backward(const float* part, int nsplit, long split_stride, int ldp, const int* row_src, int col0,
-                        int bias_row, float scale, const float* V, const float* g, int K, int N, float* dV, float* dg,
-                        float* db, hipStream_t st);
+struct fwn_wn_job;
+struct fwn_tn_job;
+long fwn_wn_group_scratch_doubles(const fwn_wn_job* jobs, int njobs);
+void fwn_wn_group_launch(const fwn_wn_job* jobs, int njobs, double* scratch, hipStream_t st);
 int fwn_up_bwd_chunks(int B, int H);
 void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
                        float* dx, float* dwk_bias, float* partial, hipStream_t st);
@@ -63,6 +64,5 @@ struct fwn_scale_job;
 struct fwn_pack_job;
 void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack_job* jobs, int njobs, float* scales,
                           int scale_ld, hipStream_t st);
-void fwn_tn_gemm_launch(const void* x, int ldx, int Kx, int ntap, int shift0, int dshift, const void* dy, int ldy, int N,
-                        int M, int Ti, int nsplit, float* part, long split_stride, int bias_row, hipStream_t st);
+void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipStream_t st);
 void fwn_colsum_bf16_launch(const void* dy, long M, int C, int ld, float scale, float* partial, float* out, hipStream_t st);

@@ -271,51 +271,113 @@ __global__ __launch_bounds__(256) void actnorm_bwd_kernel(float* __restrict__ dy
         y[i] = y[i] * an[2 * Ch + c] - an[c];
     }
 }
-// Weight-norm backward (convolutional.py:73-80): W = V g / ||V||_col, straight from the split-K
-// partials of the weight-gradient GEMM: dW[k][n] = scale * sum_s part[s][row_src ? row_src[k] : k][col0 + n]
-// (fixed order), bias gradient = the same sum over the ones row `bias_row` (< 0: none).  One workgroup
-// per output column: dg = sum_k dW V / nrm, dV = (g / nrm) (dW - V dg / nrm).  g == NULL: no weight norm,
-// dV = dW.
-__global__ __launch_bounds__(256) void wn_backward_kernel(const float* __restrict__ part, int nsplit, long split_stride,
-                                                          int ldp, const int* __restrict__ row_src, int col0,
-                                                          int bias_row, float scale, const float* __restrict__ V,
-                                                          const float* __restrict__ g, int K, int N,
-                                                          float* __restrict__ dV, float* __restrict__ dg,
-                                                          float* __restrict__ db) {
-    __shared__ double red[2][256];
-    const int n = blockIdx.x;
-    auto dw = [&](int row) {
-        float a = 0.0f;
-        const size_t off = (size_t)row * ldp + col0 + n;
-        for (int s = 0; s < nsplit; ++s) a += part[(size_t)s * split_stride + off];
-        return a * scale;
-    };
-    if (threadIdx.x == 0 && db && bias_row >= 0) db[n] = dw(bias_row);
-    double ss = 0.0, dot = 0.0;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float d = dw(row_src ? row_src[k] : k);
-        dV[(size_t)k * N + n] = d;                       // staged: finalised below
-        if (g) {
-            const double v = V[(size_t)k * N + n];
-            ss += v * v;
-            dot += v * (double)d;
+// Weight-norm backward (convolutional.py:73-80): W = V g / ||V||_col, straight from the split-K partials.
+// ---- weight-norm backward of a GROUP of convolutions (all weight gradients of one flow) in two launches ----
+// part: split-K partials fp32 [S][rows][ldp] of a weight-gradient GEMM.  dW[k][n] = scale * sum_s part[s][row_src ?
+// row_src[k] : k][col0 + n] (fixed order), bias gradient = the same sum over row `bias_row` (< 0: none).
+// dg = sum_k dW V / nrm, dV = (g / nrm) (dW - V dg / nrm).  g == NULL: no weight norm, dV = dW.
+// Pass 1 (workgroup = 32 rows x 64 columns of one job; a wave reads 256 contiguous bytes of a row): reduce the
+// splits, stage dW in dV, per-workgroup column sums of V^2 and V dW (fp64) to scratch.  Pass 2, same grid: total
+// the column sums over the row chunks in a fixed order, finish dg and dV.
+struct WnGroup {
+    fwn_wn_job job[FWN_MAX_GROUP];
+    int first[FWN_MAX_GROUP + 1];
+    long soff[FWN_MAX_GROUP];           // scratch offset (doubles) of each job: [row chunk][N][2]
+    int njobs;
+};
+__device__ __forceinline__ float wn_sum_splits(const float* __restrict__ p, int nsplit, long stride) {
+    float a = 0.0f;
+    int s = 0;
+    for (; s + 4 <= nsplit; s += 4) {
+        const float t0 = p[(size_t)s * stride], t1 = p[(size_t)(s + 1) * stride], t2 = p[(size_t)(s + 2) * stride],
+                    t3 = p[(size_t)(s + 3) * stride];
+        a = (((a + t0) + t1) + t2) + t3;
+    }
+    for (; s < nsplit; ++s) a += p[(size_t)s * stride];
+    return a;
+}
+template <int PASS>
+__global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double* __restrict__ scratch) {
+    __shared__ double red[2][4][64];
+    int jn = 0;
+    while (jn + 1 < grp.njobs && (int)blockIdx.x >= grp.first[jn + 1]) ++jn;
+    const fwn_wn_job q = grp.job[jn];
+    if (PASS == 2 && !q.g) return;
+    const int ncol = (q.N + 63) / 64, local = (int)blockIdx.x - grp.first[jn];
+    const int nc = local % ncol, kc = local / ncol, nkc = (q.K + 31) / 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = nc * 64 + lane;
+    double* sc = scratch + grp.soff[jn];
+    if (PASS == 1) {
+        double ss = 0.0, dot = 0.0;
+        if (n < q.N) {
+            if (kc == 0 && w == 0 && q.db && q.bias_row >= 0)
+                q.db[n] = q.scale * wn_sum_splits(q.part + (size_t)q.bias_row * q.ldp + q.col0 + n, q.nsplit, (long)q.split_stride);
+#pragma unroll 2
+            for (int i = 0; i < 8; ++i) {
+                const int k = kc * 32 + w + 4 * i;
+                if (k >= q.K) break;
+                const int src = q.row_src ? q.row_src[k] : k;
+                const float d = q.scale * wn_sum_splits(q.part + (size_t)src * q.ldp + q.col0 + n, q.nsplit, (long)q.split_stride);
+                q.dV[(size_t)k * q.N + n] = d;
+                if (q.g) {
+                    const double v = q.V[(size_t)k * q.N + n];
+                    ss += v * v;
+                    dot += v * (double)d;
+                }
+            }
+        }
+        if (!q.g) return;
+        red[0][w][lane] = ss;
+        red[1][w][lane] = dot;
+        __syncthreads();
+        if (w == 0 && n < q.N) {
+            double* o = sc + ((size_t)kc * q.N + n) * 2;
+            o[0] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+            o[1] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+        }
+    } else {
+        if (n >= q.N) return;
+        double ss = 0.0, dot = 0.0;
+        for (int c = 0; c < nkc; ++c) {
+            const double* o = sc + ((size_t)c * q.N + n) * 2;
+            ss += o[0];
+            dot += o[1];
+        }
+        const double nrm = sqrt(fmax(ss, 1e-12)), dgn = dot / nrm;
+        if (kc == 0 && w == 0) q.dg[n] = (float)dgn;
+        const double gn = (double)q.g[n] / nrm;
+#pragma unroll 2
+        for (int i = 0; i < 8; ++i) {
+            const int k = kc * 32 + w + 4 * i;
+            if (k >= q.K) break;
+            const size_t e = (size_t)k * q.N + n;
+            q.dV[e] = (float)(gn * ((double)q.dV[e] - (double)q.V[e] * dgn / nrm));
         }
     }
-    if (!g) return;
-    red[0][threadIdx.x] = ss;
-    red[1][threadIdx.x] = dot;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
-        __syncthreads();
+}
+long fwn_wn_group_scratch_doubles(const fwn_wn_job* jobs, int njobs) {
+    long tot = 0;
+    for (int j = 0; j < njobs; ++j)
+        if (jobs[j].g) tot += (long)((jobs[j].K + 31) / 32) * jobs[j].N * 2;
+    return tot > 0 ? tot : 1;
+}
+void fwn_wn_group_launch(const fwn_wn_job* jobs, int njobs, double* scratch, hipStream_t st) {
+    WnGroup g;
+    g.njobs = njobs;
+    int total = 0;
+    long off = 0;
+    bool any_g = false;
+    for (int j = 0; j < njobs; ++j) {
+        g.job[j] = jobs[j];
+        g.first[j] = total;
+        g.soff[j] = off;
+        total += ((jobs[j].K + 31) / 32) * ((jobs[j].N + 63) / 64);
+        if (jobs[j].g) { off += (long)((jobs[j].K + 31) / 32) * jobs[j].N * 2; any_g = true; }
     }
-    const double nrm = sqrt(fmax(red[0][0], 1e-12)), dgn = red[1][0] / nrm;
-    if (threadIdx.x == 0) dg[n] = (float)dgn;
-    const double gn = (double)g[n] / nrm;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const size_t i = (size_t)k * N + n;
-        dV[i] = (float)(gn * ((double)dV[i] - (double)V[i] * dgn / nrm));
-    }
+    for (int j = njobs; j <= FWN_MAX_GROUP; ++j) g.first[j] = total;
+    hipLaunchKernelGGL(wn_group_kernel<1>, dim3(total), dim3(256), 0, st, g, scratch);
+    if (any_g) hipLaunchKernelGGL(wn_group_kernel<2>, dim3(total), dim3(256), 0, st, g, scratch);
 }
 
 static inline unsigned ew_grid(long n) { long b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
@@ -347,12 +409,6 @@ void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float sca
 }
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st) {
     hipLaunchKernelGGL(actnorm_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, an, n, Ch);
-}
-void fwn_ew_wn_backward(const float* part, int nsplit, long split_stride, int ldp, const int* row_src, int col0,
-                        int bias_row, float scale, const float* V, const float* g, int K, int N, float* dV, float* dg,
-                        float* db, hipStream_t st) {
-    hipLaunchKernelGGL(wn_backward_kernel, dim3(N), dim3(256), 0, st, part, nsplit, split_stride, ldp, row_src, col0,
-                       bias_row, scale, V, g, K, N, dV, dg, db);
 }
 
 // ---- backward of one up-sampling stage: Conv2DTranspose((2s,3),(s,1),'same') + LeakyReLU(0.4) -----
@@ -447,17 +503,31 @@ struct TnArgs {
 };
 __device__ __forceinline__ int tn_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-__global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
+// A launch covers a GROUP of such GEMMs (the weight gradients of one flow share M and Ti): the job table rides in
+// the kernel arguments, workgroup -> (job, row tile, column tile, split) by a scan of the prefix counts, so that
+// every GEMM needs only a few splits for the group to fill the chip (fewer partials to write and re-read).
+struct TnGroup {
+    TnArgs job[FWN_MAX_GROUP];
+    int first[FWN_MAX_GROUP + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void tn_gemm_kernel(const TnGroup grp) {
     constexpr int D = 3, TILE = 64 * 256, SLOT = 2 * TILE;       // X tile + dY tile, 16 KB each
     __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave >> 1, wj = wave & 1;
+    int jn = 0;
+    while (jn + 1 < grp.njobs && (int)blockIdx.x >= grp.first[jn + 1]) ++jn;
+    const TnArgs a = grp.job[jn];
     const int kxt = (a.Kx + 127) / 128;                            // row tiles per tap
-    const int tap = blockIdx.x / kxt, kx0 = (blockIdx.x % kxt) * 128, n0 = blockIdx.y * 128;
+    const int nbx = a.ntap * kxt, nby = (a.N + 127) / 128;
+    const int local = (int)blockIdx.x - grp.first[jn];
+    const int bx = local % nbx, by = (local / nbx) % nby, bz = local / (nbx * nby);     // splits slowest: tiles of one row range run together
+    const int tap = bx / kxt, kx0 = (bx % kxt) * 128, n0 = by * 128;
     const int shift = a.shift0 + tap * a.dshift;
     const int nchunk_all = (a.M + 63) / 64, per = (nchunk_all + a.nsplit - 1) / a.nsplit;
-    const int c0 = blockIdx.z * per, nq = max(0, min(per, nchunk_all - c0));
+    const int c0 = bz * per, nq = max(0, min(per, nchunk_all - c0));
     // DMA: a 1 KB piece = 4 rows x 256 B; wave w issues pieces w, w+4, .. (16 per tile)
     const int prow = lane >> 4, pch = lane & 15;
     const srd_t sx = make_srd(a.x, (uint32_t)((size_t)a.M * a.ldx * 2)), sy = make_srd(a.dy, (uint32_t)((size_t)a.M * a.ldy * 2));
@@ -485,7 +555,7 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     // bias gradient = column sums of dY: one more MFMA per k-step against an all-ones operand, in the
     // first row tile's wi == 0 waves only
-    const bool do_bias = a.bias_row && blockIdx.x == 0 && wi == 0;
+    const bool do_bias = a.bias_row && bx == 0 && wi == 0;
     f32x16 accb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -540,7 +610,7 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(TnArgs a) {
         }
     }
     // C layout: col = lane & 31 (j), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (i)
-    float* out = a.part + (size_t)blockIdx.z * a.split_stride;
+    float* out = a.part + (size_t)bz * a.split_stride;
     const int R = a.ntap * a.Kx;
     const uint32_t obytes = (uint32_t)((size_t)(R + (a.bias_row ? 1 : 0)) * a.N * 4);
     const srd_t so = make_srd(out, obytes);
@@ -579,10 +649,19 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
     if (part == 0 && c < C)
         partial[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-void fwn_tn_gemm_launch(const void* x, int ldx, int Kx, int ntap, int shift0, int dshift, const void* dy, int ldy, int N,
-                        int M, int Ti, int nsplit, float* part, long split_stride, int bias_row, hipStream_t st) {
-    TnArgs a{(const bf16*)x, ldx, Kx, ntap, shift0, dshift, (const bf16*)dy, ldy, N, M, Ti, nsplit, part, split_stride, bias_row};
-    hipLaunchKernelGGL(tn_gemm_kernel, dim3(ntap * ((Kx + 127) / 128), (N + 127) / 128, nsplit), dim3(256), 0, st, a);
+void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipStream_t st) {
+    TnGroup g;
+    g.njobs = njobs;
+    int total = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const fwn_tn_job& q = jobs[j];
+        g.job[j] = TnArgs{(const bf16*)q.x, q.ldx, q.Kx, q.ntap, q.shift0, q.dshift, (const bf16*)q.dy, q.ldy, q.N, M, Ti,
+                          q.nsplit, q.part, (long)q.split_stride, q.bias_row};
+        g.first[j] = total;
+        total += q.ntap * ((q.Kx + 127) / 128) * ((q.N + 127) / 128) * q.nsplit;
+    }
+    for (int j = njobs; j <= FWN_MAX_GROUP; ++j) g.first[j] = total;
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3(total), dim3(256), 0, st, g);
 }
 void fwn_colsum_bf16_launch(const void* dy, long M, int C, int ld, float scale, float* partial, float* out, hipStream_t st) {
     const int nb = fwn_colsum_blocks(M, C);

@@ -4,7 +4,7 @@
 tensor of the reference, ``Trainer`` adds the data-parallel clip / Adam step of ``optim.py``.  The
 building blocks are thin wrappers over ``csrc/train_kernels.hip``: ``fwn_gemm`` (generic multi-segment
 GEMM on the LDS-DMA ring core: data gradients on transposed packed weights), ``fwn_transpose_shift`` +
-split-K ``fwn_gemm`` + ``fwn_wn_backward`` (weight gradients: K = rows, partials summed in a fixed
+split-K ``fwn_tn_gemm_group`` + ``fwn_wn_backward_group`` (weight gradients: K = rows, partials summed in a fixed
 order), and the element-wise ``fwn_*_bwd`` kernels.  The sequencing is Python; every activation-sized
 arithmetic step runs in ``libfwn.so`` and there is no fallback path.
 """
@@ -117,6 +117,60 @@ def tn_weight_grad_partials(x, dy, m, kx, n, *, shifts=(0,), ti=0, nsplit=None, 
                                dy.data_ptr(), int(dy.stride(0)), int(n), int(m), int(ti), int(nsplit), part.data_ptr(),
                                int(part.stride(0)), int(bool(bias_row)), _stream(x)), "fwn_tn_gemm")
     return part
+
+
+def tn_group_splits(specs, m):
+    """Splits of the row range for a group of weight-gradient GEMMs ``(kx, n, ntap)``: as many as keep the whole
+    group within ONE round of workgroups (a workgroup per CU), so every GEMM writes few partials."""
+    tiles = sum(ntap * ((kx + 127) // 128) * ((n + 127) // 128) for kx, n, ntap in specs)
+    return max(1, min((m + 63) // 64, 256 // max(1, tiles)))
+
+
+def tn_weight_grad_group(jobs, m, ti=0, nsplit=None):
+    """``jobs``: list of ``(x, dy, kx, n, shifts)`` sharing m and ti.  One launch (``fwn_tn_gemm_group``); returns the
+    fp32 partials ``[S, len(shifts)*kx + 1, n]`` of every job (views of one buffer; last row = bias gradient)."""
+    import torch
+    lib = _lib.load()
+    if len(jobs) > _lib.FWN_MAX_GROUP:
+        return (tn_weight_grad_group(jobs[:_lib.FWN_MAX_GROUP], m, ti, nsplit) +
+                tn_weight_grad_group(jobs[_lib.FWN_MAX_GROUP:], m, ti, nsplit))
+    if nsplit is None:
+        nsplit = tn_group_splits([(kx, n, len(sh)) for _, _, kx, n, sh in jobs], m)
+    sizes = [(len(sh) * kx + 1) * n for _, _, kx, n, sh in jobs]
+    buf = torch.empty(nsplit * sum(sizes), dtype=torch.float32, device=jobs[0][0].device)
+    arr = (_lib.TnJob * len(jobs))()
+    parts, off = [], 0
+    for q, (x, dy, kx, n, sh), size in zip(arr, jobs, sizes):
+        part = buf[off:off + nsplit * size].view(nsplit, len(sh) * kx + 1, n)
+        off += nsplit * size
+        parts.append(part)
+        q.x, q.dy, q.part, q.split_stride = x.data_ptr(), dy.data_ptr(), part.data_ptr(), size
+        q.ldx, q.Kx, q.ntap, q.shift0 = int(x.stride(0)), int(kx), len(sh), int(sh[0])
+        q.dshift = int(sh[1] - sh[0]) if len(sh) > 1 else 0
+        q.ldy, q.N, q.nsplit, q.bias_row = int(dy.stride(0)), int(n), int(nsplit), 1
+    _lib.check(lib.fwn_tn_gemm_group(arr, len(jobs), int(m), int(ti), _stream(jobs[0][0])), "fwn_tn_gemm_group")
+    return parts
+
+
+def wn_backward_group(jobs):
+    """``jobs``: list of dicts(part [S, rows, ldp], k, n, col0, bias_row (-1: none), scale, row_src, v, g, dv, dg, db):
+    split reduction + weight-norm backward of all of them in two launches (``fwn_wn_backward_group``)."""
+    import torch
+    lib = _lib.load()
+    for i0 in range(0, len(jobs), _lib.FWN_MAX_GROUP):
+        chunk = jobs[i0:i0 + _lib.FWN_MAX_GROUP]
+        arr = (_lib.WnJob * len(chunk))()
+        for q, j in zip(arr, chunk):
+            part = j["part"]
+            q.part, q.split_stride, q.nsplit, q.ldp = part.data_ptr(), int(part.stride(0)), int(part.shape[0]), int(part.shape[2])
+            q.row_src = j["row_src"].data_ptr() if j.get("row_src") is not None else None
+            q.col0, q.bias_row, q.K, q.N, q.scale = int(j.get("col0", 0)), int(j.get("bias_row", -1)), int(j["k"]), int(j["n"]), float(j.get("scale", 1.0))
+            q.V = j["v"].data_ptr() if j.get("v") is not None else None
+            q.g = j["g"].data_ptr() if j.get("g") is not None else None
+            q.dV, q.dg = j["dv"].data_ptr(), j["dg"].data_ptr() if j.get("dg") is not None else None
+            q.db = j["db"].data_ptr() if j.get("db") is not None else None
+        scr = torch.empty(int(lib.fwn_wn_group_scratch(arr, len(chunk))), dtype=torch.float64, device=chunk[0]["part"].device)
+        _lib.check(lib.fwn_wn_backward_group(arr, len(chunk), scr.data_ptr(), _stream(chunk[0]["part"])), "fwn_wn_backward_group")
 
 
 def colsum_bf16(dy, m, n, scale=1.0, out=None):
@@ -526,32 +580,42 @@ class GradEngine:
             grads[wp + "/ZeroConv1d/kernel"] = g_wz.view(1, 256, 2 * ch)
             grads[wp + "/ZeroConv1d/bias"] = g_bz
             du = gemm([(dz, ldz, 0, 0)], t["WzT"], 256, m, mask=u_act)
-            self._wn(grads, wp + "/Conv_final", tn_weight_grad_partials(s_act, du, m, 256, 256), 256, 0, (1, 256, 256))
+            # the weight gradients of the flow are collected and run as ONE grouped GEMM + ONE grouped weight-norm
+            # backward at the end of the flow (their operands stay alive until then)
+            tnj, wnj = [], []
+
+            def wgrad(x_, dy_, kx, n, shifts=(0,)):
+                tnj.append((x_, dy_, kx, n, shifts))
+                return len(tnj) - 1
+
+            def wn(name, job, k, col0, shape, scale=1.0, row_src=None):
+                wnj.append((name, job, k, col0, shape, scale, row_src))
+
+            wn(wp + "/Conv_final", wgrad(s_act, du, 256, 256), 256, 0, (1, 256, 256))
             ds = gemm([(du, 256, 0, 0)], t["WfinT"], 256, m, mask=s_act)
             d_o = []
             for l in range(L):
                 rp = "%s/ResBlock_%d" % (wp, l)
-                self._wn(grads, rp + "/skip_conv", tn_weight_grad_partials(o[l], ds, m, 256, 256), 256, 0, (1, 256, 256))
+                wn(rp + "/skip_conv", wgrad(o[l], ds, 256, 256), 256, 0, (1, 256, 256))
                 d_o.append(gemm([(ds, 256, 0, 0)], t["WskipT"][l], 256, m))
             dh_next = None
             for l in range(L - 1, -1, -1):
                 rp = "%s/ResBlock_%d" % (wp, l)
                 dil = 3 ** l
                 if dh_next is not None:      # h_{l+1} = (h_l + res(o_l)) sqrt(1/2)
-                    self._wn(grads, rp + "/res_conv", tn_weight_grad_partials(o[l], dh_next, m, 256, 256), 256, 0, (1, 256, 256),
-                             scale=SQH)
+                    wn(rp + "/res_conv", wgrad(o[l], dh_next, 256, 256), 256, 0, (1, 256, 256), scale=SQH)
                     d_o[l] = gemm([(dh_next, 256, 0, 0)], t["WresT"][l], 256, m, res=d_o[l], rscale=1.0 / SQH, oscale=SQH)
                 else:
                     for nm in ("kernel", "g", "bias"):      # dead res_conv of the last layer (modules.py:126-128)
                         grads["%s/res_conv/%s" % (rp, nm)] = torch.zeros(shp["%s/res_conv/%s" % (rp, nm)], dtype=torch.float32, device=dev)
                 dpre = b16(m, 512)
                 self._call("fwn_gate_bwd", d_o[l].data_ptr(), aux[l].data_ptr(), m, dpre.data_ptr(), st)
-                part = tn_weight_grad_partials(h[l], dpre, m, 256, 512, shifts=(-dil, 0, dil), ti=ti)
-                self._wn(grads, rp + "/Conv_filter", part, 768, 0, (3, 256, 256))
-                self._wn(grads, rp + "/Conv_gate", part, 768, 256, (3, 256, 256))
-                part = tn_weight_grad_partials(ca, dpre, m, cin, 512)
-                self._wn(grads, rp + "/filter_conv_c", part, cin, 0, (1, cin, 256), row_src=tp.cond_rows[i])
-                self._wn(grads, rp + "/gate_conv_c", part, cin, 256, (1, cin, 256), row_src=tp.cond_rows[i])
+                jd = wgrad(h[l], dpre, 256, 512, (-dil, 0, dil))
+                wn(rp + "/Conv_filter", jd, 768, 0, (3, 256, 256))
+                wn(rp + "/Conv_gate", jd, 768, 256, (3, 256, 256))
+                jc = wgrad(ca, dpre, cin, 512)
+                wn(rp + "/filter_conv_c", jc, cin, 0, (1, cin, 256), row_src=tp.cond_rows[i])
+                wn(rp + "/gate_conv_c", jc, cin, 256, (1, cin, 256), row_src=tp.cond_rows[i])
                 gemm([(dpre, 512, 0, 0)], t["WcT"][l], cin, m, out=dca, accumulate=True)
                 segs = [(dpre, 512, -(tap - 1) * dil, tap * 512) for tap in range(3)]
                 dh = gemm(segs, t["WdT"][l], 256, m, ti=ti, res=dh_next, rscale=SQH if dh_next is not None else 0.0,
@@ -560,11 +624,13 @@ class GradEngine:
             # front conv
             ya_bf = xa.to(torch.bfloat16)
             if ch % 8 == 0:
-                part = tn_weight_grad_partials(ya_bf, dh_next, m, ch, 256, shifts=(-1, 0, 1), ti=ti)
-                self._wn(grads, wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
+                wn(wp + "/Conv_front", wgrad(ya_bf, dh_next, ch, 256, (-1, 0, 1)), 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
             else:       # rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
                 part = weight_grad_partials(ya_bf, m, ch, transpose_shift(dh_next, m, 256), 256, shifts=(-1, 0, 1), ti=ti)
-                self._wn(grads, wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
+                wn(wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
+            parts = tn_weight_grad_group(tnj, m, ti)
+            self._wn_group(grads, [(nm, parts[jb] if isinstance(jb, int) else jb, k_, c0_, shp_, sc_, rs_)
+                                   for nm, jb, k_, c0_, shp_, sc_, rs_ in wnj])
             segs = [(dh_next, 256, -(tap - 1), tap * 256) for tap in range(3)]
             gemm(segs, t["WfT"], ch, m, ti=ti, out=ga, accumulate=True)
             # ActNorm (both planes), back to the flow's inputs
@@ -597,8 +663,7 @@ class GradEngine:
             v = torch.as_tensor(params["upsample_%d/kernel" % n]).to(device=dev, dtype=torch.float32).reshape(2 * s_, 3).contiguous()
             g3 = torch.as_tensor(params["upsample_%d/g" % n]).to(device=dev, dtype=torch.float32).reshape(1).expand(3).contiguous()
             dv, dg3 = f32(2 * s_, 3), f32(3)
-            self._call("fwn_wn_backward", dwk.data_ptr(), 1, 0, 3, None, 0, -1, 1.0, v.data_ptr(), g3.data_ptr(), 2 * s_, 3,
-                       dv.data_ptr(), dg3.data_ptr(), None, st)
+            wn_backward_group([dict(part=dwk.view(1, 2 * s_, 3), k=2 * s_, n=3, v=v, g=g3, dv=dv, dg=dg3)])
             grads["upsample_%d/kernel" % n] = dv.view(2 * s_, 3, 1, 1)
             grads["upsample_%d/g" % n] = dg3.sum().view(1)      # the three kw columns share one scalar g (convolutional.py:186)
             grads["upsample_%d/bias" % n] = dbias
@@ -619,29 +684,27 @@ class GradEngine:
                 go[k].copy_(grads[k].reshape(go[k].shape))
                 grads[k] = go[k]
 
-    def _wn(self, grads, name, part, k, col0, shape, scale=1.0, row_src=None, db=None):
-        """Split-K partials of a weight-gradient GEMM (fp32 [S][rows (+ 1)][ncols]) -> gradients of a weight-normed
-        conv's kernel, g and bias (one launch, summing the partials in a fixed order).  db None: the bias gradient is
-        the partials' last row (the ones row of the transposed-copy path); else the given column sums."""
+    def _wn_group(self, grads, items):
+        """items: ``(name, part, k, col0, shape, scale, row_src)`` - split-K partials of a weight-gradient GEMM (fp32
+        [S][rows + 1][ncols], bias gradient in the last row) -> gradients of a weight-normed conv's kernel, g and bias,
+        written straight into grad_out where that is contiguous."""
         import torch
-        dev = part.device
-        v, g = self._tp._f32(name + "/kernel"), self._tp._f32(name + "/g")
-        n = int(v.shape[-1])
-        go = self._gout
-        if go is not None and go[name + "/kernel"].is_contiguous():
-            dv, dg, dbo = go[name + "/kernel"].view(k, n), go[name + "/g"], go[name + "/bias"]
-        else:
-            dv = torch.empty(k, n, dtype=torch.float32, device=dev)
-            dg, dbo = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
-        self._call("fwn_wn_backward", part.data_ptr(), int(part.shape[0]), int(part.stride(0)), int(part.shape[2]),
-                   row_src.data_ptr() if row_src is not None else None, int(col0), int(part.shape[1]) - 1 if db is None else -1,
-                   float(scale), v.data_ptr(), g.data_ptr(), k, n, dv.data_ptr(), dg.data_ptr(),
-                   dbo.data_ptr() if db is None else None, _stream(part))
-        if db is not None:
-            dbo.copy_(db)
-        grads[name + "/kernel"] = dv.view(shape)
-        grads[name + "/g"] = dg
-        grads[name + "/bias"] = dbo
+        go, jobs = self._gout, []
+        for name, part, k, col0, shape, scale, row_src in items:
+            dev = part.device
+            v, g = self._tp._f32(name + "/kernel"), self._tp._f32(name + "/g")
+            n = int(v.shape[-1])
+            if go is not None and go[name + "/kernel"].is_contiguous():
+                dv, dg, dbo = go[name + "/kernel"].view(k, n), go[name + "/g"], go[name + "/bias"]
+            else:
+                dv = torch.empty(k, n, dtype=torch.float32, device=dev)
+                dg, dbo = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+            jobs.append(dict(part=part, k=k, n=n, col0=col0, bias_row=int(part.shape[1]) - 1, scale=scale, row_src=row_src,
+                             v=v, g=g, dv=dv, dg=dg, db=dbo))
+            grads[name + "/kernel"] = dv.view(shape)
+            grads[name + "/g"] = dg
+            grads[name + "/bias"] = dbo
+        wn_backward_group(jobs)
 
 
 class Trainer:
