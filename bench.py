@@ -220,6 +220,9 @@ def main():
             cur.wait_stream(st)
         return nll, wav
 
+    # reference for the result check below: one pass of each direction alone on the current stream
+    ref_nll = torch.stack(model.forward(x, c)).clone()
+    ref_wav = model.reverse(z, c).clone()
     run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
@@ -237,6 +240,10 @@ def main():
         allreduce(tmax, dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert bool(torch.isfinite(nll).all()) and bool(torch.isfinite(wav).all())
+    # the overlapped passes of the timed region must reproduce the single-stream result bit for bit
+    same = bool(torch.equal(wav, ref_wav)) and (world > 1 or bool(torch.equal(nll, ref_nll)))
+    if not same:
+        raise SystemExit("bench.py: the overlapped passes differ from the single-stream result")
 
     # per-direction timings (HIP events on the launch stream), rank 0, for the breakdown fields
     def timed(fn, n=5):
@@ -264,7 +271,8 @@ def main():
                        "clips_per_gpu": b, "samples_per_clip": t, "samples_per_step_per_gpu": 2 * b * t,
                        "weights": "synthetic seed 1234, ActNorm DDI on first batch",
                        "parallelism": "batch shard x%d, no data-path collective (2-scalar NLL all-reduce)" % world,
-                       "streams": "serial" if args.serial else "%d per direction" % args.lanes},
+                       "streams": "serial" if args.serial else "%d per direction" % args.lanes,
+                       "results": "last step bit-identical to the single-stream pass"},
             "fwd_samples_per_s": b * t / fwd_s, "inv_samples_per_s": b * t / inv_s,
             "fwd_ms": fwd_s * 1e3, "inv_ms": inv_s * 1e3,
             "model_tflops": value / world * fps / 1e12,

@@ -355,6 +355,28 @@ def test_full_size_inverse_is_deterministic_and_bounded(full_model):
     assert bool(torch.isfinite(w1).all())
 
 
+def test_concurrent_streams_reproduce_the_serial_result(full_model):
+    """bench.py overlaps passes on several HIP streams: kernels of different kinds then share CUs.  Every pass
+    must still equal the single-stream result bit for bit (regression: SLP-vectorised packed fp32 math in the
+    VALU front conv returned wrong lanes whenever another kernel was co-resident - csrc/Makefile)."""
+    hp, model, x, c, z = full_model
+    xs, cs, zs = x[:2, :6400], c[:2, :6400 // hp.hop_size], z[:2, :6400]
+    ref_wav = model.reverse(zs, cs).clone()
+    ref_nll = torch.stack(model.forward(xs, cs)).clone()
+    torch.cuda.synchronize()
+    lanes = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    for k in range(16):
+        with torch.cuda.stream(lanes[k % 4]):
+            if k % 2:
+                outs.append(("inv", model.reverse(zs, cs).clone()))
+            else:
+                outs.append(("fwd", torch.stack(model.forward(xs, cs)).clone()))
+    torch.cuda.synchronize()
+    for kind, got in outs:
+        assert torch.equal(got, ref_wav if kind == "inv" else ref_nll), kind
+
+
 def test_ten_second_clip_inverse_runs(full_model):
     """BASELINE configs[3]: 10 s @ 22.05 kHz (T = 220672 = 862 frames), one clip."""
     hp, model, x, c, z = full_model
