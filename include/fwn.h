@@ -231,6 +231,15 @@ int fwn_colsum_partials(int64_t M, int C);
 int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C, float scale, float* partial, float* out,
                     void* stream);
 int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, void* stream);
+/* The parameter-sized gradients around a flow's ActNorm, fused (two launches): for both planes (g, y = ActNorm
+ * output; an [2][4][Ch]) s1 = sum_m g, s2 = sum_m g y, then fwn_actnorm_bwd in place; z = column sums of dzz
+ * [M][2 Ch].  Outputs in the parameters' order through the index tables br [Ch] / zc [2 Ch] (int64, device):
+ * db[role Ch + br[c]] = s1 scale, dlogs[role Ch + br[c]] = 3 s2 - 3/(2 Ch), dzscale[zc[j]] = 3 z[j].
+ * partial: fwn_flow_small_grads_partials(M, Ch) doubles.  Ch: power of two <= 128. */
+int64_t fwn_flow_small_grads_partials(int64_t M, int Ch);
+int fwn_flow_small_grads(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, int64_t M, int Ch,
+                         const int64_t* br, const int64_t* zc, double* partial, float* db, float* dlogs, float* dzscale,
+                         void* stream);
 
 /* Backward of one up-sampling stage (fwn_upsample_stage with fp32 output): y, dy [B][H*s][W], x [B][H][W].
  * dy <- dy * LeakyReLU'(y) in place; dx (may be NULL) <- gradient wrt x; dwk_bias [6s + 1] <- gradients of
@@ -260,6 +269,7 @@ typedef struct fwn_wn_job {
     const float* part; const int32_t* row_src; const float* V; const float* g; float* dV; float* dg; float* db;
     int64_t split_stride;
     int32_t nsplit, ldp, col0, bias_row, K, N; float scale; int32_t reserved;
+    const int32_t* col_src;      /* NULL, or output column n reads partial column col0 + col_src[n] (a column permutation) */
 } fwn_wn_job;
 /* fwn_wn_backward for every job of the group (two launches); scratch: fwn_wn_group_scratch(jobs, njobs) doubles. */
 int64_t fwn_wn_group_scratch(const fwn_wn_job* jobs, int njobs);

@@ -114,7 +114,7 @@ def test_training_primitives_validate_their_arguments(lib):
     assert lib.fwn_wn_backward_group(wj, _lib.FWN_MAX_GROUP + 1, None, None) == -1
     tj = (_lib.TnJob * 1)()
     assert lib.fwn_tn_gemm_group(tj, 1, 64, 0, None) == -1 and b"job 0" in lib.fwn_last_error()
-    assert C.sizeof(_lib.TnJob) == 72 and C.sizeof(_lib.WnJob) == 96
+    assert C.sizeof(_lib.TnJob) == 72 and C.sizeof(_lib.WnJob) == 104
     assert lib.fwn_upsample_bwd(1 << 20, 1 << 20, 1 << 20, 1, 4, 8, 3, 1 << 20, None, 1 << 20, 1 << 20, None) == -1   # odd s
     assert lib.fwn_mel_spectrogram(1 << 20, 1, 4096, 1 << 20, 1 << 20, 1000, 256, 80, 20.0, -100.0, 1 << 20, None) == -1
     assert b"power of two" in lib.fwn_last_error()

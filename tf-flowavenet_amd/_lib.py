@@ -79,7 +79,7 @@ class WnJob(C.Structure):
     _fields_ = [("part", C.c_void_p), ("row_src", C.c_void_p), ("V", C.c_void_p), ("g", C.c_void_p), ("dV", C.c_void_p),
                 ("dg", C.c_void_p), ("db", C.c_void_p), ("split_stride", C.c_int64),
                 ("nsplit", C.c_int32), ("ldp", C.c_int32), ("col0", C.c_int32), ("bias_row", C.c_int32), ("K", C.c_int32),
-                ("N", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32)]
+                ("N", C.c_int32), ("scale", C.c_float), ("reserved", C.c_int32), ("col_src", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):
@@ -130,6 +130,8 @@ SIGNATURES = {
     "fwn_colsum_partials": (C.c_int, [i64, C.c_int]),
     "fwn_colsum_prod": (C.c_int, [vp, vp, i64, C.c_int, C.c_float, vp, vp, vp]),
     "fwn_actnorm_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
+    "fwn_flow_small_grads_partials": (i64, [i64, C.c_int]),
+    "fwn_flow_small_grads": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "fwn_tn_gemm_group": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "fwn_wn_group_scratch": (i64, [vp, C.c_int]),
     "fwn_wn_backward_group": (C.c_int, [vp, C.c_int, vp, vp]),

@@ -318,6 +318,19 @@ int fwn_actnorm_bwd(float* dy, float* y, const float* an, int64_t n, int Ch, voi
     fwn_ew_actnorm_bwd(dy, y, an, (long)n, Ch, (hipStream_t)stream);
     return check_launch("fwn_actnorm_bwd");
 }
+int64_t fwn_flow_small_grads_partials(int64_t M, int Ch) {
+    if (M <= 0 || Ch <= 0) return 0;
+    return (int64_t)fwn_small_grads_blocks((long)M, Ch) * 6 * Ch;
+}
+int fwn_flow_small_grads(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, int64_t M, int Ch,
+                         const int64_t* br, const int64_t* zc, double* partial, float* db, float* dlogs, float* dzscale,
+                         void* stream) {
+    REQUIRE(ga && ya && gb && yb && dzz && an && br && zc && partial && db && dlogs && dzscale, "fwn_flow_small_grads: null pointer");
+    REQUIRE(M > 0 && Ch >= 1 && Ch <= 128 && (Ch & (Ch - 1)) == 0, "fwn_flow_small_grads: Ch must be a power of two <= 128");
+    fwn_small_grads_launch(ga, ya, gb, yb, dzz, an, (long)M, Ch, (const long long*)br, (const long long*)zc, partial, db, dlogs,
+                           dzscale, (hipStream_t)stream);
+    return check_launch("fwn_flow_small_grads");
+}
 static bool wn_job_ok(const fwn_wn_job& q) {
     return q.part && q.dV && q.K > 0 && q.N > 0 && q.nsplit >= 1 && q.col0 >= 0 && q.ldp >= q.col0 + q.N && (!q.g || (q.V && q.dg));
 }

@@ -53,6 +53,10 @@ int fwn_colsum_blocks(long M, int C);
 void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* partial, float* out,
                         hipStream_t st);
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st);
+int fwn_small_grads_blocks(long M, int Ch);
+void fwn_small_grads_launch(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
+                            const long long* br, const long long* zc, double* partial, float* db, float* dlogs,
+                            float* dzscale, hipStream_t st);
 struct fwn_wn_job;
 struct fwn_tn_job;
 long fwn_wn_group_scratch_doubles(const fwn_wn_job* jobs, int njobs);

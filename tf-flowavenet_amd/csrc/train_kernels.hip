@@ -271,6 +271,72 @@ __global__ __launch_bounds__(256) void actnorm_bwd_kernel(float* __restrict__ dy
         y[i] = y[i] * an[2 * Ch + c] - an[c];
     }
 }
+// ---- the parameter-sized gradients around a flow's ActNorm in two launches (model.py:86-94, modules.py:51-56) ----
+// s1[role][c] = sum_m g[m][c], s2[role][c] = sum_m g[m][c] y[m][c] (y = ActNorm OUTPUT of plane role), then in
+// place g <- g * scale, y <- y * iscale - shift (back to the flow's input);  z[j] = sum_m dzz[m][j] (ZeroConv
+// scale).  Pass 1: a workgroup owns a contiguous row range; 256 is a multiple of Ch and 2 Ch, so a thread stays on
+// one column; fp64 sums, fixed order.  Pass 2 totals the row ranges and scatters into the parameters' order:
+// db[role Ch + br[c]] = s1 scale[c], dlogs[role Ch + br[c]] = 3 s2 - 3 / (2 Ch), dzscale[zc[j]] = 3 z[j].
+__global__ __launch_bounds__(256) void flow_small_grads_kernel(float* __restrict__ ga, float* __restrict__ ya,
+                                                               float* __restrict__ gb, float* __restrict__ yb,
+                                                               const float* __restrict__ dzz, const float* __restrict__ an,
+                                                               long M, int Ch, double* __restrict__ partial) {
+    __shared__ double red[5][256];
+    const int t = threadIdx.x;
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per, r1 = min(M, r0 + per);
+    const int c = t & (Ch - 1);
+    const float sh_a = an[c], sc_a = an[Ch + c], is_a = an[2 * Ch + c];
+    const float sh_b = an[4 * Ch + c], sc_b = an[5 * Ch + c], is_b = an[6 * Ch + c];
+    double s1a = 0.0, s2a = 0.0, s1b = 0.0, s2b = 0.0, sz = 0.0;
+    for (long i = r0 * Ch + t; i < r1 * Ch; i += 256) {
+        const float g0 = ga[i], y0 = ya[i], g1 = gb[i], y1 = yb[i];
+        s1a += g0; s2a += (double)g0 * y0;
+        s1b += g1; s2b += (double)g1 * y1;
+        ga[i] = g0 * sc_a; ya[i] = y0 * is_a - sh_a;
+        gb[i] = g1 * sc_b; yb[i] = y1 * is_b - sh_b;
+    }
+    for (long i = r0 * 2 * Ch + t; i < r1 * 2 * Ch; i += 256) sz += dzz[i];
+    red[0][t] = s1a; red[1][t] = s2a; red[2][t] = s1b; red[3][t] = s2b; red[4][t] = sz;
+    __syncthreads();
+    double* o = partial + (size_t)blockIdx.x * 6 * Ch;
+    for (int idx = t; idx < 6 * Ch; idx += 256) {
+        const int q = idx < 4 * Ch ? idx / Ch : 4, col = idx < 4 * Ch ? idx % Ch : idx - 4 * Ch, period = q < 4 ? Ch : 2 * Ch;
+        double a = 0.0;
+        for (int k = col; k < 256; k += period) a += red[q][k];
+        o[idx] = a;
+    }
+}
+__global__ __launch_bounds__(256) void flow_small_grads_final_kernel(const double* __restrict__ partial, int nb, int Ch,
+                                                                     const float* __restrict__ an,
+                                                                     const long long* __restrict__ br,
+                                                                     const long long* __restrict__ zc, float* __restrict__ db,
+                                                                     float* __restrict__ dlogs, float* __restrict__ dzscale) {
+    for (int idx = threadIdx.x; idx < 6 * Ch; idx += 256) {
+        double a = 0.0;
+        for (int b = 0; b < nb; ++b) a += partial[(size_t)b * 6 * Ch + idx];
+        if (idx < 4 * Ch) {
+            const int role = idx / (2 * Ch), which = (idx / Ch) & 1, c = idx % Ch;
+            const int dst = role * Ch + (int)br[c];
+            if (which == 0) db[dst] = (float)a * an[role * 4 * Ch + Ch + c];
+            else dlogs[dst] = (float)(3.0 * a) - 3.0f / (2.0f * Ch);
+        } else {
+            dzscale[zc[idx - 4 * Ch]] = (float)(3.0 * a);
+        }
+    }
+}
+int fwn_small_grads_blocks(long M, int Ch) {
+    long nb = M * Ch / 4096;
+    return (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
+}
+void fwn_small_grads_launch(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
+                            const long long* br, const long long* zc, double* partial, float* db, float* dlogs,
+                            float* dzscale, hipStream_t st) {
+    const int nb = fwn_small_grads_blocks(M, Ch);
+    hipLaunchKernelGGL(flow_small_grads_kernel, dim3(nb), dim3(256), 0, st, ga, ya, gb, yb, dzz, an, M, Ch, partial);
+    hipLaunchKernelGGL(flow_small_grads_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, Ch, an, br, zc, db, dlogs, dzscale);
+}
+
 // Weight-norm backward (convolutional.py:73-80): W = V g / ||V||_col, straight from the split-K partials.
 // ---- weight-norm backward of a GROUP of convolutions (all weight gradients of one flow) in two launches ----
 // part: split-K partials fp32 [S][rows][ldp] of a weight-gradient GEMM.  dW[k][n] = scale * sum_s part[s][row_src ?
@@ -311,14 +377,15 @@ __global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double
     if (PASS == 1) {
         double ss = 0.0, dot = 0.0;
         if (n < q.N) {
+            const int sn = q.col0 + (q.col_src ? q.col_src[n] : n);          // source column of output column n
             if (kc == 0 && w == 0 && q.db && q.bias_row >= 0)
-                q.db[n] = q.scale * wn_sum_splits(q.part + (size_t)q.bias_row * q.ldp + q.col0 + n, q.nsplit, (long)q.split_stride);
+                q.db[n] = q.scale * wn_sum_splits(q.part + (size_t)q.bias_row * q.ldp + sn, q.nsplit, (long)q.split_stride);
 #pragma unroll 2
             for (int i = 0; i < 8; ++i) {
                 const int k = kc * 32 + w + 4 * i;
                 if (k >= q.K) break;
                 const int src = q.row_src ? q.row_src[k] : k;
-                const float d = q.scale * wn_sum_splits(q.part + (size_t)src * q.ldp + q.col0 + n, q.nsplit, (long)q.split_stride);
+                const float d = q.scale * wn_sum_splits(q.part + (size_t)src * q.ldp + sn, q.nsplit, (long)q.split_stride);
                 q.dV[(size_t)k * q.N + n] = d;
                 if (q.g) {
                     const double v = q.V[(size_t)k * q.N + n];
@@ -346,13 +413,12 @@ __global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double
         }
         const double nrm = sqrt(fmax(ss, 1e-12)), dgn = dot / nrm;
         if (kc == 0 && w == 0) q.dg[n] = (float)dgn;
-        const double gn = (double)q.g[n] / nrm;
-#pragma unroll 2
+        const double gn = (double)q.g[n] / nrm, dn = dgn / nrm;        // per column: no division per element
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = kc * 32 + w + 4 * i;
-            if (k >= q.K) break;
             const size_t e = (size_t)k * q.N + n;
-            q.dV[e] = (float)(gn * ((double)q.dV[e] - (double)q.V[e] * dgn / nrm));
+            if (k < q.K) q.dV[e] = (float)(gn * ((double)q.dV[e] - (double)q.V[e] * dn));
         }
     }
 }

@@ -164,6 +164,7 @@ def wn_backward_group(jobs):
             part = j["part"]
             q.part, q.split_stride, q.nsplit, q.ldp = part.data_ptr(), int(part.stride(0)), int(part.shape[0]), int(part.shape[2])
             q.row_src = j["row_src"].data_ptr() if j.get("row_src") is not None else None
+            q.col_src = j["col_src"].data_ptr() if j.get("col_src") is not None else None
             q.col0, q.bias_row, q.K, q.N, q.scale = int(j.get("col0", 0)), int(j.get("bias_row", -1)), int(j["k"]), int(j["n"]), float(j.get("scale", 1.0))
             q.V = j["v"].data_ptr() if j.get("v") is not None else None
             q.g = j["g"].data_ptr() if j.get("g") is not None else None
@@ -307,6 +308,7 @@ class _TrainPack:
         job(wp + "/Conv_final", id256, 256, id256, 256, t["WfinT"], 0, True)
         zcol = np.concatenate([br, ch + br])
         t["zcol"] = self._i64(("zcol", i), zcol)
+        t["zinv32"] = self._i32(("zinv", i), np.argsort(zcol))
         zc32 = self._i32(("zcol", i), zcol)
         n2 = 2 * ch
         t["ldz"] = max(8, n2)
@@ -401,6 +403,7 @@ class _TrainPack:
         # ZeroConv rows in plane order: row fg*Ch + tau serves logical channel fg*Ch + bitrev(tau)
         zcol = np.concatenate([br, ch + br])
         t["zcol"] = self._i64(("zcol", i), zcol)
+        t["zinv32"] = self._i32(("zinv", i), np.argsort(zcol))
         n2 = 2 * ch
         ldz = max(8, n2)
         wz = bz(n2, 256)
@@ -463,7 +466,7 @@ class GradEngine:
         st = torch.cuda.current_stream(dev).cuda_stream
         _STREAMS.clear()
         _STREAMS[torch.zeros(0, device=dev).device] = st
-        shp = weights.param_shapes(hp)
+        shp = self._shapes = weights.param_shapes(hp)
         key = tuple(v.data_ptr() for v in list(params.values())[:4]) if all(hasattr(v, "data_ptr") for v in list(params.values())[:4]) else None
         tp = getattr(self, "_tp", None)
         if tp is not None and tp.plan is not None and key is not None and getattr(self, "_tp_key", None) == key:
@@ -568,17 +571,6 @@ class GradEngine:
             dzz = f32(m, 2 * ch)
             self._call("fwn_coupling_bwd", gb.data_ptr(), xb.data_ptr(), z.data_ptr(), t["ez"].data_ptr(), m, ch,
                        1.0 / (2.0 * m * ch), dz.data_ptr(), ldz, dzz.data_ptr(), st)
-            dscale = f32(2 * ch)
-            scratch = f32(max(lib.fwn_colsum_partials(m, 2 * ch), lib.fwn_colsum_partials(m, ch)))
-            self._call("fwn_colsum_prod", dzz.data_ptr(), None, m, 2 * ch, 3.0, scratch.data_ptr(), dscale.data_ptr(), st)
-            zc = t["zcol"]
-            g_scale = f32(2 * ch); g_scale[zc] = dscale
-            grads[wp + "/ZeroConv1d/scale"] = g_scale.view(1, 1, -1)
-            dwz, dbz = weight_grad(u_act, dz, m, 256, 2 * ch)
-            g_wz = f32(256, 2 * ch); g_wz[:, zc] = dwz
-            g_bz = f32(2 * ch); g_bz[zc] = dbz
-            grads[wp + "/ZeroConv1d/kernel"] = g_wz.view(1, 256, 2 * ch)
-            grads[wp + "/ZeroConv1d/bias"] = g_bz
             du = gemm([(dz, ldz, 0, 0)], t["WzT"], 256, m, mask=u_act)
             # the weight gradients of the flow are collected and run as ONE grouped GEMM + ONE grouped weight-norm
             # backward at the end of the flow (their operands stay alive until then)
@@ -588,9 +580,11 @@ class GradEngine:
                 tnj.append((x_, dy_, kx, n, shifts))
                 return len(tnj) - 1
 
-            def wn(name, job, k, col0, shape, scale=1.0, row_src=None):
-                wnj.append((name, job, k, col0, shape, scale, row_src))
+            def wn(name, job, k, col0, shape, scale=1.0, row_src=None, col_src=None):
+                wnj.append((name, job, k, col0, shape, scale, row_src, col_src))
 
+            # ZeroConv1d (no weight norm): columns back to the reference's channel order through col_src
+            wn(wp + "/ZeroConv1d", wgrad(u_act, dz, 256, ldz), 256, 0, (1, 256, 2 * ch), col_src=t["zinv32"])
             wn(wp + "/Conv_final", wgrad(s_act, du, 256, 256), 256, 0, (1, 256, 256))
             ds = gemm([(du, 256, 0, 0)], t["WfinT"], 256, m, mask=s_act)
             d_o = []
@@ -629,21 +623,21 @@ class GradEngine:
                 part = weight_grad_partials(ya_bf, m, ch, transpose_shift(dh_next, m, 256), 256, shifts=(-1, 0, 1), ti=ti)
                 wn(wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
             parts = tn_weight_grad_group(tnj, m, ti)
-            self._wn_group(grads, [(nm, parts[jb] if isinstance(jb, int) else jb, k_, c0_, shp_, sc_, rs_)
-                                   for nm, jb, k_, c0_, shp_, sc_, rs_ in wnj])
+            self._wn_group(grads, [(nm, parts[jb] if isinstance(jb, int) else jb, k_, c0_, shp_, sc_, rs_, cs_)
+                                   for nm, jb, k_, c0_, shp_, sc_, rs_, cs_ in wnj])
             segs = [(dh_next, 256, -(tap - 1), tap * 256) for tap in range(3)]
             gemm(segs, t["WfT"], ch, m, ti=ti, out=ga, accumulate=True)
-            # ActNorm (both planes), back to the flow's inputs
-            g_b, g_logs = f32(2 * ch), f32(2 * ch)
-            for role, (yy, gg) in enumerate(((xa, ga), (xb, gb))):
-                s1, s2 = f32(ch), f32(ch)
-                self._call("fwn_colsum_prod", gg.data_ptr(), None, m, ch, 1.0, scratch.data_ptr(), s1.data_ptr(), st)
-                self._call("fwn_colsum_prod", gg.data_ptr(), yy.data_ptr(), m, ch, 3.0, scratch.data_ptr(), s2.data_ptr(), st)
-                g_b[role * ch + br] = s1 * an[role, 1]
-                g_logs[role * ch + br] = s2 - 3.0 / (2 * ch)
-                self._call("fwn_actnorm_bwd", gg.data_ptr(), yy.data_ptr(), an[role].data_ptr(), m * ch, ch, st)
-            grads[fp + "/ActNorm/b"] = g_b.view(1, 1, -1)
-            grads[fp + "/ActNorm/logs"] = g_logs.view(1, 1, -1)
+            # ActNorm of both planes back to the flow's inputs, with its b / logs gradients and the ZeroConv scale
+            # gradient (three parameter-sized reductions) in the same two launches
+            go = self._gout
+            names = (fp + "/ActNorm/b", fp + "/ActNorm/logs", wp + "/ZeroConv1d/scale")
+            outs = [go[nm].view(-1) if go is not None and go[nm].is_contiguous() else f32(2 * ch) for nm in names]
+            scr = torch.empty(int(lib.fwn_flow_small_grads_partials(m, ch)), dtype=torch.float64, device=dev)
+            self._call("fwn_flow_small_grads", ga.data_ptr(), xa.data_ptr(), gb.data_ptr(), xb.data_ptr(), dzz.data_ptr(),
+                       an.data_ptr(), m, ch, br.data_ptr(), t["zcol"].data_ptr(), scr.data_ptr(), outs[0].data_ptr(),
+                       outs[1].data_ptr(), outs[2].data_ptr(), st)
+            for nm, o_ in zip(names, outs):
+                grads[nm] = o_.view(1, 1, -1)
             self._flush(grads, fp + "/")
             if j == 0 and self._on_block is not None:
                 self._on_block(i)
@@ -690,20 +684,24 @@ class GradEngine:
         written straight into grad_out where that is contiguous."""
         import torch
         go, jobs = self._gout, []
-        for name, part, k, col0, shape, scale, row_src in items:
+        for name, part, k, col0, shape, scale, row_src, col_src in items:
             dev = part.device
-            v, g = self._tp._f32(name + "/kernel"), self._tp._f32(name + "/g")
+            normed = (name + "/g") in self._tp.params                  # ZeroConv1d carries no weight norm
+            v = self._tp._f32(name + "/kernel")
+            g = self._tp._f32(name + "/g") if normed else None
             n = int(v.shape[-1])
             if go is not None and go[name + "/kernel"].is_contiguous():
-                dv, dg, dbo = go[name + "/kernel"].view(k, n), go[name + "/g"], go[name + "/bias"]
+                dv, dg, dbo = go[name + "/kernel"].view(k, n), go[name + "/g"] if normed else None, go[name + "/bias"].view(-1)
             else:
                 dv = torch.empty(k, n, dtype=torch.float32, device=dev)
-                dg, dbo = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+                dg = torch.empty(n, dtype=torch.float32, device=dev) if normed else None
+                dbo = torch.empty(n, dtype=torch.float32, device=dev)
             jobs.append(dict(part=part, k=k, n=n, col0=col0, bias_row=int(part.shape[1]) - 1, scale=scale, row_src=row_src,
-                             v=v, g=g, dv=dv, dg=dg, db=dbo))
+                             col_src=col_src, v=v if normed else None, g=g, dv=dv, dg=dg, db=dbo))
             grads[name + "/kernel"] = dv.view(shape)
-            grads[name + "/g"] = dg
-            grads[name + "/bias"] = dbo
+            if normed:
+                grads[name + "/g"] = dg
+            grads[name + "/bias"] = dbo.view(self._shapes[name + "/bias"])
         wn_backward_group(jobs)
 
 
