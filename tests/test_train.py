@@ -381,3 +381,27 @@ def test_grouped_weight_gradients_and_weight_norm_backward():
         dv = gg / nrm * (dw - vv * dg / nrm)
         np.testing.assert_allclose(out["dg"].cpu().numpy(), dg, rtol=1e-4, atol=1e-4 * np.abs(dg).max())
         np.testing.assert_allclose(out["dv"].cpu().numpy(), dv, rtol=1e-4, atol=1e-4 * np.abs(dv).max())
+
+
+def test_device_side_table_refresh_equals_the_host_tables():
+    """PackPlan.refresh_tables_device (batched float64 gathers from the flat masters) reproduces the host-computed
+    biases / ActNorm / ZeroConv / up-sampling tables after the parameters changed."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.optim import DataParallelAdam
+    hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
+    opt = DataParallelAdam(hp, W.synthetic_params(hp, 11))
+    tp = TR._TrainPack(opt.master_views(), hp, "cuda")
+    assert tp.plan._dev_ready
+    opt.w.add_(torch.randn_like(opt.w) * 0.05)            # "an optimiser step"
+    tp.plan.refresh_tables_device()
+    dev_tables = tp.plan._tbuf.clone()
+    tp.plan.hostview.reset()
+    tp.plan.upload_tables()
+    host_tables = tp.plan._tbuf.clone()
+    diff = (dev_tables != host_tables).nonzero().reshape(-1)
+    # float64 exp on the device vs numpy may differ in the last float64 bit: at most a handful of fp32 roundings flip
+    assert diff.numel() <= 4, diff[:10]
+    assert torch.allclose(dev_tables, host_tables, rtol=2e-7, atol=0)

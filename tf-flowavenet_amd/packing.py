@@ -167,7 +167,8 @@ class PackPlan:
     def __init__(self, dev):
         self.dev = dev
         self.sjobs, self.slot, self.jobs = [], {}, []
-        self.tables, self.host_cbs, self.keep = [], [], []
+        self.tables, self.recipes, self.host_cbs, self.keep = [], [], [], []
+        self._dev_ready = False
         self.hostview = None
         self._built = False
 
@@ -184,8 +185,70 @@ class PackPlan:
         self.keep += [v, g, src_k, src_n]
         self._built = False
 
-    def table(self, setter, fn):
+    def table(self, setter, fn, recipe=None):
+        """recipe (optional): how the table follows from the parameters, for the on-device refresh -
+        ``dict(terms=[(param name, index array or -1 per element), ..], post=scalar or array, exp=bool or array)``:
+        table = F(post * sum_t param_t[index_t]) with F = exp where flagged; or ``dict(upsample=n)``."""
         self.tables.append((setter, fn))
+        self.recipes.append(recipe)
+
+    def enable_device_tables(self, params):
+        """Build the gather tables of the on-device refresh (``refresh_tables_device``).  Needs every table to carry
+        a recipe and every parameter to be a view of ONE flat fp32 device vector (the optimiser's masters)."""
+        import torch
+        self._dev_ready = False
+        if getattr(self, "_tbuf", None) is None or any(r is None for r in self.recipes):
+            return False
+        vals = list(params.values())
+        base = vals[0]._base if isinstance(vals[0], torch.Tensor) else None
+        if base is None or base.dim() != 1 or base.dtype != torch.float32 or any(
+                not isinstance(v, torch.Tensor) or v._base is not base or not v.is_contiguous() for v in vals):
+            return False
+        total = int(self._tbuf.numel())
+        nterm = max(len(r.get("terms", ())) for r in self.recipes)
+        idx = np.zeros((nterm, total), dtype=np.int64)
+        mask = np.zeros((nterm, total), dtype=np.float64)
+        post = np.ones(total, dtype=np.float64)
+        expf = np.zeros(total, dtype=bool)
+        self._up_jobs = []
+        for (off, size), r in zip(self._toffs, self.recipes):
+            if "upsample" in r:
+                self._up_jobs.append((r["upsample"], off, size))
+                continue
+            for t, (name, ix) in enumerate(r["terms"]):
+                ix = np.broadcast_to(np.asarray(ix, dtype=np.int64).reshape(-1), (size,))
+                ok = ix >= 0
+                idx[t, off:off + size] = np.where(ok, int(params[name].storage_offset()) + ix, 0)
+                mask[t, off:off + size] = ok
+            post[off:off + size] = np.broadcast_to(np.asarray(r.get("post", 1.0), dtype=np.float64).reshape(-1), (size,))
+            expf[off:off + size] = np.broadcast_to(np.asarray(r.get("exp", False), dtype=bool).reshape(-1), (size,))
+        dev = self.dev
+        self._flat = base
+        self._didx = [torch.from_numpy(idx[t]).to(dev) for t in range(nterm)]
+        self._dmask = [torch.from_numpy(mask[t]).to(dev) for t in range(nterm)]
+        self._dpost = torch.from_numpy(post).to(dev)
+        self._dexp = torch.from_numpy(expf).to(dev)
+        self._up_params = params
+        self._dev_ready = True
+        return True
+
+    def refresh_tables_device(self):
+        """The small tables recomputed from the masters ON the device (a few batched gathers in float64, the host
+        path's arithmetic): no device -> host -> device round trip, and the whole refresh can sit in a hipGraph."""
+        import torch
+        acc = None
+        for ix, mk in zip(self._didx, self._dmask):
+            term = self._flat[ix].double() * mk
+            acc = term if acc is None else acc + term
+        acc = acc * self._dpost
+        out = torch.where(self._dexp, torch.exp(acc), acc).float()
+        for n, off, size in self._up_jobs:          # weight-normed up-sampling kernels: v / ||v||_(k) * g per kw column
+            P = self._up_params
+            v = P["upsample_%d/kernel" % n].double()
+            nrm = torch.sqrt(torch.clamp((v * v).sum(dim=(0, 2), keepdim=True), min=1e-12))
+            w = v / nrm * P["upsample_%d/g" % n].double().reshape(-1)[0]
+            out[off:off + size] = w[:, :, 0, 0].reshape(-1).float()
+        self._tbuf.copy_(out)
 
     def _build(self):
         import torch
@@ -220,6 +283,7 @@ class PackPlan:
         host = np.zeros(max(total, 4), dtype=np.float32)
         for a, off in zip(arrs, offs):
             host[off:off + a.size] = a.reshape(-1)
+        self._toffs = [(off, a.size) for a, off in zip(arrs, offs)]
         if getattr(self, "_tbuf", None) is None:
             self._tbuf = torch.from_numpy(host).to(self.dev)
             for (setter, _), a, off in zip(self.tables, arrs, offs):
@@ -231,8 +295,11 @@ class PackPlan:
 
     def refresh(self):
         """The masters changed: recompute everything that was recorded."""
-        self.hostview.reset()
-        self.upload_tables()
+        if self._dev_ready:
+            self.refresh_tables_device()
+        else:
+            self.hostview.reset()
+            self.upload_tables()
         self.run_kernels()
 
 
@@ -285,10 +352,10 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
     # device copy exists.  Every table starts on a 16-byte boundary (float4 loads in the kernels).
     pending = []
 
-    def put(setter, fn):
-        """fn() -> the table's current value (re-evaluated by plan.refresh())."""
+    def put(setter, fn, recipe=None):
+        """fn() -> the table's current value (re-evaluated by plan.refresh()); recipe: see PackPlan.table."""
         if plan is not None:
-            plan.table(setter, fn)
+            plan.table(setter, fn, recipe)
         else:
             a = fn()
             pending.append((setter, np.ascontiguousarray(a, dtype=np.float32).reshape(-1), np.shape(a)))
@@ -413,7 +480,8 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                 wfront2 = bf16_zeros(FILTER, 6 * ch)
                 pack(wp + "/Conv_front", f2, ident256, 6 * ch, FILTER, wfront2, 6 * ch)
                 d.Wfront2 = wfront2.data_ptr()
-            put(lambda v, d=d: setattr(d, "bfront", v.data_ptr()), lambda wp=wp: hostp[wp + "/Conv_front/bias"])
+            put(lambda v, d=d: setattr(d, "bfront", v.data_ptr()), lambda wp=wp: hostp[wp + "/Conv_front/bias"],
+                dict(terms=[(wp + "/Conv_front/bias", np.arange(FILTER))]))
 
             wskip = bf16_zeros(FILTER, L * FILTER)
             for l in range(L):
@@ -434,21 +502,27 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                     return np.where(fg == 0, bsum[0][gch], bsum[1][gch])
                 d.Wd[l] = wd.data_ptr()
                 d.Wc[l] = wc.data_ptr()
-                put(lambda v, d=d, l=l: d.bgate.__setitem__(l, v.data_ptr()), gate_bias)
+                put(lambda v, d=d, l=l: d.bgate.__setitem__(l, v.data_ptr()), gate_bias,
+                    dict(terms=[(rp + "/Conv_filter/bias", np.where(fg == 0, gch, -1)), (rp + "/filter_conv_c/bias", np.where(fg == 0, gch, -1)),
+                                (rp + "/Conv_gate/bias", np.where(fg == 0, -1, gch)), (rp + "/gate_conv_c/bias", np.where(fg == 0, -1, gch))],
+                         post=np.where(fg == 0, GATE_MUL[0], GATE_MUL[1])))
                 if l + 1 < L:   # the last layer's res_conv is dead (modules.py:126-128,175-176)
                     wr = bf16_zeros(FILTER, FILTER)
                     pack(rp + "/res_conv", ident256, ident256, FILTER, FILTER, wr, FILTER)
                     d.Wres[l] = wr.data_ptr()
-                    put(lambda v, d=d, l=l: d.bres.__setitem__(l, v.data_ptr()), lambda rp=rp: hostp[rp + "/res_conv/bias"])
+                    put(lambda v, d=d, l=l: d.bres.__setitem__(l, v.data_ptr()), lambda rp=rp: hostp[rp + "/res_conv/bias"],
+                        dict(terms=[(rp + "/res_conv/bias", np.arange(FILTER))]))
                 pack(rp + "/skip_conv", ident256, ident256, FILTER, FILTER, wskip, L * FILTER, col_off=l * FILTER)
             d.Wskip = wskip.data_ptr()
             put(lambda v, d=d: setattr(d, "bskip", v.data_ptr()),
-                lambda wp=wp: sum(np.asarray(hostp["%s/ResBlock_%d/skip_conv/bias" % (wp, l)], np.float64) for l in range(L)))
+                lambda wp=wp: sum(np.asarray(hostp["%s/ResBlock_%d/skip_conv/bias" % (wp, l)], np.float64) for l in range(L)),
+                dict(terms=[("%s/ResBlock_%d/skip_conv/bias" % (wp, l), np.arange(FILTER)) for l in range(L)]))
 
             wfin = bf16_zeros(FILTER, FILTER)
             pack(wp + "/Conv_final", accperm, ident256, FILTER, FILTER, wfin, FILTER)
             d.Wfinal = wfin.data_ptr()
-            put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), lambda wp=wp: hostp[wp + "/Conv_final/bias"])
+            put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), lambda wp=wp: hostp[wp + "/Conv_final/bias"],
+                dict(terms=[(wp + "/Conv_final/bias", np.arange(FILTER))]))
 
             wz = bf16_zeros(npt * 64, FILTER)
             pack(wp + "/ZeroConv1d", accperm, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
@@ -464,13 +538,21 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                     out[valid] = np.exp(3.0 * zs[zsn_host[valid]])
                 return out
             d.Wzero = wz.data_ptr()
-            put(lambda v, d=d: setattr(d, "bzero", v.data_ptr()), lambda f=zero_tables: f(0))
-            put(lambda v, d=d: setattr(d, "ezero", v.data_ptr()), lambda f=zero_tables: f(1))
+            zidx = np.where(zsn_host >= 0, zsn_host, -1)
+            put(lambda v, d=d: setattr(d, "bzero", v.data_ptr()), lambda f=zero_tables: f(0),
+                dict(terms=[(wp + "/ZeroConv1d/bias", zidx)]))
+            put(lambda v, d=d: setattr(d, "ezero", v.data_ptr()), lambda f=zero_tables: f(1),
+                dict(terms=[(wp + "/ZeroConv1d/scale", zidx)], post=3.0, exp=True))
 
             def set_an(v, d=d, key=(i, j)):
                 pm.an[key] = v
                 d.an = v.data_ptr()
-            put(set_an, lambda fp=fp, i=i: actnorm_table(hostp[fp + "/ActNorm/b"], hostp[fp + "/ActNorm/logs"], i))
+            an_idx = np.concatenate([r * ch + bitrev_table(i).astype(np.int64) for r in range(2)]).reshape(2, 1, ch)
+            rows = np.arange(4).reshape(1, 4, 1)
+            put(set_an, lambda fp=fp, i=i: actnorm_table(hostp[fp + "/ActNorm/b"], hostp[fp + "/ActNorm/logs"], i),
+                dict(terms=[(fp + "/ActNorm/b", np.where(rows == 0, an_idx, -1)), (fp + "/ActNorm/logs", np.where(rows == 0, -1, an_idx))],
+                     post=np.broadcast_to(np.array([1.0, 3.0, -3.0, 3.0]).reshape(1, 4, 1), (2, 4, ch)),
+                     exp=np.broadcast_to((rows == 1) | (rows == 2), (2, 4, ch))))
 
     md = pm.model_desc
     md.n_block, md.n_flow, md.n_layer, md.num_mels = hp.n_block, hp.n_flow, L, hp.num_mels
@@ -479,7 +561,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
         raise ValueError("too many upsample stages")
     for n, s in enumerate(hp.upsample_scales):
         md.up_scale[n] = int(s)
-        put(lambda v, n=n: md.up_w.__setitem__(n, v.data_ptr()), lambda n=n: upsample_kernel(hostp, n)[0])
+        put(lambda v, n=n: md.up_w.__setitem__(n, v.data_ptr()), lambda n=n: upsample_kernel(hostp, n)[0], dict(upsample=n))
         md.up_bias[n] = upsample_kernel(hostp, n)[1]
         if plan is not None:
             plan.host_cbs.append(lambda n=n: md.up_bias.__setitem__(n, upsample_kernel(hostp, n)[1]))

@@ -240,6 +240,7 @@ class _TrainPack:
                 self.flows[(i, j)] = self._pack_flow_plan(i, j) if stable else self._pack_flow(i, j)
         if stable:
             self.plan.run_kernels()
+            self.plan.enable_device_tables(params)      # masters in one flat vector: the small tables refresh on the device
         self._small_tables()
 
     def refresh(self):
@@ -434,9 +435,13 @@ class GradEngine:
         self.external_host_tables = False
 
     def refresh_host_tables(self):
+        """Host-computed small tables (only when the parameters are not views of one flat device vector: then
+        ``PackPlan.refresh_tables_device`` does it inside the step)."""
         tp = getattr(self, "_tp", None)
         if tp is None or tp.plan is None:
             raise RuntimeError("no recorded packing plan: run one eager step on device-resident parameters first")
+        if tp.plan._dev_ready:
+            return
         tp.plan.hostview.reset()
         tp.plan.upload_tables()
 
@@ -471,7 +476,9 @@ class GradEngine:
         tp = getattr(self, "_tp", None)
         if tp is not None and tp.plan is not None and key is not None and getattr(self, "_tp_key", None) == key:
             tp.params = params
-            if not self.external_host_tables:
+            if tp.plan._dev_ready:
+                tp.plan.refresh_tables_device()
+            elif not self.external_host_tables:
                 self.refresh_host_tables()
             tp.plan.run_kernels()
             tp._small_tables()
