@@ -77,20 +77,48 @@ __global__ __launch_bounds__(1024) void wn_scale_jobs_kernel(const fwn_scale_job
 }
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const fwn_pack_job* __restrict__ jobs,
                                                         const float* __restrict__ scales, int scale_ld) {
+    __shared__ float tile[64][65];
     const fwn_pack_job j = jobs[blockIdx.x];
     const float* sc = j.scale_slot >= 0 ? scales + (size_t)j.scale_slot * scale_ld : nullptr;
-    const long total = (long)j.k_dst * j.n_dst;
     bf16* out = (bf16*)j.out;
-    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
-        // the fastest index follows the output's contiguous axis
-        const int kd = j.transposed ? (int)(i / j.n_dst) : (int)(i % j.k_dst);
-        const int nd = j.transposed ? (int)(i % j.n_dst) : (int)(i / j.k_dst);
+    auto value = [&](int kd, int nd, bool& skip) {
         const int sk = j.src_k[kd], sn = j.src_n[nd];
-        if (sn < 0) continue;
-        float val = 0.0f;
-        if (sk >= 0)      // (scale * mul) first, like fwn_pack_bf16 fed a pre-multiplied scale: same bf16 bits
-            val = j.v[(size_t)sk * j.n_src + sn] * (sc ? sc[sn] * j.mul : j.mul);
-        out[j.transposed ? (size_t)kd * j.ld_dst + nd : (size_t)nd * j.ld_dst + kd] = (bf16)val;
+        skip = sn < 0;
+        // (scale * mul) first, like fwn_pack_bf16 fed a pre-multiplied scale: same bf16 bits
+        return (sk >= 0 && sn >= 0) ? j.v[(size_t)sk * j.n_src + sn] * (sc ? sc[sn] * j.mul : j.mul) : 0.0f;
+    };
+    if (j.transposed) {          // out[k][n], n contiguous like the source: straight through
+        const long total = (long)j.k_dst * j.n_dst;
+        for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+            const int kd = (int)(i / j.n_dst), nd = (int)(i % j.n_dst);
+            bool skip;
+            const float val = value(kd, nd, skip);
+            if (!skip) out[(size_t)kd * j.ld_dst + nd] = (bf16)val;
+        }
+        return;
+    }
+    // out[n][k], k contiguous: a transpose of the source - 64 x 64 tiles through LDS so that both the fp32 reads
+    // (n fastest) and the bf16 writes (k fastest) are coalesced
+    const int tk = (j.k_dst + 63) / 64, tn = (j.n_dst + 63) / 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int t = blockIdx.y; t < tk * tn; t += gridDim.y) {
+        const int k0 = (t % tk) * 64, n0 = (t / tk) * 64;
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int kd = k0 + ly + 4 * r, nd = n0 + lx;
+            bool skip = true;
+            float val = 0.0f;
+            if (kd < j.k_dst && nd < j.n_dst) val = value(kd, nd, skip);
+            tile[ly + 4 * r][lx] = val;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const int nd = n0 + ly + 4 * r, kd = k0 + lx;
+            // output rows whose source column is -1 belong to another job of the same matrix: left alone
+            if (kd < j.k_dst && nd < j.n_dst && j.src_n[nd] >= 0) out[(size_t)nd * j.ld_dst + kd] = (bf16)tile[lx][ly + 4 * r];
+        }
     }
 }
 void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack_job* jobs, int njobs, float* scales,
