@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 R=$PWD
 abl=${1:-0}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFWN_ABL=$abl tools/bench_gemm.hip -o /tmp/bench_gemm_$abl 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DFWN_ABL=$abl tools/bench_gemm.hip -o /tmp/bench_gemm_$abl 2>/dev/null
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/pmc_out

@@ -17,4 +17,10 @@ python3 tools/bench_extra.py > $O/bench_extra.txt 2>&1
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   echo "## $c"; PMC_FILTER=gate_halo_kernel tools/pmc_gemm.sh 0 "$c" 2>&1 | grep "258048\|516096" | head -2
 done > $O/gate_pmc_raw.txt 2>&1
+# the data-parallel training step
+python3 tools/bench_train.py --steps 20 --warmup 3 2> $O/bench_train.err | tail -1 > $O/bench_train.json
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof_train -o r01t -- python3 $R/tools/bench_train.py --steps 10 --warmup 3 > $O/rocprof_train.log 2>&1)
+cp $(ls $O/rocprof_train/*kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats_train.csv
+python3 tools/kernel_summary.py $(ls $O/rocprof_train/*kernel_trace.csv | head -1) 14 > $O/kernel_summary_train.txt
+rm -f $O/rocprof_train/*kernel_trace.csv
 ls -la $O
