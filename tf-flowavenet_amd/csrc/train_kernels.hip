@@ -15,7 +15,9 @@ struct LinProb {
     int q0, nq;               // this workgroup's chunk range (all chunks unless split)
     float* y32;               // fp32 output of this split
     struct RowCtx { int row, t; };
-    struct ChunkCtx { int s, k0; };
+    // The segment's fields are read from the kernel arguments ONCE per chunk (the segment index is a run-time value:
+    // looked up per DMA piece, every piece would wait for its own scalar loads).
+    struct ChunkCtx { const void* x; int rows, ld, k, shift, koff, k0; };
     template <int BK> __device__ int nchunks() const { return nq; }
     __device__ RowCtx row_ctx(int row) const { return RowCtx{row, g.Ti > 0 ? row % g.Ti : row}; }
     template <int BK> __device__ ChunkCtx chunk_ctx(int q) const {
@@ -25,24 +27,21 @@ struct LinProb {
             if (gq < cs) break;
             gq -= cs;
         }
-        return ChunkCtx{s, gq * BK};
+        const fwn_gemm_seg sg = g.seg[s];
+        return ChunkCtx{sg.x, sg.rows, sg.ld, sg.k, sg.shift, sg.koff, gq * BK};
     }
-    __device__ srd_t a_srd(const ChunkCtx& cc) const {
-        return make_srd(g.seg[cc.s].x, (uint32_t)((size_t)g.seg[cc.s].rows * g.seg[cc.s].ld * 2));
-    }
+    __device__ srd_t a_srd(const ChunkCtx& cc) const { return make_srd(cc.x, (uint32_t)((size_t)cc.rows * cc.ld * 2)); }
     __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
-        const fwn_gemm_seg& sg = g.seg[cc.s];
         const int kk = cc.k0 + c8 * 8;
-        bool ok = rc.row < g.M && kk < sg.k;
-        if (g.Ti > 0) ok = ok && (unsigned)(rc.t + sg.shift) < (unsigned)g.Ti;
-        else ok = ok && (unsigned)(rc.row + sg.shift) < (unsigned)sg.rows;
-        return ok ? (uint32_t)((rc.row + sg.shift) * sg.ld + kk) * 2u : FWN_OOB;
+        bool ok = rc.row < g.M && kk < cc.k;
+        if (g.Ti > 0) ok = ok && (unsigned)(rc.t + cc.shift) < (unsigned)g.Ti;
+        else ok = ok && (unsigned)(rc.row + cc.shift) < (unsigned)cc.rows;
+        return ok ? (uint32_t)((rc.row + cc.shift) * cc.ld + kk) * 2u : FWN_OOB;
     }
     __device__ srd_t b_srd(const ChunkCtx&) const { return make_srd(g.W, (uint32_t)((size_t)g.N * g.ldw * 2)); }
     __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
-        const fwn_gemm_seg& sg = g.seg[cc.s];
         const int kk = cc.k0 + c8 * 8;
-        return (n < g.N && kk < sg.k) ? (uint32_t)(n * g.ldw + sg.koff + kk) * 2u : FWN_OOB;
+        return (n < g.N && kk < cc.k) ? (uint32_t)(n * g.ldw + cc.koff + kk) * 2u : FWN_OOB;
     }
     __device__ float acc_init(int) const { return 0.0f; }
     template <int MI>
@@ -406,10 +405,17 @@ __global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double
     } else {
         if (n >= q.N) return;
         double ss = 0.0, dot = 0.0;
-        for (int c = 0; c < nkc; ++c) {
-            const double* o = sc + ((size_t)c * q.N + n) * 2;
-            ss += o[0];
-            dot += o[1];
+        for (int c0 = 0; c0 < nkc; c0 += 8) {          // 8 row chunks' sums in flight at a time, added in order
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double* o = sc + ((size_t)min(c0 + u, nkc - 1) * q.N + n) * 2;
+                a[u] = o[0];
+                b[u] = o[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u < nkc) { ss += a[u]; dot += b[u]; }
         }
         const double nrm = sqrt(fmax(ss, 1e-12)), dgn = dot / nrm;
         if (kc == 0 && w == 0) q.dg[n] = (float)dgn;
