@@ -379,17 +379,39 @@ __global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double
             const int sn = q.col0 + (q.col_src ? q.col_src[n] : n);          // source column of output column n
             if (kc == 0 && w == 0 && q.db && q.bias_row >= 0)
                 q.db[n] = q.scale * wn_sum_splits(q.part + (size_t)q.bias_row * q.ldp + sn, q.nsplit, (long)q.split_stride);
-#pragma unroll 2
+            // the 8 rows of this thread together: every load of a pass over the splits is independent of the others
+            // (one memory round trip per split instead of one per row and split); each element still sums its
+            // splits in ascending order
+            size_t off[8];
+            float d[8];
+            bool ok[8];
+#pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = kc * 32 + w + 4 * i;
-                if (k >= q.K) break;
-                const int src = q.row_src ? q.row_src[k] : k;
-                const float d = q.scale * wn_sum_splits(q.part + (size_t)src * q.ldp + sn, q.nsplit, (long)q.split_stride);
-                q.dV[(size_t)k * q.N + n] = d;
-                if (q.g) {
-                    const double v = q.V[(size_t)k * q.N + n];
-                    ss += v * v;
-                    dot += v * (double)d;
+                ok[i] = k < q.K;
+                const int kk = ok[i] ? k : q.K - 1;
+                off[i] = (size_t)(q.row_src ? q.row_src[kk] : kk) * q.ldp + sn;
+                d[i] = 0.0f;
+            }
+            for (int s_ = 0; s_ < q.nsplit; ++s_) {
+                const float* ps = q.part + (size_t)s_ * q.split_stride;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d[i] += ps[off[i]];
+            }
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kk = min(kc * 32 + w + 4 * i, q.K - 1);
+                v[i] = q.g ? q.V[(size_t)kk * q.N + n] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = kc * 32 + w + 4 * i;
+                const float di = q.scale * d[i];
+                if (ok[i]) {
+                    q.dV[(size_t)k * q.N + n] = di;
+                    ss += (double)v[i] * v[i];
+                    dot += (double)v[i] * (double)di;
                 }
             }
         }
@@ -420,11 +442,17 @@ __global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double
         const double nrm = sqrt(fmax(ss, 1e-12)), dgn = dot / nrm;
         if (kc == 0 && w == 0) q.dg[n] = (float)dgn;
         const double gn = (double)q.g[n] / nrm, dn = dgn / nrm;        // per column: no division per element
+        float dv[8], vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {                 // all loads first
+            const size_t e = (size_t)min(kc * 32 + w + 4 * i, q.K - 1) * q.N + n;
+            dv[i] = q.dV[e];
+            vv[i] = q.V[e];
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = kc * 32 + w + 4 * i;
-            const size_t e = (size_t)k * q.N + n;
-            if (k < q.K) q.dV[e] = (float)(gn * ((double)q.dV[e] - (double)q.V[e] * dn));
+            if (k < q.K) q.dV[(size_t)k * q.N + n] = (float)(gn * ((double)dv[i] - (double)vv[i] * dn));
         }
     }
 }
