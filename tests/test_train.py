@@ -94,6 +94,8 @@ def _grad_case(cfg, b, t, seed):
     (dict(n_block=2, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=8), 2, 128),
     (dict(n_block=3, n_flow=3, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16), 3, 256),
     (dict(n_block=4, n_flow=2, n_layer=3, hop_size=32, upsample_scales=[4, 8], num_mels=16), 2, 512),
+    # 4 layers: 18 weight-gradient GEMMs and 26 weight-norm jobs per flow - more than one group (FWN_MAX_GROUP = 16)
+    (dict(n_block=4, n_flow=2, n_layer=4, hop_size=16, upsample_scales=[4, 4], num_mels=16), 2, 512),
 ])
 def test_loss_and_all_parameter_gradients_match_autograd_oracle(cfg, b, t):
     """GradEngine (training forward + backward through the stage kernels) against autograd of the
