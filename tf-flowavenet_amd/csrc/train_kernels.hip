@@ -347,7 +347,8 @@ void fwn_small_grads_launch(float* ga, float* ya, float* gb, float* yb, const fl
 struct WnGroup {
     fwn_wn_job job[FWN_MAX_GROUP];
     int first[FWN_MAX_GROUP + 1];
-    long soff[FWN_MAX_GROUP];           // scratch offset (doubles) of each job: [row chunk][N][2]
+    int first_mid[FWN_MAX_GROUP + 1];   // workgroup prefix of the middle pass: one per (job, 64 columns)
+    long soff[FWN_MAX_GROUP];           // scratch offset (doubles) of each job: [row chunk][N][2], then totals [N][2]
     int njobs;
 };
 __device__ __forceinline__ float wn_sum_splits(const float* __restrict__ p, int nsplit, long stride) {
@@ -426,19 +427,8 @@ __global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double
         }
     } else {
         if (n >= q.N) return;
-        double ss = 0.0, dot = 0.0;
-        for (int c0 = 0; c0 < nkc; c0 += 8) {          // 8 row chunks' sums in flight at a time, added in order
-            double a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const double* o = sc + ((size_t)min(c0 + u, nkc - 1) * q.N + n) * 2;
-                a[u] = o[0];
-                b[u] = o[1];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (c0 + u < nkc) { ss += a[u]; dot += b[u]; }
-        }
+        const double* tot = sc + ((size_t)nkc * q.N + n) * 2;      // column totals of the middle pass
+        const double ss = tot[0], dot = tot[1];
         const double nrm = sqrt(fmax(ss, 1e-12)), dgn = dot / nrm;
         if (kc == 0 && w == 0) q.dg[n] = (float)dgn;
         const double gn = (double)q.g[n] / nrm, dn = dgn / nrm;        // per column: no division per element
@@ -456,28 +446,68 @@ __global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double
         }
     }
 }
+// Middle pass: column totals of the per-row-chunk sums, once per column (a conditioning conv of the last block has
+// K = 10240 = 320 row chunks: left to pass 2, every one of its workgroups would re-read all of them).  One workgroup
+// per (job, 64 columns); wave w adds chunks w, w+4, .. (8 loads in flight), the four waves are added in order.
+__global__ __launch_bounds__(256) void wn_group_mid_kernel(const WnGroup grp, double* __restrict__ scratch) {
+    __shared__ double red[2][4][64];
+    int jn = 0;
+    while (jn + 1 < grp.njobs && (int)blockIdx.x >= grp.first_mid[jn + 1]) ++jn;
+    const fwn_wn_job q = grp.job[jn];
+    const int nc = (int)blockIdx.x - grp.first_mid[jn], nkc = (q.K + 31) / 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = min(nc * 64 + lane, q.N - 1);
+    const double* sc = scratch + grp.soff[jn];
+    double ss = 0.0, dot = 0.0;
+    for (int c0 = w; c0 < nkc; c0 += 32) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double* o = sc + ((size_t)min(c0 + 4 * u, nkc - 1) * q.N + n) * 2;
+            a[u] = o[0];
+            b[u] = o[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + 4 * u < nkc) { ss += a[u]; dot += b[u]; }
+    }
+    red[0][w][lane] = ss;
+    red[1][w][lane] = dot;
+    __syncthreads();
+    if (w == 0 && nc * 64 + lane < q.N) {
+        double* o = scratch + grp.soff[jn] + ((size_t)nkc * q.N + n) * 2;
+        o[0] = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+        o[1] = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+    }
+}
 long fwn_wn_group_scratch_doubles(const fwn_wn_job* jobs, int njobs) {
     long tot = 0;
     for (int j = 0; j < njobs; ++j)
-        if (jobs[j].g) tot += (long)((jobs[j].K + 31) / 32) * jobs[j].N * 2;
+        if (jobs[j].g) tot += (long)((jobs[j].K + 31) / 32 + 1) * jobs[j].N * 2;
     return tot > 0 ? tot : 1;
 }
 void fwn_wn_group_launch(const fwn_wn_job* jobs, int njobs, double* scratch, hipStream_t st) {
     WnGroup g;
     g.njobs = njobs;
-    int total = 0;
+    int total = 0, total_mid = 0;
     long off = 0;
-    bool any_g = false;
     for (int j = 0; j < njobs; ++j) {
         g.job[j] = jobs[j];
         g.first[j] = total;
+        g.first_mid[j] = total_mid;
         g.soff[j] = off;
         total += ((jobs[j].K + 31) / 32) * ((jobs[j].N + 63) / 64);
-        if (jobs[j].g) { off += (long)((jobs[j].K + 31) / 32) * jobs[j].N * 2; any_g = true; }
+        if (jobs[j].g) {
+            off += (long)((jobs[j].K + 31) / 32 + 1) * jobs[j].N * 2;
+            total_mid += (jobs[j].N + 63) / 64;
+        }
     }
-    for (int j = njobs; j <= FWN_MAX_GROUP; ++j) g.first[j] = total;
+    for (int j = njobs; j <= FWN_MAX_GROUP; ++j) { g.first[j] = total; g.first_mid[j] = total_mid; }
     hipLaunchKernelGGL(wn_group_kernel<1>, dim3(total), dim3(256), 0, st, g, scratch);
-    if (any_g) hipLaunchKernelGGL(wn_group_kernel<2>, dim3(total), dim3(256), 0, st, g, scratch);
+    if (total_mid > 0) {
+        hipLaunchKernelGGL(wn_group_mid_kernel, dim3(total_mid), dim3(256), 0, st, g, scratch);
+        hipLaunchKernelGGL(wn_group_kernel<2>, dim3(total), dim3(256), 0, st, g, scratch);
+    }
 }
 
 static inline unsigned ew_grid(long n) { long b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
