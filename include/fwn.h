@@ -265,6 +265,8 @@ typedef struct fwn_tn_job {
     int32_t ldx, Kx, ntap, shift0, dshift, ldy, N, nsplit, bias_row, reserved;
 } fwn_tn_job;
 int fwn_tn_gemm_group(const fwn_tn_job* jobs, int njobs, int M, int Ti, void* stream);
+/* Edge of the square output tile the group launch uses at this M (128 or 256): what a caller sizes nsplit with. */
+int fwn_tn_gemm_tile(int M);
 typedef struct fwn_wn_job {
     const float* part; const int32_t* row_src; const float* V; const float* g; float* dV; float* dg; float* db;
     int64_t split_stride;

@@ -132,6 +132,7 @@ SIGNATURES = {
     "fwn_actnorm_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
     "fwn_flow_small_grads_partials": (i64, [i64, C.c_int]),
     "fwn_flow_small_grads": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "fwn_tn_gemm_tile": (C.c_int, [C.c_int]),
     "fwn_tn_gemm_group": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
     "fwn_wn_group_scratch": (i64, [vp, C.c_int]),
     "fwn_wn_backward_group": (C.c_int, [vp, C.c_int, vp, vp]),

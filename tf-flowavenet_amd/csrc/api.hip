@@ -370,6 +370,7 @@ static const char* tn_job_error(const fwn_tn_job& q, int M) {
     if (!(q.nsplit == 1 || q.split_stride >= ((int64_t)q.ntap * q.Kx + (q.bias_row ? 1 : 0)) * q.N)) return "split_stride too small";
     return nullptr;
 }
+int fwn_tn_gemm_tile(int M) { return fwn_tn_tile(M); }
 int fwn_tn_gemm_group(const fwn_tn_job* jobs, int njobs, int M, int Ti, void* stream) {
     REQUIRE(jobs && njobs >= 1 && njobs <= FWN_MAX_GROUP && M > 0 && Ti >= 0, "fwn_tn_gemm_group: 1..FWN_MAX_GROUP jobs, M > 0");
     for (int j = 0; j < njobs; ++j) {

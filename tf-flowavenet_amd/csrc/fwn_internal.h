@@ -68,5 +68,6 @@ struct fwn_scale_job;
 struct fwn_pack_job;
 void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack_job* jobs, int njobs, float* scales,
                           int scale_ld, hipStream_t st);
+int fwn_tn_tile(int M);
 void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipStream_t st);
 void fwn_colsum_bf16_launch(const void* dy, long M, int C, int ld, float scale, float* partial, float* out, hipStream_t st);

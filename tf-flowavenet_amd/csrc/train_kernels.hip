@@ -641,20 +641,27 @@ struct TnGroup {
     int first[FWN_MAX_GROUP + 1];
     int njobs;
 };
-__global__ __launch_bounds__(256) void tn_gemm_kernel(const TnGroup grp) {
-    constexpr int D = 3, TILE = 64 * 256, SLOT = 2 * TILE;       // X tile + dY tile, 16 KB each
+// WI x WJ waves of 64 x 64 each: <2,2,3> = 128 x 128 tile, 96 KB of LDS; <4,4,2> = 256 x 256 tile (half the
+// L2 -> LDS bytes per flop: the long contractions of the first blocks are bound by exactly that), 128 KB.
+// X and dY chunks are stored as panels of 128 columns (16 KB images).
+template <int WI, int WJ, int D>
+__global__ __launch_bounds__(64 * WI * WJ) void tn_gemm_kernel(const TnGroup grp) {
+    constexpr int TILE = 64 * 256, XP = WI / 2, YP = WJ / 2, SLOT = (XP + YP) * TILE, NW = WI * WJ;
+    constexpr int BMX = 64 * WI, BNY = 64 * WJ;
+    constexpr int PX = 16 * XP / NW, PY = 16 * YP / NW;          // DMA pieces per wave per chunk
+    static_assert(PX * NW == 16 * XP && PY * NW == 16 * YP, "pieces must divide over the waves");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / WJ, wj = wave % WJ;
     int jn = 0;
     while (jn + 1 < grp.njobs && (int)blockIdx.x >= grp.first[jn + 1]) ++jn;
     const TnArgs a = grp.job[jn];
-    const int kxt = (a.Kx + 127) / 128;                            // row tiles per tap
-    const int nbx = a.ntap * kxt, nby = (a.N + 127) / 128;
+    const int kxt = (a.Kx + BMX - 1) / BMX;                        // row tiles per tap
+    const int nbx = a.ntap * kxt, nby = (a.N + BNY - 1) / BNY;
     const int local = (int)blockIdx.x - grp.first[jn];
     const int bx = local % nbx, by = (local / nbx) % nby, bz = local / (nbx * nby);     // splits slowest: tiles of one row range run together
-    const int tap = bx / kxt, kx0 = (bx % kxt) * 128, n0 = by * 128;
+    const int tap = bx / kxt, kx0 = (bx % kxt) * BMX, n0 = by * BNY;
     const int shift = a.shift0 + tap * a.dshift;
     const int nchunk_all = (a.M + 63) / 64, per = (nchunk_all + a.nsplit - 1) / a.nsplit;
     const int c0 = bz * per, nq = max(0, min(per, nchunk_all - c0));
@@ -665,15 +672,23 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnGroup grp) {
         unsigned char* base = lds + (q % D) * SLOT;
         const int m0 = (c0 + q) * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = 4 * (wave + 4 * j) + prow;               // tile row 0..63
+        for (int j = 0; j < PX + PY; ++j) {
+            const bool isx = j < PX;
+            const int pidx = wave + NW * (isx ? j : j - PX);        // piece of the X (dY) part: panel pidx / 16, 4 rows each
+            const int panel = pidx >> 4, pp = pidx & 15;
+            const int row = 4 * pp + prow;                          // tile row 0..63
             const int ch = pch ^ (((row & 3) << 2) | ((row >> 2) & 3));   // source chunk for this lane's linear slot
             const int m = m0 + row;
-            const int t = a.Ti > 0 ? m % a.Ti : m;
-            const bool okx = m < a.M && (unsigned)(t + shift) < (unsigned)(a.Ti > 0 ? a.Ti : a.M) && kx0 + ch * 8 < a.Kx;
-            buf_load16_lds(sx, okx ? (uint32_t)((m + shift) * a.ldx + kx0 + ch * 8) * 2u : FWN_OOB, base + (wave + 4 * j) * 1024);
-            const bool oky = m < a.M && n0 + ch * 8 < a.N;
-            buf_load16_lds(sy, oky ? (uint32_t)(m * a.ldy + n0 + ch * 8) * 2u : FWN_OOB, base + TILE + (wave + 4 * j) * 1024);
+            if (isx) {
+                const int t = a.Ti > 0 ? m % a.Ti : m;
+                const int col = kx0 + 128 * panel + ch * 8;
+                const bool ok = m < a.M && (unsigned)(t + shift) < (unsigned)(a.Ti > 0 ? a.Ti : a.M) && col < a.Kx;
+                buf_load16_lds(sx, ok ? (uint32_t)((m + shift) * a.ldx + col) * 2u : FWN_OOB, base + panel * TILE + pp * 1024);
+            } else {
+                const int col = n0 + 128 * panel + ch * 8;
+                const bool ok = m < a.M && col < a.N;
+                buf_load16_lds(sy, ok ? (uint32_t)(m * a.ldy + col) * 2u : FWN_OOB, base + (XP + panel) * TILE + pp * 1024);
+            }
         }
     };
     f32x16 acc[2][2];
@@ -683,17 +698,10 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnGroup grp) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    // bias gradient = column sums of dY: one more MFMA per k-step against an all-ones operand, in the
-    // first row tile's wi == 0 waves only
+    // bias gradient = column sums of dY: the wi == 0 waves of the first row tile add up the dY fragments they hold
+    // anyway (fp32 VALU adds next to the MFMAs; two registers instead of a second accumulator tile)
     const bool do_bias = a.bias_row && bx == 0 && wi == 0;
-    f32x16 accb[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accb[j][r] = 0.0f;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    float bsum[2] = {0.0f, 0.0f};
     // transposed-read addresses: group g = lane>>4 = (khalf, chalf); lane 4q+p of a group supplies row q,
     // 8-byte half (p&1) of chunk c0 + (p>>1)
     const int kh = lane >> 5, chalf = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
@@ -704,18 +712,18 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnGroup grp) {
         if (q < nq) issue(q);
     for (int q = 0; q < nq; ++q) {
         const int pending = min(nq, q + D - 1) - (q + 1);
-        if (pending >= 1) FWN_WAIT_VMCNT(8); else FWN_WAIT_VMCNT(0);
+        if (pending >= 1) FWN_WAIT_VMCNT(PX + PY); else FWN_WAIT_VMCNT(0);
         __builtin_amdgcn_s_barrier();
         if (q + D - 1 < nq) issue(q + D - 1);
-        const unsigned char* xa = lds + (q % D) * SLOT;
-        const unsigned char* ya = xa + TILE;
+        const unsigned char* xa = lds + (q % D) * SLOT + (wi >> 1) * TILE;
+        const unsigned char* ya = lds + (q % D) * SLOT + (XP + (wj >> 1)) * TILE;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {                 // k-steps of 16 rows
             const int rb = 16 * s + 8 * kh;
             bf16x8 af[2], bfr[2];
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib) {          // operand columns: 32*(2*wi + ib) + 16*chalf + lane-in-group
-                const int cb = 2 * (2 * wi + ib) + chalf;
+                const int cb = 2 * (2 * (wi & 1) + ib) + chalf;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xa + tr_addr(rb, cb)));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xa + tr_addr(rb + 4, cb)));
                 const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnGroup grp) {
             }
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
-                const int cb = 2 * (2 * wj + jb) + chalf;
+                const int cb = 2 * (2 * (wj & 1) + jb) + chalf;
                 const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ya + tr_addr(rb, cb)));
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ya + tr_addr(rb + 4, cb)));
                 const short v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -735,7 +743,12 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnGroup grp) {
                 for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = mfma32(af[ib], bfr[jb], acc[ib][jb]);
             if (do_bias) {
 #pragma unroll
-                for (int jb = 0; jb < 2; ++jb) accb[jb] = mfma32(ones, bfr[jb], accb[jb]);
+                for (int jb = 0; jb < 2; ++jb) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t += (float)bfr[jb][e];
+                    bsum[jb] += t;
+                }
             }
         }
     }
@@ -744,11 +757,12 @@ __global__ __launch_bounds__(256) void tn_gemm_kernel(const TnGroup grp) {
     const int R = a.ntap * a.Kx;
     const uint32_t obytes = (uint32_t)((size_t)(R + (a.bias_row ? 1 : 0)) * a.N * 4);
     const srd_t so = make_srd(out, obytes);
-    if (do_bias && lane < 32) {        // every row of accb holds the column sums: row 0 = register 0 of lanes 0..31
+    if (do_bias) {                     // lane and lane + 32 hold the two k halves of column lane & 31
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
+            const float tot = bsum[jb] + __shfl_xor(bsum[jb], 32);
             const int col = n0 + 64 * wj + 32 * jb + lane;
-            buf_store_f32(so, col < a.N ? (uint32_t)(R * a.N + col) * 4u : FWN_OOB, 0, accb[jb][0]);
+            if (lane < 32) buf_store_f32(so, col < a.N ? (uint32_t)(R * a.N + col) * 4u : FWN_OOB, 0, tot);
         }
     }
 #pragma unroll
@@ -779,6 +793,10 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
     if (part == 0 && c < C)
         partial[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
+#ifndef FWN_TN256_MIN
+#define FWN_TN256_MIN 8192
+#endif
+int fwn_tn_tile(int M) { return M >= FWN_TN256_MIN ? 256 : 128; }     // output tile edge of the weight-gradient GEMM
 void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipStream_t st) {
     TnGroup g;
     g.njobs = njobs;
@@ -788,10 +806,12 @@ void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipSt
         g.job[j] = TnArgs{(const bf16*)q.x, q.ldx, q.Kx, q.ntap, q.shift0, q.dshift, (const bf16*)q.dy, q.ldy, q.N, M, Ti,
                           q.nsplit, q.part, (long)q.split_stride, q.bias_row};
         g.first[j] = total;
-        total += q.ntap * ((q.Kx + 127) / 128) * ((q.N + 127) / 128) * q.nsplit;
+        const int tile = fwn_tn_tile(M);
+        total += q.ntap * ((q.Kx + tile - 1) / tile) * ((q.N + tile - 1) / tile) * q.nsplit;
     }
     for (int j = njobs; j <= FWN_MAX_GROUP; ++j) g.first[j] = total;
-    hipLaunchKernelGGL(tn_gemm_kernel, dim3(total), dim3(256), 0, st, g);
+    if (fwn_tn_tile(M) == 256) hipLaunchKernelGGL((tn_gemm_kernel<4, 4, 2>), dim3(total), dim3(1024), 0, st, g);
+    else hipLaunchKernelGGL((tn_gemm_kernel<2, 2, 3>), dim3(total), dim3(256), 0, st, g);
 }
 void fwn_colsum_bf16_launch(const void* dy, long M, int C, int ld, float scale, float* partial, float* out, hipStream_t st) {
     const int nb = fwn_colsum_blocks(M, C);

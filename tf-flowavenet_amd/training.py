@@ -122,7 +122,8 @@ def tn_weight_grad_partials(x, dy, m, kx, n, *, shifts=(0,), ti=0, nsplit=None, 
 def tn_group_splits(specs, m):
     """Splits of the row range for a group of weight-gradient GEMMs ``(kx, n, ntap)``: as many as keep the whole
     group within ONE round of workgroups (a workgroup per CU), so every GEMM writes few partials."""
-    tiles = sum(ntap * ((kx + 127) // 128) * ((n + 127) // 128) for kx, n, ntap in specs)
+    e = int(_lib.load().fwn_tn_gemm_tile(int(m)))             # 128 x 128 or 256 x 256 output tiles at this m
+    tiles = sum(ntap * ((kx + e - 1) // e) * ((n + e - 1) // e) for kx, n, ntap in specs)
     return max(1, min((m + 63) // 64, 256 // max(1, tiles)))
 
 
