@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
         partial[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 #ifndef FWN_TN256_MIN
-#define FWN_TN256_MIN 8192
+#define FWN_TN256_MIN 2048
 #endif
 int fwn_tn_tile(int M) { return M >= FWN_TN256_MIN ? 256 : 128; }     // output tile edge of the weight-gradient GEMM
 void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipStream_t st) {
