@@ -51,7 +51,8 @@ struct RingGeom {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_le(int pending_chunks) {
     // pending_chunks (wave-uniform) in {0, 1, .., MAXC}: wait until at most pending*N DMAs remain
-    if (pending_chunks >= 3) FWN_WAIT_VMCNT(3 * N);
+    if (pending_chunks >= 4 && 4 * N <= 63) FWN_WAIT_VMCNT((4 * N <= 63 ? 4 * N : 63));      // ring depth 5
+    else if (pending_chunks >= 3) FWN_WAIT_VMCNT(3 * N);
     else if (pending_chunks == 2) FWN_WAIT_VMCNT(2 * N);
     else if (pending_chunks == 1) FWN_WAIT_VMCNT(N);
     else FWN_WAIT_VMCNT(0);
@@ -147,6 +148,9 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = c0;
     }
 
+    // context of the chunk the NEXT refill loads: looked up one iteration ahead (a problem whose chunk_ctx reads a
+    // descriptor table - fwn_gemm's segments - then has its scalar loads in flight under the previous chunk's MFMAs)
+    typename Prob::ChunkCtx ccn = p.template chunk_ctx<BK>(D - 1 < nq ? D - 1 : 0);
     for (int q = 0; q < nq; ++q) {
         // chunks issued so far: min(nq, q + D - 1); those after q may stay in flight
         const int pending = min(nq, q + D - 1) - (q + 1);
@@ -156,7 +160,6 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         // The refill of the slot freed by this barrier (chunk q+D-1) is spread over the k-steps,
         // so every DMA issue (~100 cycles of this wave's issue time) hides under MFMAs in flight.
         const bool refill = FWN_ABL_DMA && q + D - 1 < nq;
-        typename Prob::ChunkCtx ccn = p.template chunk_ctx<BK>(refill ? q + D - 1 : 0);
         if (FWN_ABL == 1) {
             if (refill) issue(q + D - 1);
             continue;
@@ -190,6 +193,7 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+        ccn = p.template chunk_ctx<BK>(q + D < nq ? q + D : 0);
     }
     if constexpr (KSP > 1) {
         // sum the KSP partial accumulators: groups 1.. park theirs in LDS (the ring is drained)

@@ -88,14 +88,14 @@ struct LinProb {
     }
 };
 
-template <int BM, int BN, int WM, int WN, int D>
-__global__ __launch_bounds__(64 * WM * WN) void lin_kernel(const fwn_gemm_desc g, int ntn, int nq_all) {
+template <int BM, int BN, int WM, int WN, int D, int KSP = 1>
+__global__ __launch_bounds__(64 * WM * WN * KSP) void lin_kernel(const fwn_gemm_desc g, int ntn, int nq_all) {
     const int per = (nq_all + g.nsplit - 1) / g.nsplit;
     const int q0 = (int)blockIdx.z * per;
     const int nq = max(0, min(per, nq_all - q0));      // an empty split still writes its zero partial
     const LinProb p{g, q0, nq, (float*)g.Y + (size_t)blockIdx.z * g.split_stride};
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    gemm_ring_body<BM, BN, WM, WN, 64, D, LinProb>(p, wg / ntn, wg % ntn);
+    gemm_ring_body<BM, BN, WM, WN, 64, D, LinProb, KSP>(p, wg / ntn, wg % ntn);
 }
 
 int fwn_gemm_launch(const fwn_gemm_desc* g, hipStream_t st) {
