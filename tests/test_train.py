@@ -260,12 +260,19 @@ def test_two_rank_data_parallel_step_matches_one_process_on_the_whole_batch(tmp_
         out = tmp_path / ("graph" + mode)
         out.mkdir()
         try:
-            procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(out))) for r in range(2)]
+            procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(out)), daemon=True) for r in range(2)]
             for p in procs:
                 p.start()
-            for p in procs:
-                p.join(timeout=300)
-                assert p.exitcode == 0
+            try:
+                for p in procs:
+                    p.join(timeout=240)
+                codes = [p.exitcode for p in procs]
+            finally:
+                for p in procs:         # a rank that died leaves its peer waiting in a collective: never leave it behind
+                    if p.is_alive():
+                        p.kill()
+                        p.join(timeout=10)
+            assert codes == [0, 0], codes
         finally:
             os.environ.pop("FWN_TRAIN_GRAPH")
         r0, r1 = (np.load(out / ("rank%d.npz" % r)) for r in range(2))

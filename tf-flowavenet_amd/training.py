@@ -250,15 +250,58 @@ class _TrainPack:
         self._small_tables()
 
     def _small_tables(self):
-        """Per-flow bias / scale vectors of the un-fused tail, in device channel order (parameter-sized)."""
+        """Per-flow bias / scale vectors of the un-fused tail, in device channel order (parameter-sized).  With the
+        masters in one flat vector all flows are done by a handful of batched gathers (``_batched_tables``)."""
         import torch
         hp = self.hp
+        if self.plan is not None and self.plan._dev_ready:
+            return self._batched_tables()
         for (i, j), t in self.flows.items():
             wp = weights.flow_prefix(i, j) + "/WaveNet"
             t["bskip"] = sum(self._f32("%s/ResBlock_%d/skip_conv/bias" % (wp, l)) for l in range(hp.n_layer))
             t["bfin"] = self._f32(wp + "/Conv_final/bias")
             t["bz"] = self._f32(wp + "/ZeroConv1d/bias").reshape(-1)[t["zcol"]].contiguous()
             t["ez"] = torch.exp(3.0 * self._f32(wp + "/ZeroConv1d/scale").reshape(-1))[t["zcol"]].contiguous()
+        self.an_logdet = None
+
+    def _batched_tables(self):
+        import torch
+        hp, P = self.hp, self.params
+        flat = self.plan._flat
+        if getattr(self, "_bt", None) is None:          # gather tables into the flat master vector, built once
+            off = lambda name: int(P[name].storage_offset())
+            skip = [[] for _ in range(hp.n_layer)]
+            bz, ez, an3, anw, spans = [], [], [], [], {}
+            zpos = 0
+            for (i, j), t in self.flows.items():
+                wp = weights.flow_prefix(i, j) + "/WaveNet"
+                for l in range(hp.n_layer):
+                    skip[l].append(off("%s/ResBlock_%d/skip_conv/bias" % (wp, l)) + np.arange(256))
+                zc = t["zcol"].cpu().numpy()
+                bz.append(off(wp + "/ZeroConv1d/bias") + zc)
+                ez.append(off(wp + "/ZeroConv1d/scale") + zc)
+                lg = off(weights.flow_prefix(i, j) + "/ActNorm/logs") + np.arange(2 << i)
+                an3.append(lg)
+                anw.append(np.full(2 << i, 3.0 / (2 << i)))          # sum over both planes of mean_C(3 logs)
+                spans[(i, j)] = (zpos, zpos + len(zc))
+                zpos += len(zc)
+            dev_i = lambda a: torch.from_numpy(np.concatenate(a).astype(np.int64)).to(self.dev)
+            self._bt = dict(skip=[dev_i(a) for a in skip], bz=dev_i(bz), ez=dev_i(ez), an3=dev_i(an3),
+                            anw=torch.from_numpy(np.concatenate(anw).astype(np.float32)).to(self.dev), spans=spans)
+        bt = self._bt
+        bskip = flat[bt["skip"][0]]
+        for l in range(1, hp.n_layer):
+            bskip = bskip + flat[bt["skip"][l]]
+        bz_all = flat[bt["bz"]]
+        ez_all = torch.exp(3.0 * flat[bt["ez"]])
+        # sum over flows of mean_C(3 logs) of both ActNorm planes: the parameter-only part of logdet (model.py:86-94)
+        self.an_logdet = (flat[bt["an3"]] * bt["anw"]).sum()
+        for f, ((i, j), t) in enumerate(self.flows.items()):
+            wp = weights.flow_prefix(i, j) + "/WaveNet"
+            lo, hi = bt["spans"][(i, j)]
+            t["bskip"] = bskip[f * 256:(f + 1) * 256]
+            t["bfin"] = self._f32(wp + "/Conv_final/bias")
+            t["bz"], t["ez"] = bz_all[lo:hi], ez_all[lo:hi]
 
     def _pack_flow_plan(self, i, j):
         """The backward's transposed / natural-order copies as jobs of the plan (transposed packing:
@@ -431,6 +474,7 @@ class GradEngine:
         self._gout = None
         self._on_block = None
         self._consts = {}
+        self._zeroed = set()
         # True: the caller refreshes the host-computed tables itself (``refresh_host_tables``) - a recorded
         # step keeps that device -> host -> device round trip outside its hipGraph
         self.external_host_tables = False
@@ -525,7 +569,8 @@ class GradEngine:
                 ca = cplanes[p].view(m, cin)
                 self._call("fwn_actnorm_apply", xa.data_ptr(), an[0].data_ptr(), m * ch, ch, st)
                 self._call("fwn_actnorm_apply", xb.data_ptr(), an[1].data_ptr(), m * ch, ch, st)
-                an_logdet = an_logdet + an[:, 3, :].sum() / (2 * ch)        # mean_C(3 logs): parameter-only scalar
+                if tp.an_logdet is None:
+                    an_logdet = an_logdet + an[:, 3, :].sum() / (2 * ch)    # mean_C(3 logs): parameter-only scalar
                 h = [b16(m, 256) for _ in range(L)]
                 o = [b16(m, 256) for _ in range(L)]
                 aux = [b16(m, 512) for _ in range(L)]
@@ -547,7 +592,7 @@ class GradEngine:
         partial_all = torch.cat(partials)
         out2 = f32(2)
         self._call("fwn_prior_logp", planes.data_ptr(), B * T, partial_all.data_ptr(), partial_all.numel(), out2.data_ptr(), st)
-        log_p, logdet = out2[0], out2[1] + an_logdet
+        log_p, logdet = out2[0], out2[1] + (an_logdet if tp.an_logdet is None else tp.an_logdet)
         loss = -(log_p + logdet)
 
         # ---------------- backward ----------------
@@ -575,7 +620,7 @@ class GradEngine:
             br = tp.br[i]
             # coupling
             ldz = t["ldz"]
-            dz = torch.zeros(m, ldz, dtype=torch.bfloat16, device=dev)
+            dz = (torch.zeros if ldz > 2 * ch else torch.empty)(m, ldz, dtype=torch.bfloat16, device=dev)   # padding columns must be 0
             dzz = f32(m, 2 * ch)
             self._call("fwn_coupling_bwd", gb.data_ptr(), xb.data_ptr(), z.data_ptr(), t["ez"].data_ptr(), m, ch,
                        1.0 / (2.0 * m * ch), dz.data_ptr(), ldz, dzz.data_ptr(), st)
@@ -609,7 +654,15 @@ class GradEngine:
                     d_o[l] = gemm([(dh_next, 256, 0, 0)], t["WresT"][l], 256, m, res=d_o[l], rscale=1.0 / SQH, oscale=SQH)
                 else:
                     for nm in ("kernel", "g", "bias"):      # dead res_conv of the last layer (modules.py:126-128)
-                        grads["%s/res_conv/%s" % (rp, nm)] = torch.zeros(shp["%s/res_conv/%s" % (rp, nm)], dtype=torch.float32, device=dev)
+                        key = "%s/res_conv/%s" % (rp, nm)
+                        go_ = self._gout
+                        if go_ is None:
+                            grads[key] = torch.zeros(shp[key], dtype=torch.float32, device=dev)
+                        else:       # nothing else ever writes there: zeroed the first time this buffer is seen
+                            if (key, go_[key].data_ptr()) not in self._zeroed:
+                                go_[key].zero_()
+                                self._zeroed.add((key, go_[key].data_ptr()))
+                            grads[key] = go_[key]
                 dpre = b16(m, 512)
                 self._call("fwn_gate_bwd", d_o[l].data_ptr(), aux[l].data_ptr(), m, dpre.data_ptr(), st)
                 jd = wgrad(h[l], dpre, 256, 512, (-dil, 0, dil))
