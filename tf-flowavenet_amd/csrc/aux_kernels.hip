@@ -87,13 +87,32 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const fwn_pack_job* __re
         // (scale * mul) first, like fwn_pack_bf16 fed a pre-multiplied scale: same bf16 bits
         return (sk >= 0 && sn >= 0) ? j.v[(size_t)sk * j.n_src + sn] * (sc ? sc[sn] * j.mul : j.mul) : 0.0f;
     };
-    if (j.transposed) {          // out[k][n], n contiguous like the source: straight through
-        const long total = (long)j.k_dst * j.n_dst;
+    if (j.transposed) {          // out[k][n], n contiguous like the source: straight through, 4 columns per thread
+        const int n4 = (j.n_dst + 3) / 4;
+        const long total = (long)j.k_dst * n4;
+        const bool vec = (j.ld_dst & 3) == 0 && (((uintptr_t)out) & 7) == 0;
         for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
-            const int kd = (int)(i / j.n_dst), nd = (int)(i % j.n_dst);
-            bool skip;
-            const float val = value(kd, nd, skip);
-            if (!skip) out[(size_t)kd * j.ld_dst + nd] = (bf16)val;
+            const int kd = (int)(i / n4), nd0 = (int)(i % n4) * 4;
+            float v[4];
+            bool skip[4], any_skip = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                skip[e] = true;
+                v[e] = 0.0f;
+                if (nd0 + e < j.n_dst) v[e] = value(kd, nd0 + e, skip[e]);
+                any_skip = any_skip || skip[e];
+            }
+            bf16* o = out + (size_t)kd * j.ld_dst + nd0;
+            if (vec && !any_skip) {
+                union { bf16 e[4]; uint2 u; } pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk.e[e] = (bf16)v[e];
+                *(uint2*)o = pk.u;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (!skip[e]) o[e] = (bf16)v[e];
+            }
         }
         return;
     }
@@ -125,7 +144,7 @@ void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack
                           int scale_ld, hipStream_t st) {
     if (nsjobs > 0)
         hipLaunchKernelGGL(wn_scale_jobs_kernel, dim3(nsjobs, (scale_ld + 31) / 32), dim3(1024), 0, st, sjobs, scales, scale_ld);
-    if (njobs > 0) hipLaunchKernelGGL(pack_jobs_kernel, dim3(njobs, 16), dim3(256), 0, st, jobs, scales, scale_ld);
+    if (njobs > 0) hipLaunchKernelGGL(pack_jobs_kernel, dim3(njobs, 160), dim3(256), 0, st, jobs, scales, scale_ld);
 }
 
 // ---- one Conv2DTranspose(filters=1, kernel (2s,3), strides (s,1), 'same') + LeakyReLU(0.4) --
