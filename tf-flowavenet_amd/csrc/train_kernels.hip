@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void flow_small_grads_final_kernel(const doubl
     }
 }
 int fwn_small_grads_blocks(long M, int Ch) {
-    long nb = M * Ch / 4096;
+    long nb = M * Ch / 512;           // two passes of a workgroup over its rows: the kernel is a latency chain, not bytes
     return (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
 }
 void fwn_small_grads_launch(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
