@@ -157,13 +157,16 @@ def test_recorded_step_replays_the_eager_step_bit_for_bit():
     inp = W.synthetic_inputs(hp, 4, 256)
     x0, c0 = torch.from_numpy(inp["x"]).reshape(4, 256).cuda(), torch.from_numpy(inp["c"]).cuda()
     batches = [(x0.roll(k, 0) * (1.0 - 0.05 * k), c0.roll(k, 0)) for k in range(5)]
+    # a second input shape in between: its own eager step + recording, the first shape's recording stays valid
+    half = (x0[:2, :128].contiguous(), c0[:2, :128 // hp.hop_size].contiguous())
+    batches = batches[:3] + [half, half, half] + batches[3:]
     runs = {}
     for graph in (False, True):
         tr = Trainer(hp, W.synthetic_params(hp, 11), graph=graph)
         tr.ddi(*batches[0])
         outs = [tuple(float(v) for v in tr.step(x, c)) for x, c in batches]
         runs[graph] = (outs, tr.opt.w.clone(), tr.opt.global_step)
-    assert runs[True][2] == runs[False][2] == 5
+    assert runs[True][2] == runs[False][2] == 8
     assert runs[True][0] == runs[False][0]
     assert torch.equal(runs[True][1], runs[False][1])
 
