@@ -201,10 +201,11 @@ int fwn_transpose_shift(const void* src, int M, int C, int ld_src, int shift0, i
 int fwn_reduce_splits(const float* partial, int nsplit, int64_t stride, int64_t n, float scale, float* out,
                       void* stream);
 
-/* Training forward of a gated layer: as fwn_gate (conditioning fused, never hoisted), also storing
- * aux [M][512] bf16 = (tanh f | sigmoid g) in natural channel order for fwn_gate_bwd. */
-int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void* ca, void* o, void* aux, int M,
-                   int Ti, void* stream);
+/* Training forward of a gated layer: as fwn_gate (conditioning fused from ca, or hoisted: P = c_a Wc of this layer
+ * from fwn_cond; exactly one of the two), also storing aux [M][512] bf16 = (tanh f | sigmoid g) in natural channel
+ * order for fwn_gate_bwd. */
+int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void* ca, const float* P, void* o, void* aux,
+                   int M, int Ti, void* stream);
 /* Element-wise pieces.  Planes are fp32 [M][Ch]; `an` points at one plane's table [4][Ch] = (shift,
  * scale, 1/scale, 3 logs) (fwn_flow_desc.an + role*4*Ch); Z is the ZeroConv output before its exp(3 scale)
  * factor ez [2Ch] (modules.py:51-56), fp32 [M][2Ch]: (log_s | t) = Z * ez.

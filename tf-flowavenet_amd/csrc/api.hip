@@ -142,14 +142,15 @@ int fwn_gate(const fwn_flow_desc* d, int layer, const void* h, const void* ca, c
     return check_launch("fwn_gate");
 }
 
-int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void* ca, void* o, void* aux, int M,
-                   int Ti, void* stream) {
+int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void* ca, const float* P, void* o, void* aux,
+                   int M, int Ti, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(layer >= 0 && layer < d->L, "fwn_gate_train: layer %d out of range", layer);
-    REQUIRE(h && ca && o && aux && M > 0 && Ti > 0 && M % Ti == 0, "fwn_gate_train: bad argument");
-    REQUIRE(ALIGNED16(h) && ALIGNED16(ca), "fwn_gate_train: buffers must be 16-byte aligned");
-    fwn_launch_gate(h, ca, nullptr, d->Wd[layer], d->Wc[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
+    REQUIRE(h && o && aux && M > 0 && Ti > 0 && M % Ti == 0, "fwn_gate_train: bad argument");
+    REQUIRE((ca != nullptr) != (P != nullptr), "fwn_gate_train: exactly one of ca / P");
+    REQUIRE(ALIGNED16(h) && (!ca || ALIGNED16(ca)), "fwn_gate_train: buffers must be 16-byte aligned");
+    fwn_launch_gate(h, ca, P, d->Wd[layer], d->Wc[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
                     d->cin, d->kcpad, aux, (hipStream_t)stream);
     return check_launch("fwn_gate_train");
 }

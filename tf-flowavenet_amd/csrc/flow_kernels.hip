@@ -271,7 +271,29 @@ struct GateProb {
         const srd_t so = make_srd(o, (uint32_t)((size_t)M * FWN_HID * 2));
         const int rbase = mrow0 + 4 * (lane >> 5);
         const uint32_t voff = (uint32_t)(rbase * FWN_HID + ch) * 2u;
-        if (P) {    // hoisted conditioning projection (fp32 [M][512], packed-N columns)
+        if (aux) {   // training forward: the two factors are stored for the gate's derivative (P: hoisted conditioning)
+            const srd_t sp = make_srd(P ? (const void*)P : (const void*)o, P ? (uint32_t)((size_t)M * 512 * 4) : 0u);
+            const uint32_t vp = (uint32_t)(rbase * 512 + ncol0 + lr) * 4u;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + mi * 32 + acc_row_c(r);
+                    if (row >= M) continue;
+                    float fa = acc[mi][0][r], ga = acc[mi][1][r];
+                    if (P) {
+                        const uint32_t sro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 4);
+                        fa += buf_load_f32(sp, vp, sro);
+                        ga += buf_load_f32(sp, vp, sro + 128);
+                    }
+                    const float a = __builtin_amdgcn_exp2f(fminf(fa, 40.0f));
+                    const float b = __builtin_amdgcn_exp2f(fminf(ga, 40.0f));
+                    const float tf = (1.0f - a) * __builtin_amdgcn_rcpf(1.0f + a), sg = __builtin_amdgcn_rcpf(1.0f + b);
+                    o[(size_t)row * FWN_HID + ch] = (bf16)(tf * sg);
+                    aux[(size_t)row * 512 + ch] = (bf16)tf;
+                    aux[(size_t)row * 512 + 256 + ch] = (bf16)sg;
+                }
+        } else if (P) {    // hoisted conditioning projection (fp32 [M][512], packed-N columns)
             const srd_t sp = make_srd(P, (uint32_t)((size_t)M * 512 * 4));
             const uint32_t vp = (uint32_t)(rbase * 512 + ncol0 + lr) * 4u;
 #pragma unroll
@@ -292,20 +314,6 @@ struct GateProb {
                     buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r + 1)) * FWN_HID * 2), y.y);
                 }
             }
-        } else if (aux) {   // training forward: the two factors are stored for the gate's derivative
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + mi * 32 + acc_row_c(r);
-                    if (row >= M) continue;
-                    const float a = __builtin_amdgcn_exp2f(fminf(acc[mi][0][r], 40.0f));
-                    const float b = __builtin_amdgcn_exp2f(fminf(acc[mi][1][r], 40.0f));
-                    const float tf = (1.0f - a) * __builtin_amdgcn_rcpf(1.0f + a), sg = __builtin_amdgcn_rcpf(1.0f + b);
-                    o[(size_t)row * FWN_HID + ch] = (bf16)(tf * sg);
-                    aux[(size_t)row * 512 + ch] = (bf16)tf;
-                    aux[(size_t)row * 512 + 256 + ch] = (bf16)sg;
-                }
         } else {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)

@@ -561,6 +561,16 @@ class GradEngine:
             ti = T // (2 * ch)
             m = B * ti
             cin = half * (2 << i)
+            # Small-M blocks: the conditioning projections P = c_a Wc of ALL flows and layers of the block in two
+            # batched launches (one per conditioning parity), as in inference (api.hip hoist_cond) - fused into every
+            # gate they would put K = cin (up to 10240) on the latency chain of a handful of workgroups.
+            P = None
+            if m < 4096:
+                d0 = pm.flow_descs[i * hp.n_flow]
+                P = f32(hp.n_flow, L, m, 512)
+                for g_ in range(min(2, hp.n_flow)):
+                    self._call("fwn_cond", cplanes[p ^ g_].data_ptr(), d0.Wc[0], P.data_ptr(), 512 * d0.kcpad, m * 512, g_, 2,
+                               (hp.n_flow - g_ + 1) // 2, L, m, cin, d0.kcpad, st)
             for j in range(hp.n_flow):
                 d = pm.flow_descs[i * hp.n_flow + j]
                 t = tp.flows[(i, j)]
@@ -576,8 +586,8 @@ class GradEngine:
                 aux = [b16(m, 512) for _ in range(L)]
                 self._call("fwn_front", C.byref(d), xa.data_ptr(), h[0].data_ptr(), None, m, ti, 0, st)
                 for l in range(L):
-                    self._call("fwn_gate_train", C.byref(d), l, h[l].data_ptr(), ca.data_ptr(), o[l].data_ptr(),
-                               aux[l].data_ptr(), m, ti, st)
+                    self._call("fwn_gate_train", C.byref(d), l, h[l].data_ptr(), ca.data_ptr() if P is None else None,
+                               P[j, l].data_ptr() if P is not None else None, o[l].data_ptr(), aux[l].data_ptr(), m, ti, st)
                     if l + 1 < L:
                         self._call("fwn_res", C.byref(d), l, o[l].data_ptr(), h[l].data_ptr(), h[l + 1].data_ptr(), m, st)
                 s_act = gemm([(o[l], 256, 0, l * 256) for l in range(L)], t["Wskip"], 256, m, bias=t["bskip"], relu=True)
