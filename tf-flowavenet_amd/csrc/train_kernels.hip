@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256) void flow_small_grads_final_kernel(const doubl
     }
 }
 int fwn_small_grads_blocks(long M, int Ch) {
-    long nb = M * Ch / 512;           // two passes of a workgroup over its rows: the kernel is a latency chain, not bytes
-    return (int)(nb < 1 ? 1 : nb > 512 ? 512 : nb);
+    long nb = M * Ch / 1024;          // few passes of a workgroup over its rows (a latency chain, not bytes); the final
+    return (int)(nb < 1 ? 1 : nb > 96 ? 96 : nb);      // pass adds the blocks serially: keep them few
 }
 void fwn_small_grads_launch(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
                             const long long* br, const long long* zc, double* partial, float* db, float* dlogs,
