@@ -424,3 +424,28 @@ def test_device_side_table_refresh_equals_the_host_tables():
     # float64 exp on the device vs numpy may differ in the last float64 bit: at most a handful of fp32 roundings flip
     assert diff.numel() <= 4, diff[:10]
     assert torch.allclose(dev_tables, host_tables, rtol=2e-7, atol=0)
+
+
+def test_full_size_model_recorded_step_equals_eager_step():
+    """The reference configuration (n_block=8, n_flow=6: 181 M parameters, conditioning widths up to 10240) on a short
+    batch: three steps recorded / replayed give the bits of three eager steps, losses finite (that the loss
+    falls is shown on the small model above and by tools/train_probe.py at full size: the first Adam steps of 181 M
+    parameters on two short clips are not monotonic)."""
+    from tf_flowavenet_amd.hparams import default_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import Trainer
+    hp = default_hparams()
+    inp = W.synthetic_inputs(hp, 2, 1024)
+    x, c = torch.from_numpy(inp["x"]).reshape(2, 1024).cuda(), torch.from_numpy(inp["c"]).cuda()
+    params = W.synthetic_params(hp, 1234)
+    res = {}
+    for graph in (True, False):
+        tr = Trainer(hp, params, graph=graph)
+        tr.ddi(x, c)
+        outs = [tuple(float(v) for v in tr.step(x, c)) for _ in range(3)]
+        res[graph] = (outs, tr.opt.w.clone())
+        del tr
+        torch.cuda.empty_cache()
+    assert all(np.isfinite(v) for o in res[True][0] for v in o)
+    assert res[True][0] == res[False][0]
+    assert torch.equal(res[True][1], res[False][1])
