@@ -849,7 +849,9 @@ class Trainer:
             try:
                 with torch.cuda.stream(side):
                     cur = [torch.cuda.CUDAGraph()]
-                    cur[0].capture_begin(pool=pool)
+                    # thread_local: other threads (the RCCL watchdog of a data-parallel run polls events) may call
+                    # HIP while this thread records
+                    cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
 
                     def cut(i):
                         if world == 1 and i >= 0:
@@ -857,7 +859,7 @@ class Trainer:
                         cur[0].capture_end()
                         segs.append((cur[0], i))
                         cur[0] = torch.cuda.CUDAGraph()
-                        cur[0].capture_begin(pool=pool)
+                        cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
 
                     loss, log_p, logdet, _ = self.engine.loss_and_grads(params, xs, cs, grad_out=gv, on_block_done=cut)
                     gnorm = self.opt.record_update()
