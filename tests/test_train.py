@@ -449,3 +449,27 @@ def test_full_size_model_recorded_step_equals_eager_step():
     assert all(np.isfinite(v) for o in res[True][0] for v in o)
     assert res[True][0] == res[False][0]
     assert torch.equal(res[True][1], res[False][1])
+
+
+def test_recording_failure_falls_back_to_eager_steps(monkeypatch):
+    """A runtime that refuses stream capture must not stop training: warn once, continue eagerly, same bits."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import Trainer
+    hp = small_hparams(n_block=2, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=8)
+    inp = W.synthetic_inputs(hp, 2, 128)
+    x, c = torch.from_numpy(inp["x"]).reshape(2, 128).cuda(), torch.from_numpy(inp["c"]).cuda()
+    ref = Trainer(hp, W.synthetic_params(hp, 11), graph=False)
+    ref.ddi(x, c)
+    want = [tuple(float(v) for v in ref.step(x, c)) for _ in range(3)]
+
+    def refuse(self, *a, **k):
+        raise RuntimeError("capture refused (test)")
+    monkeypatch.setattr(torch.cuda.CUDAGraph, "capture_begin", refuse)
+    tr = Trainer(hp, W.synthetic_params(hp, 11), graph=True)
+    tr.ddi(x, c)
+    with pytest.warns(UserWarning, match="continuing with eager steps"):
+        got = [tuple(float(v) for v in tr.step(x, c)) for _ in range(3)]
+    assert got == want and tr.graph is False and torch.equal(tr.opt.w, ref.opt.w)

@@ -846,9 +846,10 @@ class Trainer:
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             self.engine.external_host_tables = True
+            cur = [None]
             try:
                 with torch.cuda.stream(side):
-                    cur = [torch.cuda.CUDAGraph()]
+                    cur[0] = torch.cuda.CUDAGraph()
                     # thread_local: other threads (the RCCL watchdog of a data-parallel run polls events) may call
                     # HIP while this thread records
                     cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
@@ -865,6 +866,18 @@ class Trainer:
                     gnorm = self.opt.record_update()
                     cur[0].capture_end()
                     segs.append((cur[0], None))
+            except Exception as e:      # recording is an optimisation: a runtime that refuses it must not stop training
+                import warnings
+                try:
+                    if cur[0] is not None:
+                        cur[0].capture_end()
+                except Exception:
+                    pass
+                torch.cuda.synchronize(dev)
+                warnings.warn("recording the training step failed (%s: %s); continuing with eager steps" % (type(e).__name__, e))
+                self.graph = False
+                self.engine.external_host_tables = False
+                return self._step_eager(x, c)
             finally:
                 self.engine.external_host_tables = False
             torch.cuda.current_stream(dev).wait_stream(side)
