@@ -8,6 +8,7 @@ from tf_flowavenet_amd.hparams import default_hparams
 from tf_flowavenet_amd.model import FloWaveNet
 
 b, t, lanes, steps = 8, 16128, int(sys.argv[1]) if len(sys.argv) > 1 else 3, 30
+split = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # each pass as `split` chains of b / split clips
 hp = default_hparams()
 dev = torch.device("cuda", 0)
 model = FloWaveNet(hp, init=True, device=dev).load_params(W.synthetic_params(hp, 1234))
@@ -17,32 +18,37 @@ model.forward(x, c)
 ref_wav = model.reverse(z, c).clone()
 torch.cuda.synchronize()
 graphs = []
+bs = b // split
 for k in range(lanes):
     for direction in ("f", "i"):
-        s = torch.cuda.Stream(dev)
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                out = model.forward(x, c) if direction == "f" else model.reverse(z, c)     # allocates this stream's workspace
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            g.capture_begin()
-            out = model.forward(x, c) if direction == "f" else model.reverse(z, c)
-            g.capture_end()
-        graphs.append((s, g, out, direction))
+        for part in range(split):
+            xs, cs, zs = x[part * bs:(part + 1) * bs], c[part * bs:(part + 1) * bs], z[part * bs:(part + 1) * bs]
+            s = torch.cuda.Stream(dev)
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    out = model.forward(xs, cs) if direction == "f" else model.reverse(zs, cs)     # allocates this stream's workspace
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin()
+                out = model.forward(xs, cs) if direction == "f" else model.reverse(zs, cs)
+                g.capture_end()
+            graphs.append((s, g, out, direction, part))
 torch.cuda.synchronize()
 
 def run(n):
     cur = torch.cuda.current_stream(dev)
-    for s, _, _, _ in graphs:
+    for s, *_ in graphs:
         s.wait_stream(cur)
+    per = 2 * split
     for k in range(n):
-        for s, g, _, _ in graphs[2 * (k % lanes):2 * (k % lanes) + 2]:
+        for s, g, *_ in graphs[per * (k % lanes):per * (k % lanes) + per]:
             with torch.cuda.stream(s):
                 g.replay()
-    for s, _, _, _ in graphs:
+    for s, *_ in graphs:
         cur.wait_stream(s)
 
 run(3); torch.cuda.synchronize()
 t0 = time.perf_counter(); run(steps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-ok = all(torch.equal(o, ref_wav) for _, _, o, d in graphs if d == "i")
-print("lanes %d graph replay: %.3f ms per step, %.2f M samples/s, inverse outputs bit-identical to serial: %s" % (lanes, dt / steps * 1e3, b * t * steps / dt / 1e6, ok))
+ok = all(torch.equal(o, ref_wav[part * bs:(part + 1) * bs]) for _, _, o, d, part in graphs if d == "i")
+print("lanes %d split %d graph replay: %.3f ms per step, %.2f M samples/s (forward + inverse), inverse outputs bit-identical to serial: %s" % (
+    lanes, split, dt / steps * 1e3, 2 * b * t * steps / dt / 1e6, ok))
