@@ -22,13 +22,15 @@ struct RingGeom {
     static constexpr int KS = BK / 16;           // MFMA k-steps per chunk
     // byte offset of 16-byte piece c of row `row` in a [rows][BK] tile
     static __device__ __forceinline__ int off(int row, int c) {
-        if constexpr (BK == 64) return row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        if constexpr (BK == 128) return row * 256 + ((c ^ (row & 15)) << 4);
+        else if constexpr (BK == 64) return row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
         else return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
     }
     // lane -> (row within piece, global 16-byte piece index it must fetch for its linear LDS slot)
     static __device__ __forceinline__ int piece_row(int lane) { return lane / CPR; }
     static __device__ __forceinline__ int piece_c(int lane, int row) {
-        if constexpr (BK == 64) return (lane & 7) ^ ((row >> 1) & 7);
+        if constexpr (BK == 128) return (lane & 15) ^ (row & 15);
+        else if constexpr (BK == 64) return (lane & 7) ^ ((row >> 1) & 7);
         else return (lane & 3) ^ ((row >> 2) & 3);
     }
 };
