@@ -272,27 +272,31 @@ struct GateProb {
         const int rbase = mrow0 + 4 * (lane >> 5);
         const uint32_t voff = (uint32_t)(rbase * FWN_HID + ch) * 2u;
         if (aux) {   // training forward: the two factors are stored for the gate's derivative (P: hoisted conditioning)
+            // branch-free like the other paths: rows past M fall outside the buffer descriptors
             const srd_t sp = make_srd(P ? (const void*)P : (const void*)o, P ? (uint32_t)((size_t)M * 512 * 4) : 0u);
+            const srd_t sa = make_srd(aux, (uint32_t)((size_t)M * 512 * 2));
             const uint32_t vp = (uint32_t)(rbase * 512 + ncol0 + lr) * 4u;
+            const uint32_t va = (uint32_t)(rbase * 512 + ch) * 2u;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+                float pf[16], pg[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + mi * 32 + acc_row_c(r);
-                    if (row >= M) continue;
-                    float fa = acc[mi][0][r], ga = acc[mi][1][r];
-                    if (P) {
-                        const uint32_t sro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 4);
-                        fa += buf_load_f32(sp, vp, sro);
-                        ga += buf_load_f32(sp, vp, sro + 128);
-                    }
-                    const float a = __builtin_amdgcn_exp2f(fminf(fa, 40.0f));
-                    const float b = __builtin_amdgcn_exp2f(fminf(ga, 40.0f));
-                    const float tf = (1.0f - a) * __builtin_amdgcn_rcpf(1.0f + a), sg = __builtin_amdgcn_rcpf(1.0f + b);
-                    o[(size_t)row * FWN_HID + ch] = (bf16)(tf * sg);
-                    aux[(size_t)row * 512 + ch] = (bf16)tf;
-                    aux[(size_t)row * 512 + 256 + ch] = (bf16)sg;
+                    const uint32_t sro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 4);
+                    pf[r] = P ? buf_load_f32(sp, vp, sro) : 0.0f;
+                    pg[r] = P ? buf_load_f32(sp, vp, sro + 128) : 0.0f;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = __builtin_amdgcn_exp2f(fminf(acc[mi][0][r] + pf[r], 40.0f));
+                    const float b = __builtin_amdgcn_exp2f(fminf(acc[mi][1][r] + pg[r], 40.0f));
+                    const float tf = (1.0f - a) * __builtin_amdgcn_rcpf(1.0f + a), sg = __builtin_amdgcn_rcpf(1.0f + b);
+                    const uint32_t ro = (uint32_t)(mi * 32 + acc_row_c(r));
+                    buf_store_bf16(so, voff, ro * FWN_HID * 2, tf * sg);
+                    buf_store_bf16(sa, va, ro * 512 * 2, tf);
+                    buf_store_bf16(sa, va, ro * 512 * 2 + 512, sg);
+                }
+            }
         } else if (P) {    // hoisted conditioning projection (fp32 [M][512], packed-N columns)
             const srd_t sp = make_srd(P, (uint32_t)((size_t)M * 512 * 4));
             const uint32_t vp = (uint32_t)(rbase * 512 + ncol0 + lr) * 4u;
