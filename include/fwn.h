@@ -213,7 +213,8 @@ int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void*
  * fwn_coupling_fwd : y_b <- (y_b - t) exp(-log_s); partial[nblocks] <- sums of -log_s   (:124-141)
  * fwn_coupling_bwd : g = dL/d out_b <- dL/d y_b; out_b <- y_b; dZ (bf16, ld ldz) <- (dL/dlog_s | dL/dt)
  *                    with the log-det term cls = 1/(2 M Ch) added; dzz <- dZ * Z (ZeroConv scale gradient)
- * fwn_gate_bwd     : dpre [M][512] <- (do sg (1 - tf^2) | do tf sg (1 - sg))          (modules.py:124)
+ * fwn_gate_bwd     : dpre [M][512] <- (do sg (1 - tf^2) | do tf sg (1 - sg)), do bf16 [M][256] with row stride
+ *                    ld_do (a column block of a wider matrix is fine)                  (modules.py:124)
  * fwn_colsum_prod  : out[c] <- scale * sum_m A[m][c] * (B ? B[m][c] : 1), fp32 [M][C], fixed order;
  *                    partial: scratch of fwn_colsum_partials(M, C) floats
  * fwn_actnorm_bwd  : dy <- dy * scale; y <- y / scale - shift (the plane before ActNorm)
@@ -227,7 +228,7 @@ int fwn_coupling_fwd(float* yb, const float* Z, const float* ez, int64_t M, int 
                      void* stream);
 int fwn_coupling_bwd(float* g, float* out_b, const float* Z, const float* ez, int64_t M, int Ch, float cls, void* dZ,
                      int ldz, float* dzz, void* stream);
-int fwn_gate_bwd(const void* d_o, const void* aux, int64_t M, void* dpre, void* stream);
+int fwn_gate_bwd(const void* d_o, int ld_do, const void* aux, int64_t M, void* dpre, void* stream);
 int fwn_colsum_partials(int64_t M, int C);
 int fwn_colsum_prod(const float* A, const float* B, int64_t M, int C, float scale, float* partial, float* out,
                     void* stream);

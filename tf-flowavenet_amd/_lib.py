@@ -126,7 +126,7 @@ SIGNATURES = {
     "fwn_actnorm_apply": (C.c_int, [vp, vp, i64, C.c_int, vp]),
     "fwn_coupling_fwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp, C.c_int, vp]),
     "fwn_coupling_bwd": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, C.c_float, vp, C.c_int, vp, vp]),
-    "fwn_gate_bwd": (C.c_int, [vp, vp, i64, vp, vp]),
+    "fwn_gate_bwd": (C.c_int, [vp, C.c_int, vp, i64, vp, vp]),
     "fwn_colsum_partials": (C.c_int, [i64, C.c_int]),
     "fwn_colsum_prod": (C.c_int, [vp, vp, i64, C.c_int, C.c_float, vp, vp, vp]),
     "fwn_actnorm_bwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),

@@ -302,9 +302,9 @@ int fwn_coupling_bwd(float* g, float* out_b, const float* Z, const float* ez, in
     fwn_ew_coupling_bwd(g, out_b, Z, ez, (long)M * Ch, Ch, cls, dZ, ldz, dzz, (hipStream_t)stream);
     return check_launch("fwn_coupling_bwd");
 }
-int fwn_gate_bwd(const void* d_o, const void* aux, int64_t M, void* dpre, void* stream) {
-    REQUIRE(d_o && aux && dpre && M > 0, "fwn_gate_bwd: bad argument");
-    fwn_ew_gate_bwd(d_o, aux, (long)M * 256, dpre, (hipStream_t)stream);
+int fwn_gate_bwd(const void* d_o, int ld_do, const void* aux, int64_t M, void* dpre, void* stream) {
+    REQUIRE(d_o && aux && dpre && M > 0 && ld_do >= 256, "fwn_gate_bwd: bad argument");
+    fwn_ew_gate_bwd(d_o, ld_do, aux, (long)M * 256, dpre, (hipStream_t)stream);
     return check_launch("fwn_gate_bwd");
 }
 int fwn_colsum_partials(int64_t M, int C_) { return fwn_colsum_blocks((long)M, C_) * C_; }

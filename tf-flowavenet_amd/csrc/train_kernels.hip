@@ -228,12 +228,12 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ g
 }
 // gate backward: aux = [tanh f | sigmoid g] (bf16 [M][512]), do_ (bf16 [M][256]) ->
 // dpre = [do * sg * (1 - tf^2) | do * tf * sg * (1 - sg)]  (bf16 [M][512], natural channel order)
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16* __restrict__ do_, const bf16* __restrict__ aux,
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16* __restrict__ do_, int ld_do, const bf16* __restrict__ aux,
                                                        long n, bf16* __restrict__ dpre) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const long m = i >> 8;
         const int c = (int)(i & 255);
-        const float d = (float)do_[i], tf = (float)aux[m * 512 + c], sg = (float)aux[m * 512 + 256 + c];
+        const float d = (float)do_[m * ld_do + c], tf = (float)aux[m * 512 + c], sg = (float)aux[m * 512 + 256 + c];
         dpre[m * 512 + c] = (bf16)(d * sg * (1.0f - tf * tf));
         dpre[m * 512 + 256 + c] = (bf16)(d * tf * sg * (1.0f - sg));
     }
@@ -525,8 +525,8 @@ void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, l
                          int ldz, float* dzz, hipStream_t st) {
     hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, ob, Z, ez, n, Ch, cls, (bf16*)dZ, ldz, dzz);
 }
-void fwn_ew_gate_bwd(const void* do_, const void* aux, long n, void* dpre, hipStream_t st) {
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, (const bf16*)do_, (const bf16*)aux, n, (bf16*)dpre);
+void fwn_ew_gate_bwd(const void* do_, int ld_do, const void* aux, long n, void* dpre, hipStream_t st) {
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, (const bf16*)do_, ld_do, (const bf16*)aux, n, (bf16*)dpre);
 }
 int fwn_colsum_blocks(long M, int C) {
     long nb = M / 256;                                    // >= 256 rows per block

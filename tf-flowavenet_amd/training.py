@@ -345,7 +345,9 @@ class _TrainPack:
                 job(rp + "/res_conv", id256, 256, id256, 256, wrt, 0, True)
                 t["WresT"].append(wrt)
             job(rp + "/skip_conv", id256, 256, id256, 256, t["Wskip"], l * 256, False)
-            wst = bz(256, 256)
+            if l == 0:
+                t["WskipT_all"] = bz(L * 256, 256)              # the L transposed skip convs stacked along N: one GEMM for all do_l
+            wst = t["WskipT_all"][l * 256:(l + 1) * 256]
             job(rp + "/skip_conv", id256, 256, id256, 256, wst, 0, True)
             t["WskipT"].append(wst)
         t["Wfin"], t["WfinT"] = bz(256, 256), bz(256, 256)
@@ -442,6 +444,7 @@ class _TrainPack:
             wskip[:, l * 256:(l + 1) * 256] = ws
             t["WskipT"].append(transpose_shift(ws, 256, 256, ld_dst=256))
         t["Wskip"] = wskip
+        t["WskipT_all"] = torch.cat(t["WskipT"], 0).contiguous()
         wfin = bz(256, 256)
         self._pack(wp + "/Conv_final", id256, id256, 256, 256, wfin)
         t["Wfin"], t["WfinT"] = wfin, transpose_shift(wfin, 256, 256, ld_dst=256)
@@ -650,11 +653,11 @@ class GradEngine:
             wn(wp + "/ZeroConv1d", wgrad(u_act, dz, 256, ldz), 256, 0, (1, 256, 2 * ch), col_src=t["zinv32"])
             wn(wp + "/Conv_final", wgrad(s_act, du, 256, 256), 256, 0, (1, 256, 256))
             ds = gemm([(du, 256, 0, 0)], t["WfinT"], 256, m, mask=s_act)
-            d_o = []
+            d_all = gemm([(ds, 256, 0, 0)], t["WskipT_all"], L * 256, m)       # do_l = dS Wskip_l for every layer at once
+            d_o = [d_all[:, l * 256:(l + 1) * 256] for l in range(L)]
             for l in range(L):
                 rp = "%s/ResBlock_%d" % (wp, l)
                 wn(rp + "/skip_conv", wgrad(o[l], ds, 256, 256), 256, 0, (1, 256, 256))
-                d_o.append(gemm([(ds, 256, 0, 0)], t["WskipT"][l], 256, m))
             dh_next = None
             for l in range(L - 1, -1, -1):
                 rp = "%s/ResBlock_%d" % (wp, l)
@@ -674,7 +677,7 @@ class GradEngine:
                                 self._zeroed.add((key, go_[key].data_ptr()))
                             grads[key] = go_[key]
                 dpre = b16(m, 512)
-                self._call("fwn_gate_bwd", d_o[l].data_ptr(), aux[l].data_ptr(), m, dpre.data_ptr(), st)
+                self._call("fwn_gate_bwd", d_o[l].data_ptr(), int(d_o[l].stride(0)), aux[l].data_ptr(), m, dpre.data_ptr(), st)
                 jd = wgrad(h[l], dpre, 256, 512, (-dil, 0, dil))
                 wn(rp + "/Conv_filter", jd, 768, 0, (3, 256, 256))
                 wn(rp + "/Conv_gate", jd, 768, 256, (3, 256, 256))
