@@ -224,6 +224,8 @@ int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void*
  *                    bias_row (< 0 / NULL: none); V fp32 [K][N], g [N] -> dV, dg; g == NULL: dV = dW (no
  *                    weight norm)   (convolutional.py:73-80) */
 int fwn_actnorm_apply(float* x, const float* an, int64_t n, int Ch, void* stream);
+/* Both planes of a flow in one launch: an2 = the flow's table [2][4][Ch] (fwn_flow_desc.an), n elements per plane. */
+int fwn_actnorm_apply2(float* xa, float* xb, const float* an2, int64_t n, int Ch, void* stream);
 int fwn_coupling_fwd(float* yb, const float* Z, const float* ez, int64_t M, int Ch, float* partial, int nblocks,
                      void* stream);
 int fwn_coupling_bwd(float* g, float* out_b, const float* Z, const float* ez, int64_t M, int Ch, float cls, void* dZ,

@@ -124,6 +124,7 @@ SIGNATURES = {
     "fwn_upsample_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "fwn_gate_train": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "fwn_actnorm_apply": (C.c_int, [vp, vp, i64, C.c_int, vp]),
+    "fwn_actnorm_apply2": (C.c_int, [vp, vp, vp, i64, C.c_int, vp]),
     "fwn_coupling_fwd": (C.c_int, [vp, vp, vp, i64, C.c_int, vp, C.c_int, vp]),
     "fwn_coupling_bwd": (C.c_int, [vp, vp, vp, vp, i64, C.c_int, C.c_float, vp, C.c_int, vp, vp]),
     "fwn_gate_bwd": (C.c_int, [vp, C.c_int, vp, i64, vp, vp]),

@@ -290,6 +290,11 @@ int fwn_actnorm_apply(float* x, const float* an, int64_t n, int Ch, void* stream
     fwn_ew_actnorm_fwd(x, an, (long)n, Ch, (hipStream_t)stream);
     return check_launch("fwn_actnorm_apply");
 }
+int fwn_actnorm_apply2(float* xa, float* xb, const float* an2, int64_t n, int Ch, void* stream) {
+    REQUIRE(xa && xb && an2 && n > 0 && Ch >= 1 && (Ch & (Ch - 1)) == 0, "fwn_actnorm_apply2: bad argument");
+    fwn_ew_actnorm_fwd2(xa, xb, an2, (long)n, Ch, (hipStream_t)stream);
+    return check_launch("fwn_actnorm_apply2");
+}
 int fwn_coupling_fwd(float* yb, const float* Z, const float* ez, int64_t M, int Ch, float* partial, int nblocks,
                      void* stream) {
     REQUIRE(yb && Z && ez && partial && M > 0 && Ch >= 1 && nblocks >= 1, "fwn_coupling_fwd: bad argument");

@@ -44,6 +44,7 @@ void fwn_transpose_launch(const void* src, int M, int C, int ld_src, int shift0,
 void fwn_reduce_splits_launch(const float* partial, int nsplit, long stride, long n, float scale, float* out,
                               hipStream_t st);
 void fwn_ew_actnorm_fwd(float* x, const float* an, long n, int Ch, hipStream_t st);
+void fwn_ew_actnorm_fwd2(float* xa, float* xb, const float* an2, long n, int Ch, hipStream_t st);
 void fwn_ew_coupling_fwd(float* yb, const float* Z, const float* ez, long n, int Ch, float* partial, int nblocks,
                          hipStream_t st);
 void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,

@@ -180,6 +180,18 @@ __global__ __launch_bounds__(256) void actnorm_fwd_kernel(float* __restrict__ x,
         x[i] = (x[i] + an[c]) * an[Ch + c];
     }
 }
+// both planes of a flow in one launch: an2 = [2][4][Ch] (the flow's table: plane a, plane b)
+__global__ __launch_bounds__(256) void actnorm_fwd2_kernel(float* __restrict__ xa, float* __restrict__ xb,
+                                                           const float* __restrict__ an2, long n, int Ch) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 2 * n; i += (long)gridDim.x * 256) {
+        const bool second = i >= n;
+        float* x = second ? xb : xa;
+        const float* an = an2 + (second ? 4 * Ch : 0);
+        const long e = second ? i - n : i;
+        const int c = (int)(e & (Ch - 1));
+        x[e] = (x[e] + an[c]) * an[Ch + c];
+    }
+}
 // Z here is the ZeroConv output BEFORE its exp(3 scale) factor ez (modules.py:51-56): (log_s | t) = Z * ez.
 // coupling forward (model.py:124-141): out_b = (y_b - t) exp(-log_s), in place over y_b;
 // partial[block] = sum(-log_s) of the block's elements (fixed order).
@@ -516,6 +528,9 @@ void fwn_wn_group_launch(const fwn_wn_job* jobs, int njobs, double* scratch, hip
 static inline unsigned ew_grid(long n) { long b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 void fwn_ew_actnorm_fwd(float* x, const float* an, long n, int Ch, hipStream_t st) {
     hipLaunchKernelGGL(actnorm_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, an, n, Ch);
+}
+void fwn_ew_actnorm_fwd2(float* xa, float* xb, const float* an2, long n, int Ch, hipStream_t st) {
+    hipLaunchKernelGGL(actnorm_fwd2_kernel, dim3(ew_grid(2 * n)), dim3(256), 0, st, xa, xb, an2, n, Ch);
 }
 void fwn_ew_coupling_fwd(float* yb, const float* Z, const float* ez, long n, int Ch, float* partial, int nblocks,
                          hipStream_t st) {

@@ -580,8 +580,7 @@ class GradEngine:
                 an = pm.an[(i, j)]                                   # [2][4][Ch]
                 xa, xb = planes[p].view(m, ch), planes[p ^ 1].view(m, ch)
                 ca = cplanes[p].view(m, cin)
-                self._call("fwn_actnorm_apply", xa.data_ptr(), an[0].data_ptr(), m * ch, ch, st)
-                self._call("fwn_actnorm_apply", xb.data_ptr(), an[1].data_ptr(), m * ch, ch, st)
+                self._call("fwn_actnorm_apply2", xa.data_ptr(), xb.data_ptr(), an.data_ptr(), m * ch, ch, st)
                 if tp.an_logdet is None:
                     an_logdet = an_logdet + an[:, 3, :].sum() / (2 * ch)    # mean_C(3 logs): parameter-only scalar
                 h = [b16(m, 256) for _ in range(L)]
