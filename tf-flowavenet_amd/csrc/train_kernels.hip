@@ -328,7 +328,14 @@ __global__ __launch_bounds__(256) void flow_small_grads_final_kernel(const doubl
                                                                      float* __restrict__ dlogs, float* __restrict__ dzscale) {
     for (int idx = threadIdx.x; idx < 6 * Ch; idx += 256) {
         double a = 0.0;
-        for (int b = 0; b < nb; ++b) a += partial[(size_t)b * 6 * Ch + idx];
+        for (int b0 = 0; b0 < nb; b0 += 8) {          // 8 loads in flight, added in block order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(b0 + u, nb - 1) * 6 * Ch + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b0 + u < nb) a += v[u];
+        }
         if (idx < 4 * Ch) {
             const int role = idx / (2 * Ch), which = (idx / Ch) & 1, c = idx % Ch;
             const int dst = role * Ch + (int)br[c];
