@@ -235,15 +235,128 @@ def test_wav_writer_and_checkpoint_loader(tmp_path):
     assert list(S.load_checkpoint(str(tmp_path))) == ["a"]
 
 
+# The reference's variable names for n_block=1, n_flow=1, n_layer=2, written out by hand from its scopes:
+# train.py:53 'vocoder' / model.py:283 'FloWaveNet' / :297 'Block_%d' / :218 'Flow_%d' / :13 'ActNorm' (b, logs :57,71) /
+# :110 'AffineCoupling' / modules.py:136 'WaveNet' / :144 'Conv_front' / :152 'ResBlock_%d_%d' / :73-74 'Conv_filter',
+# 'Conv_gate' / :158 'Conv_final' / :41 'ZeroConv1d' (+ 'scale' :49); every un-named tf.layers layer opens
+# variable_scope(default_name='conv1d' | 'conv2d_transpose') at its FIRST CALL (modules.py:113-127: filter_conv_c,
+# gate_conv_c, res_conv, skip_conv; model.py:401-402: the two up-sampling convs), variables 'kernel', 'wn/g', 'bias'
+# (convolutional.py:64-87,167-192).
+_P = "vocoder/FloWaveNet/"
+_W = _P + "Block_0/Flow_0/AffineCoupling/WaveNet/"
+_O = "Block_0/Flow_0/WaveNet/"
+REFERENCE_NAMES = {
+    _P + "conv2d_transpose/kernel:0": "upsample_0/kernel",
+    _P + "conv2d_transpose/wn/g:0": "upsample_0/g",
+    _P + "conv2d_transpose/bias:0": "upsample_0/bias",
+    _P + "conv2d_transpose_1/kernel:0": "upsample_1/kernel",
+    _P + "conv2d_transpose_1/wn/g:0": "upsample_1/g",
+    _P + "conv2d_transpose_1/bias:0": "upsample_1/bias",
+    _P + "Block_0/Flow_0/ActNorm/b:0": "Block_0/Flow_0/ActNorm/b",
+    _P + "Block_0/Flow_0/ActNorm/logs:0": "Block_0/Flow_0/ActNorm/logs",
+    _W + "Conv_front/conv1d/kernel:0": _O + "Conv_front/kernel",
+    _W + "Conv_front/conv1d/wn/g:0": _O + "Conv_front/g",
+    _W + "Conv_front/conv1d/bias:0": _O + "Conv_front/bias",
+    _W + "ResBlock_0_0/Conv_filter/conv1d/kernel:0": _O + "ResBlock_0/Conv_filter/kernel",
+    _W + "ResBlock_0_0/Conv_filter/conv1d/wn/g:0": _O + "ResBlock_0/Conv_filter/g",
+    _W + "ResBlock_0_0/Conv_filter/conv1d/bias:0": _O + "ResBlock_0/Conv_filter/bias",
+    _W + "ResBlock_0_0/Conv_gate/conv1d/kernel:0": _O + "ResBlock_0/Conv_gate/kernel",
+    _W + "ResBlock_0_0/Conv_gate/conv1d/wn/g:0": _O + "ResBlock_0/Conv_gate/g",
+    _W + "ResBlock_0_0/Conv_gate/conv1d/bias:0": _O + "ResBlock_0/Conv_gate/bias",
+    _W + "ResBlock_0_0/conv1d/kernel:0": _O + "ResBlock_0/filter_conv_c/kernel",
+    _W + "ResBlock_0_0/conv1d/wn/g:0": _O + "ResBlock_0/filter_conv_c/g",
+    _W + "ResBlock_0_0/conv1d/bias:0": _O + "ResBlock_0/filter_conv_c/bias",
+    _W + "ResBlock_0_0/conv1d_1/kernel:0": _O + "ResBlock_0/gate_conv_c/kernel",
+    _W + "ResBlock_0_0/conv1d_1/wn/g:0": _O + "ResBlock_0/gate_conv_c/g",
+    _W + "ResBlock_0_0/conv1d_1/bias:0": _O + "ResBlock_0/gate_conv_c/bias",
+    _W + "ResBlock_0_0/conv1d_2/kernel:0": _O + "ResBlock_0/res_conv/kernel",
+    _W + "ResBlock_0_0/conv1d_2/wn/g:0": _O + "ResBlock_0/res_conv/g",
+    _W + "ResBlock_0_0/conv1d_2/bias:0": _O + "ResBlock_0/res_conv/bias",
+    _W + "ResBlock_0_0/conv1d_3/kernel:0": _O + "ResBlock_0/skip_conv/kernel",
+    _W + "ResBlock_0_0/conv1d_3/wn/g:0": _O + "ResBlock_0/skip_conv/g",
+    _W + "ResBlock_0_0/conv1d_3/bias:0": _O + "ResBlock_0/skip_conv/bias",
+    _W + "ResBlock_0_1/Conv_filter/conv1d/kernel:0": _O + "ResBlock_1/Conv_filter/kernel",
+    _W + "ResBlock_0_1/Conv_filter/conv1d/wn/g:0": _O + "ResBlock_1/Conv_filter/g",
+    _W + "ResBlock_0_1/Conv_filter/conv1d/bias:0": _O + "ResBlock_1/Conv_filter/bias",
+    _W + "ResBlock_0_1/Conv_gate/conv1d/kernel:0": _O + "ResBlock_1/Conv_gate/kernel",
+    _W + "ResBlock_0_1/Conv_gate/conv1d/wn/g:0": _O + "ResBlock_1/Conv_gate/g",
+    _W + "ResBlock_0_1/Conv_gate/conv1d/bias:0": _O + "ResBlock_1/Conv_gate/bias",
+    _W + "ResBlock_0_1/conv1d/kernel:0": _O + "ResBlock_1/filter_conv_c/kernel",
+    _W + "ResBlock_0_1/conv1d/wn/g:0": _O + "ResBlock_1/filter_conv_c/g",
+    _W + "ResBlock_0_1/conv1d/bias:0": _O + "ResBlock_1/filter_conv_c/bias",
+    _W + "ResBlock_0_1/conv1d_1/kernel:0": _O + "ResBlock_1/gate_conv_c/kernel",
+    _W + "ResBlock_0_1/conv1d_1/wn/g:0": _O + "ResBlock_1/gate_conv_c/g",
+    _W + "ResBlock_0_1/conv1d_1/bias:0": _O + "ResBlock_1/gate_conv_c/bias",
+    _W + "ResBlock_0_1/conv1d_2/kernel:0": _O + "ResBlock_1/res_conv/kernel",
+    _W + "ResBlock_0_1/conv1d_2/wn/g:0": _O + "ResBlock_1/res_conv/g",
+    _W + "ResBlock_0_1/conv1d_2/bias:0": _O + "ResBlock_1/res_conv/bias",
+    _W + "ResBlock_0_1/conv1d_3/kernel:0": _O + "ResBlock_1/skip_conv/kernel",
+    _W + "ResBlock_0_1/conv1d_3/wn/g:0": _O + "ResBlock_1/skip_conv/g",
+    _W + "ResBlock_0_1/conv1d_3/bias:0": _O + "ResBlock_1/skip_conv/bias",
+    _W + "Conv_final/conv1d/kernel:0": _O + "Conv_final/kernel",
+    _W + "Conv_final/conv1d/wn/g:0": _O + "Conv_final/g",
+    _W + "Conv_final/conv1d/bias:0": _O + "Conv_final/bias",
+    _W + "ZeroConv1d/conv1d/kernel:0": _O + "ZeroConv1d/kernel",
+    _W + "ZeroConv1d/conv1d/bias:0": _O + "ZeroConv1d/bias",
+    _W + "ZeroConv1d/scale:0": _O + "ZeroConv1d/scale",
+}
+
+
 def test_reference_variable_names_map_onto_parameter_names():
-    from tf_flowavenet_amd.weights import from_reference_names, param_shapes, synthetic_params
-    hp = small_hparams()
+    """A dump of a reference checkpoint (names written out literally above, NOT derived from this package) maps onto
+    exactly the parameters load_params wants - together with the slots a tf.train.Saver(global_variables) file also
+    holds (train.py:190)."""
+    from tf_flowavenet_amd.weights import from_reference_names, param_shapes, synthetic_params, to_reference_names
+    hp = small_hparams(n_block=1, n_flow=1, n_layer=2)
     p = synthetic_params(hp, 3)
-    dumped = {"vocoder/FloWaveNet/%s:0" % k: v for k, v in p.items()}
-    dumped["vocoder/FloWaveNet/Block_0/Flow_0/ActNorm/b/Adam:0"] = np.zeros(1)
-    dumped["vocoder/FloWaveNet/Block_0/Flow_0/ActNorm/b/Adam_1:0"] = np.zeros(1)
+    assert sorted(REFERENCE_NAMES.values()) == sorted(param_shapes(hp))
+    dumped = {tf_name: p[ours] for tf_name, ours in REFERENCE_NAMES.items()}
+    dumped[_P + "Block_0/Flow_0/ActNorm/b/Adam:0"] = np.zeros(1)
+    dumped[_W + "ResBlock_0_0/conv1d_2/wn/g/Adam_1:0"] = np.zeros(1)
     dumped["global_step:0"] = np.zeros(())
     dumped["beta1_power:0"] = np.zeros(())
-    dumped["vocoder/FloWaveNet/Block_0/Flow_0/WaveNet/Conv_front/kernel/fp16_cast:0"] = np.zeros(1)
+    dumped["beta2_power:0"] = np.zeros(())
+    dumped[_W + "Conv_front/conv1d/kernel/fp16_cast:0"] = np.zeros(1)
+    dumped[_P + "speaker_embeddings:0"] = np.zeros((2, 4))
     got = from_reference_names(dumped)
-    assert sorted(got) == sorted(param_shapes(hp)) and all(got[k] is p[k] for k in p)
+    assert sorted(got) == sorted(param_shapes(hp))
+    for tf_name, ours in REFERENCE_NAMES.items():
+        assert got[ours] is p[ours], (tf_name, ours)
+    # the inverse map regenerates the literal list
+    assert sorted(k + ":0" for k in to_reference_names(p)) == sorted(REFERENCE_NAMES)
+    # synthesize.py builds its graph under the same 'vocoder' scope (synthesize.py:11); a dump without it, or one
+    # already in this package's names, also loads
+    assert sorted(from_reference_names({k[len("vocoder/"):] if k.startswith("vocoder/") else k: v for k, v in dumped.items()})) == sorted(param_shapes(hp))
+    assert from_reference_names(p) == dict(p)
+
+
+def test_reference_name_map_survives_construction_order_numbering():
+    """If the four bare 1x1 convs of a ResBlock were numbered in construction order instead (res, skip, filter_c,
+    gate_c: modules.py:75-94), kernel shapes + order inside each pair still identify them."""
+    from tf_flowavenet_amd.weights import from_reference_names, synthetic_params
+    hp = small_hparams(n_block=1, n_flow=1, n_layer=2)
+    p = synthetic_params(hp, 3)
+    alt = {"conv1d": "conv1d_2", "conv1d_1": "conv1d_3", "conv1d_2": "conv1d", "conv1d_3": "conv1d_1"}
+    dumped = {}
+    for tf_name, ours in REFERENCE_NAMES.items():
+        parts = tf_name.split("/")
+        if parts[-3].startswith("ResBlock_0_") and parts[-2] in alt:            # .../ResBlock_0_n/conv1d_k/kernel
+            parts[-2] = alt[parts[-2]]
+        elif parts[-4].startswith("ResBlock_0_") and parts[-3] in alt and parts[-2] == "wn":
+            parts[-3] = alt[parts[-3]]
+        dumped["/".join(parts)] = p[ours]
+    got = from_reference_names(dumped)
+    assert all(got[k] is p[k] for k in p)
+    with pytest.raises(KeyError):
+        from_reference_names({_W + "ResBlock_1_0/conv1d/kernel:0": np.zeros((1, 8, 256))})
+
+
+def test_load_params_accepts_a_reference_named_dump(tmp_path):
+    """synthesize.load_checkpoint on an .npz holding the reference's variable names."""
+    from tf_flowavenet_amd import synthesize as S
+    from tf_flowavenet_amd.weights import param_shapes, synthetic_params, to_reference_names
+    hp = small_hparams(n_block=2, n_flow=2)
+    p = synthetic_params(hp, 4)
+    np.savez(tmp_path / "dump.npz", **{k + ":0": v for k, v in to_reference_names(p).items()})
+    got = S.load_checkpoint(str(tmp_path))
+    assert sorted(got) == sorted(param_shapes(hp)) and all(np.array_equal(got[k], p[k]) for k in p)

@@ -25,22 +25,135 @@ def flow_prefix(i: int, j: int) -> str:
     return "Block_%d/Flow_%d" % (i, j)
 
 
+_LEAF = {"kernel": "kernel", "wn/g": "g", "bias": "bias"}
+_BARE = ("filter_conv_c", "gate_conv_c", "res_conv", "skip_conv")      # first-call order, modules.py:113-127
+
+
+def _split_layer_var(rest):
+    """``<keras layer scope>/<kernel | wn/g | bias>`` (convolutional.py:64-87) -> (layer scope, our leaf) or None."""
+    for tf_leaf, leaf in _LEAF.items():
+        if rest.endswith("/" + tf_leaf):
+            return rest[:-len(tf_leaf) - 1], leaf
+    return None
+
+
+def _layer_index(scope, base):
+    """``conv1d`` -> 0, ``conv1d_3`` -> 3 (variable_scope(default_name=...) numbering); None if it is not `base`."""
+    if scope == base:
+        return 0
+    if scope.startswith(base + "_") and scope[len(base) + 1:].isdigit():
+        return int(scope[len(base) + 1:])
+    return None
+
+
 def from_reference_names(variables: dict) -> dict:
-    """Variables dumped from one of the reference's TF checkpoints (``vocoder/FloWaveNet/<scope>/<var>[:0]``,
-    train.py:53 + model.py:283) -> this package's parameter names.  Optimiser slots (``.../Adam``,
-    ``.../Adam_1``, ``beta*_power``), ``global_step`` and the cached low-precision casts of
-    ``fp16_dtype_getter`` (utils.py:19-29) are dropped; names without the prefix pass through."""
-    out = {}
+    """Variables dumped from one of the reference's TF checkpoints -> this package's parameter names.
+
+    The reference's variable names are its nested ``tf.variable_scope``s plus the scope every un-named
+    ``tf.layers`` layer opens at its first call (``variable_scope(default_name=<snake-cased class name>)``):
+
+    ======================================================================  ==========================================
+    TF variable (train.py:53 + model.py:283 prefix ``vocoder/FloWaveNet/``)   parameter here
+    ======================================================================  ==========================================
+    ``conv2d_transpose[_n]/{kernel,wn/g,bias}`` (model.py:301-311,398-404)   ``upsample_n/{kernel,g,bias}``
+    ``Block_i/Flow_j/ActNorm/{b,logs}`` (model.py:13,57,71,181,218,297)       unchanged
+    ``Block_i/Flow_j/AffineCoupling/WaveNet/...`` (model.py:110,114)          ``Block_i/Flow_j/WaveNet/...``
+    ``.../Conv_front|Conv_final/conv1d/{kernel,wn/g,bias}`` (modules.py:8,17) ``.../Conv_front|Conv_final/{kernel,g,bias}``
+    ``.../ResBlock_0_n/Conv_filter|Conv_gate/conv1d/...`` (modules.py:73,152)  ``.../ResBlock_n/Conv_filter|Conv_gate/...``
+    ``.../ResBlock_0_n/conv1d[_k]/...``: the four un-scoped 1x1 convs, k in    ``.../ResBlock_n/{filter_conv_c,gate_conv_c,
+    first-call order filter_c, gate_c, res, skip (modules.py:113-127)          res_conv,skip_conv}/...``
+    ``.../ZeroConv1d/conv1d/{kernel,bias}``, ``.../ZeroConv1d/scale`` (:41-49)  ``.../ZeroConv1d/{kernel,bias,scale}``
+    ======================================================================  ==========================================
+
+    The four bare convs of a ResBlock are told apart by kernel shape (the conditioning pair has C_in = cin != 256
+    = the res / skip pair) and, inside a pair, by scope index - which is the same under first-call and under
+    construction order, so either numbering convention maps correctly.  Optimiser slots (``.../Adam``,
+    ``.../Adam_1``, ``beta*_power``), ``global_step``, ``speaker_embeddings`` (inert, modules.py:188-189) and the
+    cached low-precision casts of ``fp16_dtype_getter`` (utils.py:19-29) are dropped; names already in this
+    package's form pass through."""
+    out, bare = {}, {}
     for name, value in variables.items():
         n = name[:-2] if name.endswith(":0") else name
         leaf = n.rsplit("/", 1)[-1]
-        if leaf in ("Adam", "Adam_1", "global_step") or leaf.startswith("beta") or "fp16_cast" in n or n.startswith("__opt/"):
+        if leaf in ("Adam", "Adam_1", "global_step", "speaker_embeddings") or leaf.startswith("beta") or \
+                "fp16_cast" in n or n.startswith("__opt/"):
             continue
-        for prefix in ("vocoder/FloWaveNet/", "FloWaveNet/"):
-            if n.startswith(prefix):
-                n = n[len(prefix):]
-                break
-        out[n] = value
+        if "FloWaveNet/" in n:
+            n = n[n.index("FloWaveNet/") + len("FloWaveNet/"):]
+        top = n.split("/", 1)
+        if len(top) == 2 and _layer_index(top[0], "conv2d_transpose") is not None and _split_layer_var(n):
+            scope, lf = _split_layer_var(n)
+            out["upsample_%d/%s" % (_layer_index(scope, "conv2d_transpose"), lf)] = value
+            continue
+        if "/AffineCoupling/WaveNet/" not in n:
+            out[n] = value                                   # ActNorm, or a name already in this package's form
+            continue
+        flow, rest = n.split("/AffineCoupling/WaveNet/")
+        wp = flow + "/WaveNet/"
+        parts = rest.split("/")
+        if parts[0].startswith("ResBlock_"):                 # 'ResBlock_%d_%d' % (b, n), num_blocks = 1 (model.py:116)
+            ids = parts[0].split("_")[1:]
+            if len(ids) != 2 or ids[0] != "0":
+                raise KeyError("unexpected ResBlock scope in %r" % name)
+            rp = wp + "ResBlock_%d/" % int(ids[1])
+            sv = _split_layer_var("/".join(parts[1:]))
+            if sv is None:
+                raise KeyError("unexpected variable %r" % name)
+            scope, lf = sv
+            if scope.startswith("Conv_filter/") or scope.startswith("Conv_gate/"):
+                out[rp + scope.split("/")[0] + "/" + lf] = value
+            else:
+                k = _layer_index(scope, "conv1d")
+                if k is None:
+                    raise KeyError("unexpected layer scope in %r" % name)
+                bare.setdefault(rp, {}).setdefault(k, {})[lf] = value
+            continue
+        if parts[0] == "ZeroConv1d" and parts[1:] == ["scale"]:
+            out[wp + "ZeroConv1d/scale"] = value
+            continue
+        sv = _split_layer_var("/".join(parts[1:]))
+        if parts[0] not in ("Conv_front", "Conv_final", "ZeroConv1d") or sv is None or _layer_index(sv[0], "conv1d") is None:
+            raise KeyError("unexpected variable %r" % name)
+        out[wp + parts[0] + "/" + sv[1]] = value
+    for rp, layers in bare.items():
+        cond = sorted(k for k, v in layers.items() if np.shape(v["kernel"])[1] != FILTER)
+        plain = sorted(k for k, v in layers.items() if np.shape(v["kernel"])[1] == FILTER)
+        if len(cond) != 2 or len(plain) != 2:
+            raise KeyError("%s: expected two conditioning and two res/skip 1x1 convs, found %d + %d (global conditioning "
+                           "convs are never built: modules.py:188-189)" % (rp, len(cond), len(plain)))
+        for k, nm in zip(cond + plain, _BARE):
+            for lf, value in layers[k].items():
+                out[rp + nm + "/" + lf] = value
+    return out
+
+
+def to_reference_names(params: dict, prefix: str = "vocoder/FloWaveNet/") -> dict:
+    """The inverse map: this package's names -> the reference's TF variable names (see ``from_reference_names``),
+    e.g. to hand a checkpoint trained here to the reference's ``tf.train.Saver`` tooling."""
+    tf_leaf = {v: k for k, v in _LEAF.items()}
+    out = {}
+    for name, value in params.items():
+        head, leaf = name.rsplit("/", 1)
+        if head.startswith("upsample_"):
+            n = int(head.split("_")[1])
+            out["%sconv2d_transpose%s/%s" % (prefix, "_%d" % n if n else "", tf_leaf[leaf])] = value
+        elif "/WaveNet/" not in name:
+            out[prefix + name] = value
+        else:
+            flow, rest = name.split("/WaveNet/")
+            parts = rest.split("/")
+            base = "%s%s/AffineCoupling/WaveNet/" % (prefix, flow)
+            if parts[0].startswith("ResBlock_"):
+                base += "ResBlock_0_%d/" % int(parts[0].split("_")[1])
+                if parts[1] in _BARE:
+                    k = _BARE.index(parts[1])
+                    out["%sconv1d%s/%s" % (base, "_%d" % k if k else "", tf_leaf[leaf])] = value
+                else:
+                    out["%s%s/conv1d/%s" % (base, parts[1], tf_leaf[leaf])] = value
+            elif leaf == "scale":
+                out[base + "ZeroConv1d/scale"] = value
+            else:
+                out["%s%s/conv1d/%s" % (base, parts[0], tf_leaf[leaf])] = value
     return out
 
 
