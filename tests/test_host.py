@@ -360,3 +360,40 @@ def test_load_params_accepts_a_reference_named_dump(tmp_path):
     np.savez(tmp_path / "dump.npz", **{k + ":0": v for k, v in to_reference_names(p).items()})
     got = S.load_checkpoint(str(tmp_path))
     assert sorted(got) == sorted(param_shapes(hp)) and all(np.array_equal(got[k], p[k]) for k in p)
+
+
+def test_checkpoints_survive_a_crash_mid_write_and_order_by_step(tmp_path):
+    import os
+    """ADVICE r1: the temp file of save_checkpoint must not match the restore globs; restore takes the highest
+    STEP (not mtime) and skips a truncated file (train.py:190,214-218,251-252 Saver semantics: latest checkpoint)."""
+    import torch
+    from tf_flowavenet_amd import synthesize as S
+    from tf_flowavenet_amd import train as T
+
+    class Opt:
+        def __init__(self, fill):
+            self.w = torch.full((6,), float(fill))
+            self.m, self.v, self.global_step = torch.zeros(6), torch.ones(6), int(fill)
+
+        def master_views(self):
+            return {"a/kernel": self.w[:4].view(2, 2), "a/bias": self.w[4:]}
+
+    tr = lambda fill: type("Tr", (), {"opt": Opt(fill)})()
+    base = str(tmp_path / "flowavenet_model.ckpt")
+    T.save_checkpoint(base + "-200.npz", tr(200))
+    T.save_checkpoint(base + "-1000.npz", tr(1000))
+    os.utime(base + "-1000.npz", (1, 1))                       # older mtime than step 200: the step number decides
+    assert [os.path.basename(p) for p in T.checkpoint_files(str(tmp_path))] == ["flowavenet_model.ckpt-200.npz",
+                                                                                "flowavenet_model.ckpt-1000.npz"]
+    assert not [f for f in os.listdir(tmp_path) if "tmp" in f]
+    fresh = tr(0)
+    assert T.restore_checkpoint(str(tmp_path), fresh) == 1000 and float(fresh.opt.w[0]) == 1000.0
+    # a crash while writing step 3000 leaves either a '.tmp' (ignored) or, with the old naming, a truncated .npz
+    with open(base + "-3000.npz.tmp", "wb") as f:
+        f.write(b"PK\x03\x04 truncated")
+    with open(base + "-3000.npz", "wb") as f:
+        f.write(b"PK\x03\x04 truncated")
+    fresh = tr(0)
+    assert T.restore_checkpoint(str(tmp_path), fresh) == 1000
+    assert float(S.load_checkpoint(str(tmp_path))["a/bias"][0]) == 1000.0
+    assert T.restore_checkpoint(str(tmp_path / "nothing"), fresh) is None

@@ -21,19 +21,35 @@ import numpy as np
 
 
 def load_checkpoint(saved_dir):
-    """Newest ``*.npz`` / ``*.safetensors`` in ``saved_dir`` -> dict name -> ndarray."""
-    files = sorted(glob.glob(os.path.join(saved_dir, "*.npz")) + glob.glob(os.path.join(saved_dir, "*.safetensors")),
-                   key=os.path.getmtime)
+    """Latest readable ``*.npz`` / ``*.safetensors`` in ``saved_dir`` -> dict name -> ndarray.  ``...ckpt-<step>.npz``
+    files (train.py's) are ordered by step number, anything else by modification time; a file that cannot be read
+    (e.g. truncated by a crash) is skipped with a message."""
+    import re
+    files = glob.glob(os.path.join(saved_dir, "*.npz")) + glob.glob(os.path.join(saved_dir, "*.safetensors"))
     if not files:
         raise FileNotFoundError("no *.npz / *.safetensors checkpoint in %r" % saved_dir)
-    path = files[-1]
-    print("Loading checkpoint {}".format(path))
+
+    def order(path):
+        m = re.search(r"ckpt-(\d+)\.npz$", path)
+        return (1, int(m.group(1)), 0.0) if m else (0, 0, os.path.getmtime(path))
+
     from .weights import from_reference_names
-    if path.endswith(".npz"):
-        with np.load(path) as f:
-            return from_reference_names({k: f[k] for k in f.files})
-    from safetensors.numpy import load_file
-    return from_reference_names(load_file(path))
+    last_error = None
+    for path in sorted(files, key=order, reverse=True):
+        try:
+            if path.endswith(".npz"):
+                with np.load(path) as f:
+                    raw = {k: f[k] for k in f.files}
+            else:
+                from safetensors.numpy import load_file
+                raw = load_file(path)
+        except Exception as e:
+            print("Skipping unreadable checkpoint {} ({}: {})".format(path, type(e).__name__, e))
+            last_error = e
+            continue
+        print("Loading checkpoint {}".format(path))
+        return from_reference_names(raw)
+    raise FileNotFoundError("no readable checkpoint in %r (last error: %s)" % (saved_dir, last_error))
 
 
 def write_wav(path, audio, sample_rate):

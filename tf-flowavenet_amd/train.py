@@ -22,6 +22,7 @@ import argparse
 import glob
 import json
 import os
+import collections
 import time
 
 import numpy as np
@@ -29,6 +30,7 @@ import numpy as np
 
 class Dataset:
     """Random fixed-length crops of (mel, audio) pairs (dataset.py:47-85)."""
+    MAX_OPEN = 512          # memory-mapped utterances kept open per rank (_load)
 
     def __init__(self, metadata_path, hparams, seed=None, rank=0):
         self._hp = hparams
@@ -50,7 +52,7 @@ class Dataset:
         self.train_meta, self.test_meta = [meta[i] for i in tr], [meta[i] for i in te]
         base = hparams.shuffle_random_seed if seed is None else seed
         self._rng = np.random.RandomState(base + 7919 * rank)
-        self._cache = {}
+        self._cache, self._lru = {}, collections.OrderedDict()
 
     @classmethod
     def from_tfrecords(cls, train_path, test_path, hparams, seed=None, rank=0):
@@ -60,7 +62,7 @@ class Dataset:
         self._hp, self._basedir = hparams, os.path.dirname(train_path)
         self._frames = hparams.max_time_steps // hparams.hop_size
         self._steps = self._frames * hparams.hop_size
-        self._cache = {}
+        self._cache, self._lru = {}, collections.OrderedDict()      # TFRecord samples stay resident (not in the LRU)
 
         def load(path, tag):
             metas = []
@@ -80,10 +82,21 @@ class Dataset:
         return self
 
     def _load(self, m):
-        if m[0] not in self._cache:
-            self._cache[m[0]] = (np.load(os.path.join(self._basedir, "audios", m[0])),
-                                 np.load(os.path.join(self._basedir, "mels", m[1])))
-        return self._cache[m[0]]
+        """Utterances read from ``audios/`` / ``mels/`` are memory-mapped (a crop touches a few pages; nothing of an
+        LJSpeech-sized set stays resident per rank), with at most ``MAX_OPEN`` maps kept open (LRU)."""
+        hit = self._cache.get(m[0])
+        if hit is not None:
+            if m[0] in self._lru:
+                self._lru.move_to_end(m[0])
+            return hit
+        pair = (np.load(os.path.join(self._basedir, "audios", m[0]), mmap_mode="r"),
+                np.load(os.path.join(self._basedir, "mels", m[1]), mmap_mode="r"))
+        self._cache[m[0]] = pair
+        self._lru[m[0]] = None
+        while len(self._lru) > self.MAX_OPEN:
+            old, _ = self._lru.popitem(last=False)
+            del self._cache[old]
+        return pair
 
     def _batch(self, metas):
         hp = self._hp
@@ -121,26 +134,46 @@ def save_checkpoint(path, trainer):
     out["__opt/m"] = trainer.opt.m.cpu().numpy()
     out["__opt/v"] = trainer.opt.v.cpu().numpy()
     out["__opt/global_step"] = np.asarray(trainer.opt.global_step, dtype=np.int64)
-    tmp = path + ".tmp.npz"
-    np.savez(tmp, **out)
+    tmp = path + ".tmp"              # outside every restore glob (*.npz): a crash mid-write never shadows a good checkpoint
+    with open(tmp, "wb") as f:
+        np.savez(f, **out)
+        f.flush()
+        os.fsync(f.fileno())
     os.replace(tmp, path)
 
 
+def checkpoint_files(save_dir):
+    """``flowavenet_model.ckpt-<step>.npz`` files of save_dir, oldest step first (by step number, not mtime)."""
+    import re
+    found = []
+    for path in glob.glob(os.path.join(save_dir, "flowavenet_model.ckpt-*.npz")):
+        m = re.search(r"ckpt-(\d+)\.npz$", path)
+        if m:
+            found.append((int(m.group(1)), path))
+    return [p for _, p in sorted(found)]
+
+
 def restore_checkpoint(save_dir, trainer):
-    """Newest ``flowavenet_model.ckpt-*.npz`` -> masters, Adam slots, global step.  Returns the step or None."""
+    """Highest-step readable ``flowavenet_model.ckpt-<step>.npz`` -> masters, Adam slots, global step (a file that
+    cannot be read - truncated by a crash - is skipped with a message).  Returns the step or None."""
     import torch
-    files = sorted(glob.glob(os.path.join(save_dir, "flowavenet_model.ckpt-*.npz")), key=os.path.getmtime)
-    if not files:
-        return None
-    print("Loading checkpoint {}".format(files[-1]))
-    with np.load(files[-1]) as f:
-        views = trainer.opt.master_views()
+    for path in reversed(checkpoint_files(save_dir)):
+        try:
+            with np.load(path) as f:
+                views = trainer.opt.master_views()
+                loaded = {k: torch.from_numpy(f[k]).reshape(v.shape) for k, v in views.items()}
+                m, v_, gs = torch.from_numpy(f["__opt/m"]), torch.from_numpy(f["__opt/v"]), int(f["__opt/global_step"])
+        except Exception as e:        # zipfile.BadZipFile, KeyError, OSError, ValueError ...
+            print("Skipping unreadable checkpoint {} ({}: {})".format(path, type(e).__name__, e))
+            continue
+        print("Loading checkpoint {}".format(path))
         for k, v in views.items():
-            v.copy_(torch.from_numpy(f[k]).reshape(v.shape))
-        trainer.opt.m.copy_(torch.from_numpy(f["__opt/m"]))
-        trainer.opt.v.copy_(torch.from_numpy(f["__opt/v"]))
-        trainer.opt.global_step = int(f["__opt/global_step"])
-    return trainer.opt.global_step
+            v.copy_(loaded[k])
+        trainer.opt.m.copy_(m)
+        trainer.opt.v.copy_(v_)
+        trainer.opt.global_step = gs
+        return gs
+    return None
 
 
 def train(log_dir, args, hparams, input_path, device="cuda", params=None):
