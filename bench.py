@@ -12,8 +12,13 @@ region.  ``value`` = audio samples pushed through a flow pass per second, whole 
 (B*T forward + B*T inverse) * n_gpus / step time.  The batch is sharded across ranks
 (weak scaling); the only exchange on the path is the 2-scalar NLL all-reduce.
 
-One JSON line on stdout (rank 0) with ``roofline`` and ``cpu_baseline`` objects as
-described in DESIGN.md "Measurement".
+``--gpus N`` (N > 1) without a torchrun environment makes this process a pure launcher: it never touches the GPU,
+starts ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a CHILD process (one rank per GPU over
+RCCL), relays rank 0's JSON line and exits non-zero if fewer than N GPUs exist or the line does not say ``n_gpus: N``.
+
+One JSON line on stdout (rank 0) with ``roofline`` and ``cpu_baseline`` objects as described in DESIGN.md
+"Measurement", plus ``rtf_10s`` (BASELINE configs[3]: 10 s clip inverse, one clip per GPU) and ``train``
+(configs[2]: the data-parallel training step, B=8 x 6400 samples per GPU, RCCL gradient all-reduce).
 """
 from __future__ import annotations
 
@@ -107,16 +112,178 @@ def gate_roofline(model, hp, b, t, iters=30):
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     flops = 2.0 * m * (768 + d.cin) * 512
     ach = flops / sec / 1e12
-    traffic = None      # HBM bytes per launch from the committed PMC profile of this exact launch shape
-    tj = os.path.join(ROOT, "profiles", "r01_gate_traffic.json")
-    if os.path.exists(tj):
-        with open(tj) as f:
-            rec = json.load(f)
-        if rec.get("rows") == m:
-            traffic = rec["traffic_bytes"]
+    traffic, traffic_source = gate_traffic(m)
     return {"bound": "mfma", "kernel": "gate_halo_kernel<256,256,GateProb> (block 0 gated dilated layer, fwn_gate)",
             "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-            "traffic": traffic, "launch_us": sec * 1e6, "flop_per_launch": flops, "rows": m}
+            "traffic": traffic, "traffic_source": traffic_source, "launch_us": sec * 1e6, "flop_per_launch": flops,
+            "rows": m}
+
+
+GATE_SOURCES = ("gate_halo.h", "gemm_ring.h", "common.h", "flow_kernels.hip")
+
+
+def gate_source_hash():
+    """sha256 over the sources the dominant kernel is compiled from (what a PMC profile must have been taken on)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in GATE_SOURCES:
+        with open(os.path.join(ROOT, "tf-flowavenet_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def gate_traffic(rows):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC profile
+    (``profiles/r*_gate_traffic.json``, written by tools/gate_pmc.py from separate rocprofv3 --pmc passes).  The
+    counters cannot be read inside this process, so the number is only reported when the profile was taken at this
+    launch shape AND on the current kernel sources (hash recorded in the profile); otherwise null."""
+    import glob
+    for tj in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gate_traffic.json")), reverse=True):
+        with open(tj) as f:
+            rec = json.load(f)
+        if rec.get("rows") == rows and rec.get("source_sha") == gate_source_hash():
+            return rec["traffic_bytes"], "%s (source_sha %s)" % (os.path.relpath(tj, ROOT), rec["source_sha"])
+    return None, "no PMC profile of the current kernel sources (hash %s) under profiles/" % gate_source_hash()
+
+
+def rtf_10s(model, hp, dev, world, iters=5):
+    """BASELINE configs[3]: inverse synthesis of a 10 s clip @ 22.05 kHz (T = 220672 = 862 frames), one clip per GPU
+    (the batch shard of the 8-clip job), HIP events on the launch stream."""
+    import torch
+    from tf_flowavenet_amd import weights as W
+    t = 220672 if hp.hop_size == 256 else (10 * hp.sample_rate // np.lcm(hp.hop_size, 1 << hp.n_block)) * np.lcm(hp.hop_size, 1 << hp.n_block)
+    inp = W.synthetic_inputs(hp, 1, int(t), want=("c", "z"))
+    z, c = torch.from_numpy(inp["z"]).to(dev), torch.from_numpy(inp["c"]).to(dev)
+    for _ in range(2):
+        wav = model.reverse(z, c)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        wav = model.reverse(z, c)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    assert bool(torch.isfinite(wav).all())
+    audio_s = t / hp.sample_rate
+    return {"workload": "configs[3]: inverse synthesis, one %.3f s clip (T=%d) per GPU, B=1" % (audio_s, t),
+            "inverse_ms": sec * 1e3, "rtf_per_gpu": audio_s / sec, "rtf_whole_job": world * audio_s / sec,
+            "samples_per_s_whole_job": world * t / sec, "n_gpus": world}
+
+
+def train_leg(hp, params, rank, world, dev, steps=10, batch=8, samples=6400, force_collectives=False):
+    """BASELINE configs[2]: the data-parallel training step, `batch` crops of `samples` samples per GPU (global batch
+    64 on 8 GPUs): gradients of -(log_p + logdet), RCCL all-reduce of the flat fp32 gradient started block by block
+    under the backward pass, global-norm clip, Adam.  Also times the step without the exchange and the exchange
+    alone, so the overlap can be read off."""
+    import torch
+    import torch.distributed as dist
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import Trainer
+    inp = W.synthetic_inputs(hp, batch, samples, want=("x", "c"))
+    x = torch.from_numpy(np.roll(inp["x"], 997 * rank, axis=1)).reshape(batch, samples).to(dev)
+    c = torch.from_numpy(np.roll(inp["c"], rank, axis=1)).to(dev)
+    tr = Trainer(hp, params, device=dev)
+    tr.opt.force_collectives = bool(force_collectives)
+    tr.ddi(x, c)
+    exchanging = world > 1 or force_collectives
+
+    def timed(n):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = tr.step(x, c)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tm = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+        return el / n, out
+
+    for _ in range(3):                   # eager step, recording, first replay
+        tr.step(x, c)
+    step_s, (loss, _, _, gnorm) = timed(steps)
+    rec = {"workload": "configs[2]: data-parallel training step, %d x %d samples per GPU, full n_block=%d model"
+                       % (batch, samples, hp.n_block),
+           "ms_per_step": step_s * 1e3, "samples_per_s": batch * samples * world / step_s, "n_gpus": world,
+           "global_batch": batch * world, "loss": float(loss), "grad_norm": float(gnorm),
+           "recorded_step": bool(tr.graph), "allreduce_ms": None, "compute_ms": None, "overlap": None,
+           "gradient_bytes": int(tr.opt.g.numel()) * 4}
+    if exchanging:
+        tr.exchange = False              # same step without the gradient exchange (weights drift apart: timing only)
+        compute_s, _ = timed(max(3, steps // 2))
+        tr.exchange = True
+        ranges = [(lo, hi) for _, lo, hi in tr.opt.block_ranges()]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            works = [tr.opt.allreduce_range(lo, hi) for lo, hi in reversed(ranges)]
+            for w in works:
+                if w is not None:
+                    w.wait()
+            torch.cuda.synchronize()
+        ar_s = (time.perf_counter() - t0) / 3
+        rec.update(allreduce_ms=ar_s * 1e3, compute_ms=compute_s * 1e3,
+                   overlap=max(0.0, min(1.0, (compute_s + ar_s - step_s) / ar_s)) if ar_s > 0 else None)
+    return rec
+
+
+def launch_ranks(n):
+    """``--gpus N`` outside torchrun: this process stays off the GPU and runs the N ranks as a child job."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print("bench.py: the %d-rank job failed (exit code %d)" % (n, proc.returncode), file=sys.stderr)
+        raise SystemExit(proc.returncode or 1)
+    if json.loads(line).get("n_gpus") != n:
+        print("bench.py: the job reported n_gpus=%r, expected %d" % (json.loads(line).get("n_gpus"), n), file=sys.stderr)
+        raise SystemExit(1)
+    print(line, flush=True)
+    raise SystemExit(0)
+
+
+class Deadline:
+    """The optional legs (10 s clip, training step) must never cost the headline line: if one of them is still
+    running `seconds` after it started (a stuck collective on an untested topology), rank 0 prints the line with what
+    it has and every rank leaves."""
+
+    def __init__(self, emit):
+        import threading
+        self._emit, self._timer, self._threading = emit, None, threading
+
+    def arm(self, seconds, what):
+        def fire():
+            self._emit("%s did not finish within %d s" % (what, seconds))
+            sys.stdout.flush()
+            os._exit(0)
+        self._timer = self._threading.Timer(seconds, fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
 
 
 def main():
@@ -131,7 +298,17 @@ def main():
     ap.add_argument("--serial", action="store_true", help="forward and inverse on one stream (no overlap)")
     ap.add_argument("--lanes", type=int, default=3,
                     help="HIP streams per direction; successive (independent) steps rotate over them")
+    ap.add_argument("--no-train", action="store_true", help="skip the configs[2] training-step leg")
+    ap.add_argument("--no-rtf", action="store_true", help="skip the configs[3] 10 s clip leg")
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--leg-timeout", type=int, default=240, help="seconds an optional leg may take")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="issue the gradient all-reduces even with one rank (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus)          # never returns; this process has not touched the GPU
 
     import torch
     import torch.distributed as dist
@@ -142,13 +319,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     # FWN_BENCH_SHARE_GPU=1 is a plumbing test for boxes with one GPU: every rank uses cuda:0 and the
     # scalar exchanges go over gloo.  The measured configuration is always one GPU per rank + RCCL.
     share_gpu = os.environ.get("FWN_BENCH_SHARE_GPU") == "1"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if share_gpu:
         local_rank = 0
-    if world > 1:
+    elif torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: --gpus %d needs %d GPUs on this node, found %d" % (world, world, torch.cuda.device_count()))
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        if world == 1:                   # --force-collectives: a one-rank RCCL group
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if share_gpu:
             dist.init_process_group("gloo")
         else:
@@ -255,6 +444,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / n
 
+    out = {}
     if rank == 0:
         fwd_s = timed(lambda: model.forward(x, c))
         inv_s = timed(lambda: model.reverse(z, c))
@@ -269,7 +459,7 @@ def main():
             "config": {"workload": "configs[1]: full model n_block=8 n_flow=6 n_layer=2, forward NLL + inverse "
                                    "synthesis, 16128-sample (63-frame) clips @22.05 kHz",
                        "clips_per_gpu": b, "samples_per_clip": t, "samples_per_step_per_gpu": 2 * b * t,
-                       "weights": "synthetic seed 1234, ActNorm DDI on first batch",
+                       "weights": "synthetic seed 1234, ActNorm DDI on the first (global) batch",
                        "parallelism": "batch shard x%d, no data-path collective (2-scalar NLL all-reduce)" % world,
                        "streams": "serial" if args.serial else "%d per direction" % args.lanes,
                        "results": "last step bit-identical to the single-stream pass"},
@@ -284,9 +474,37 @@ def main():
             out["cpu_baseline"] = None
         else:
             out["cpu_baseline"] = cpu_baseline(hp, params, t)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    out["rtf_10s"] = out["train"] = None
+
+    def emit(note=None):
+        if rank == 0:
+            if note:
+                out["note"] = note
+            print(json.dumps(out), flush=True)
+
+    # optional legs (all ranks take part; a failure or a stall is reported inside the line, never instead of it)
+    deadline = Deadline(emit)
+    if not args.no_rtf:
+        deadline.arm(args.leg_timeout, "the configs[3] 10 s clip leg")
+        try:
+            out["rtf_10s"] = rtf_10s(model, hp, dev, world)
+        except Exception as e:
+            out["rtf_10s"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        deadline.disarm()
+    if not args.no_train:
+        del model
+        torch.cuda.empty_cache()
+        deadline.arm(args.leg_timeout, "the configs[2] training-step leg")
+        try:
+            out["train"] = train_leg(hp, params, rank, world, dev, steps=args.train_steps,
+                                     force_collectives=args.force_collectives)
+        except Exception as e:
+            out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        deadline.disarm()
+    emit()
+    if world > 1 or args.force_collectives:
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

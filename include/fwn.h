@@ -81,6 +81,12 @@ int fwn_merge_planes(const float* planes, int64_t B, int64_t T, float* x, void* 
 /* ---- K3 (init only): ActNorm data-dependent init of one flow (model.py:30-83).
  * an[2][4][Ch] <- per (a|b) plane: shift b, scale exp(3 logs), inverse scale, 3*logs. */
 int fwn_actnorm_ddi(const float* xa, const float* xb, int M, int Ch, float* an, void* stream);
+/* The same init for a batch sharded over ranks (the reference's towers race on this assign, model.py:39 under
+ * train.py:43-57): fwn_actnorm_moments writes this rank's mom[4 Ch + 1] doubles = per plane (sum_m x | sum_m x^2)
+ * [2][2][Ch] followed by the row count M; the caller all-reduces (sums) them over the ranks;
+ * fwn_actnorm_from_moments turns the global moments into the table `an` - identical on every rank. */
+int fwn_actnorm_moments(const float* xa, const float* xb, int M, int Ch, double* mom, void* stream);
+int fwn_actnorm_from_moments(const double* mom, int Ch, float* an, void* stream);
 
 /* Static description of one flow (model.py:176-205 Flow = ActNorm + AffineCoupling(WaveNet)).
  * All pointers are device pointers to packed weights; layouts in packing.py. */
@@ -300,6 +306,14 @@ size_t fwn_workspace_bytes(const fwn_model_desc* m, int64_t B, int64_t T);
 int fwn_model_forward(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
                       void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
                       void* stream);
+/* fwn_model_forward with init != 0 for one rank of a data-parallel job: before each flow's ActNorm tables are
+ * derived, `reduce(user, buf, n, stream)` is called on the host with the DEVICE buffer of n doubles holding this
+ * rank's moments (inside `workspace`); it must enqueue, in `stream` order, an in-place sum over all ranks (RCCL
+ * all-reduce) and return 0.  reduce == NULL: single rank (moments of the local batch). */
+typedef int (*fwn_reduce_fn)(void* user, double* buf, int n, void* stream);
+int fwn_model_forward_init(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
+                           void* workspace, size_t workspace_bytes, float* out2, float* z_planes,
+                           fwn_reduce_fn reduce, void* user, void* stream);
 /* z [B][T] fp32, mel -> x_out [B][T] fp32. */
 int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float* z, const float* mel,
                       void* workspace, size_t workspace_bytes, float* x_out, void* stream);

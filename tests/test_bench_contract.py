@@ -25,3 +25,45 @@ def test_bench_fails_loudly_without_a_gpu():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "needs a GPU" in (out.stderr + out.stdout)
+
+
+def test_gpus_flag_launches_ranks_as_a_child_job_and_reports_their_failure():
+    """``--gpus 2`` without a torchrun environment: the parent (which never touches a GPU) starts the two ranks with
+    torch.distributed.run as a child and must pass their failure on (here: no GPU) instead of printing a 1-rank line."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0
+    assert "2-rank job failed" in out.stderr and "needs a GPU" in out.stderr
+    assert '"metric"' not in out.stdout
+
+
+def test_rank_count_must_match_the_gpus_flag():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "started 2 ranks" in (out.stderr + out.stdout)
+
+
+def test_traffic_is_only_reported_for_the_current_kernel_sources(tmp_path, monkeypatch):
+    import json
+    import bench
+    sha = bench.gate_source_hash()
+    assert len(sha) == 16
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    src = tmp_path / "tf-flowavenet_amd" / "csrc"
+    os.makedirs(src)
+    for name in bench.GATE_SOURCES:
+        (src / name).write_text("// " + name)
+    cur = bench.gate_source_hash()
+    (tmp_path / "profiles" / "r01_gate_traffic.json").write_text(json.dumps({"rows": 64512, "traffic_bytes": 1, "source_sha": "stale"}))
+    assert bench.gate_traffic(64512)[0] is None
+    (tmp_path / "profiles" / "r02_gate_traffic.json").write_text(json.dumps({"rows": 64512, "traffic_bytes": 7, "source_sha": cur}))
+    assert bench.gate_traffic(64512)[0] == 7 and bench.gate_traffic(100)[0] is None
+    (src / "gate_halo.h").write_text("// edited")
+    assert bench.gate_traffic(64512)[0] is None

@@ -38,6 +38,8 @@ def _worker(rank, world, port, n_clips, q):
     assert D.init_from_env("gloo") == world
     x = torch.arange(n_clips, dtype=torch.float32).reshape(n_clips, 1, 1) + 1.0
     c = -2.0 * x
+    mom = torch.tensor([1.0 + rank, 10.0 * (rank + 1), 3.0], dtype=torch.float64)     # (sum x, sum x^2, rows) of a shard
+    assert D.allreduce_sum_(mom) is mom and mom.tolist() == [3.0, 30.0, 6.0]            # the ActNorm moment exchange
     nll = D.sharded_forward(FakeModel(), x, c)
     out, (lo, hi) = D.sharded_reverse(FakeModel(), x, c)
     q.put((rank, nll.tolist(), lo, hi, None if out is None else out.reshape(-1).tolist()))

@@ -5,8 +5,9 @@ BASELINE.json's full sizes.  Nothing here reads /root/reference.
 Tolerances (stated, fp): hidden activations and weights are bf16 with fp32 accumulation, the
 flow state / ActNorm / coupling / reductions are fp32:
   * log_p within 1e-3 relative (north_star), logdet within 1e-3 * max(1, |logdet|);
-  * final z within 3e-2 max-abs (|z| ~ 1) on <= 48 flows;
-  * inverse waveform within 5e-2 max-abs for DDI-initialised (normalised) models.
+  * final z within 1e-2 max-abs (|z| ~ 1) on <= 48 flows;
+  * inverse waveform within 1e-2 max-abs (relative to max(1, |x|max)) for DDI-initialised (normalised) models;
+  * fixtures stored as float16 (the B=8 and 10 s cases) add half a float16 ulp of the reference value.
 """
 import ctypes as C
 import os
@@ -28,8 +29,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 REL_LOGP = 1e-3
 ABS_LOGDET = 1e-3
-ABS_Z = 3e-2
-ABS_WAV = 5e-2
+ABS_Z = 1e-2
+ABS_WAV = 1e-2
 
 
 def dev(a):
@@ -84,6 +85,38 @@ def test_forward_and_inverse_match_golden(name, cond_mode):
         wav = model.reverse(dev(inp["z"]), dev(inp["c"])).cpu().numpy()
         assert wav.shape == (b, t, 1)
         assert np.abs(wav - g["x_rev"]).max() <= ABS_WAV * max(1.0, np.abs(g["x_rev"]).max())
+
+
+@pytest.mark.parametrize("name", ["full_b8f6_B1_T16128", "full_b8f6_B8_T16128", "full_b8f6_T220672_10s"])
+def test_baseline_configs_at_their_real_sizes_match_golden(name):
+    """BASELINE configs[1] at the latency shape (B=1) and at the bench.py workload (B=8, T=16128), and configs[3]
+    (one 10 s clip, T=220672): forward (log_p, logdet, every latent sample) and inverse (every waveform sample)
+    against the fp64 oracle's committed outputs, ActNorm initialised from the case's own batch on the device."""
+    mg = _golden_cases()
+    over, b, t, actnorm, ddi = mg.CASES[name]
+    hp = mg.hp_of(over)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    half_ulp = 2.0 ** -11 if g["z"].dtype == np.float16 else 0.0
+    model = FloWaveNet(hp, init=True).load_params(W.synthetic_params(hp, 1234, actnorm=actnorm))
+    inp = W.synthetic_inputs(hp, b, t)
+    c = dev(inp["c"])
+    log_p, logdet, zp = model.forward(dev(inp["x"]), c, return_z=True)
+    check_scalars(log_p, logdet, float(g["log_p"]), float(g["logdet"]))
+    z = z_planes_to_squeezed(zp, hp.n_block, hp.n_flow).cpu().numpy()
+    z0 = g["z"].astype(np.float32)
+    assert z.shape == z0.shape
+    assert (np.abs(z - z0) <= ABS_Z + half_ulp * np.abs(z0)).all(), np.abs(z - z0).max()
+    assert np.abs(z - z0).mean() < 1e-3
+    an = model.export_actnorm()
+    last = "Block_%d/Flow_%d/ActNorm/" % (hp.n_block - 1, hp.n_flow - 1)
+    np.testing.assert_allclose(an[last + "b"], g["an_b_last"], atol=2e-2)
+    np.testing.assert_allclose(an[last + "logs"], g["an_logs_last"], atol=5e-3)
+    wav = model.reverse(dev(inp["z"]), c).cpu().numpy()
+    x0 = g["x_rev"].astype(np.float32)
+    assert wav.shape == x0.shape == (b, t, 1)
+    scale = max(1.0, float(np.abs(x0).max()))
+    assert (np.abs(wav - x0) <= ABS_WAV * scale + half_ulp * np.abs(x0)).all(), np.abs(wav - x0).max()
+    assert np.abs(wav - x0).mean() < 1e-3 * scale
 
 
 @pytest.mark.parametrize("cfg,b,t", [
@@ -377,12 +410,18 @@ def test_concurrent_streams_reproduce_the_serial_result(full_model):
         assert torch.equal(got, ref_wav if kind == "inv" else ref_nll), kind
 
 
-def test_ten_second_clip_inverse_runs(full_model):
-    """BASELINE configs[3]: 10 s @ 22.05 kHz (T = 220672 = 862 frames), one clip."""
+def test_ten_second_clip_batch_of_clips_is_clipwise_identical(full_model):
+    """BASELINE configs[3] shards 10 s clips over GPUs; one GPU may also take several: every clip of a B=2 call equals
+    the same clip synthesised alone at the B=1 tile shapes up to bf16 rounding flips (values are checked against the
+    oracle in test_baseline_configs_at_their_real_sizes_match_golden)."""
     hp, model, x, c, z = full_model
-    inp = W.synthetic_inputs(hp, 1, 220672, want=("c", "z"))
-    wav = model.reverse(dev(inp["z"]), dev(inp["c"]))
-    assert wav.shape == (1, 220672, 1) and bool(torch.isfinite(wav).all())
+    inp = W.synthetic_inputs(hp, 2, 220672, want=("c", "z"))
+    zz, cc = dev(inp["z"]), dev(inp["c"])
+    both = model.reverse(zz, cc)
+    assert both.shape == (2, 220672, 1) and bool(torch.isfinite(both).all())
+    one = model.reverse(zz[1:2], cc[1:2])
+    d = (both[1:2] - one).abs()
+    assert float(d.max()) < 1e-2 and float(d.mean()) < 1e-3
 
 
 # ------------------------------------------------------------------ error behaviour of the surface

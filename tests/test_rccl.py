@@ -1,0 +1,89 @@
+"""RCCL (torch.distributed backend "nccl") on the GPU box.  The box the driver gives the tests has one GPU, so the
+collective path is exercised with a ONE-rank RCCL group: process-group init, the ActNorm moment all-reduce, the
+per-block gradient all-reduces issued between the hipGraph segments of the recorded training step (with the RCCL
+watchdog thread alive next to the capture), the NLL all-reduce of bench.py.  With two or more GPUs the same checks
+run with one rank per GPU through ``bench.py --gpus 2`` (which launches the ranks itself)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--train-steps", "4"] + list(flags), capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_with_a_one_rank_rccl_group_runs_every_collective():
+    rec = _bench("--force-collectives")
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and "note" not in rec
+    tr = rec["train"]
+    assert "error" not in tr, tr
+    assert tr["recorded_step"] is True and np.isfinite(tr["loss"]) and np.isfinite(tr["grad_norm"])
+    assert tr["allreduce_ms"] is not None and tr["allreduce_ms"] > 0 and tr["compute_ms"] > 0
+    assert tr["gradient_bytes"] > 700e6
+    assert "error" not in rec["rtf_10s"] and rec["rtf_10s"]["rtf_per_gpu"] > 100
+    assert rec["roofline"]["frac"] > 0.2 and rec["roofline"]["bound"] == "mfma"
+
+
+def _one_rank_worker(q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import Trainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
+    inp = W.synthetic_inputs(hp, 4, 256)
+    x, c = torch.from_numpy(inp["x"]).reshape(4, 256).cuda(), torch.from_numpy(inp["c"]).cuda()
+    res = {}
+    for graph in (False, True):
+        tr = Trainer(hp, W.synthetic_params(hp, 11), graph=graph)
+        tr.opt.force_collectives = True
+        tr.ddi(x, c)
+        outs = [tuple(float(v) for v in tr.step(x, c)) for _ in range(4)]
+        if graph:
+            res["segments"] = len(tr._recorded[(tuple(x.shape), tuple(c.shape))]["segs"])
+        res[graph] = (outs, tr.opt.w.cpu())
+    q.put((res[True][0] == res[False][0], bool(torch.equal(res[True][1], res[False][1])), res["segments"]))
+    dist.destroy_process_group()
+
+
+def test_recorded_step_with_rccl_all_reduces_between_graph_segments_equals_the_eager_step():
+    """Trainer over a one-rank RCCL group with the collectives forced on: the recording is cut at every block (4
+    hipGraph segments + the optimiser for a 3-block model), each block's all-reduce is issued on RCCL's stream between
+    two replays, and loss / gradient norm / weights equal the eager trainer's bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(q,), daemon=True)
+    p.start()
+    try:
+        same_outs, same_w, segments = q.get(timeout=300)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    assert same_outs and same_w and segments == 5, (same_outs, same_w, segments)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_launches_two_rccl_ranks_itself():
+    rec = _bench("--gpus", "2")
+    assert rec["n_gpus"] == 2 and rec["train"]["n_gpus"] == 2 and "error" not in rec["train"]
+    assert rec["train"]["allreduce_ms"] > 0 and 0.0 <= rec["train"]["overlap"] <= 1.0

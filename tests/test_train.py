@@ -75,6 +75,12 @@ def test_weight_and_bias_gradient_via_transposes_and_split_k(m, ti, shifts):
 
 
 # ------------------------------------------------------------------ whole-model gradients
+# Per-tensor agreement with fp64 autograd, ||got - want|| / ||want||: activations and their gradients are bf16, so a
+# tensor agrees to a few %; only tensors whose norm is tiny next to the rest of the gradient (sums that cancel) may
+# deviate more.
+GRAD_REL, GRAD_REL_SMALL, SMALL_NORM = 0.1, 0.3, 1e-2
+
+
 def _grad_case(cfg, b, t, seed):
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -115,10 +121,43 @@ def test_loss_and_all_parameter_gradients_match_autograd_oracle(cfg, b, t):
             continue
         rel = np.linalg.norm(a - r) / np.linalg.norm(r)
         rels.append(rel)
-        assert rel < 0.3, (k, rel)
+        assert rel < (GRAD_REL if np.linalg.norm(r) >= SMALL_NORM else GRAD_REL_SMALL), (k, rel, np.linalg.norm(r))
         dot += float((a * r).sum()); na += float((a * a).sum()); nb_ += float((r * r).sum())
     assert np.median(rels) < 3e-2, np.median(rels)
     assert dot / np.sqrt(na * nb_) > 0.999            # direction of the whole gradient
+
+
+@pytest.mark.parametrize("n_block,b,t", [(6, 2, 1024), (8, 2, 1024)])
+def test_full_width_model_gradients_match_autograd_oracle(n_block, b, t):
+    """The real architecture (hop 256, 80 mels, n_flow=6, n_layer=2; BASELINE configs[2]'s model at n_block=8, and
+    n_block=6 as the cheap case that already reaches the Ch = 32 ring front conv and the hoisted conditioning
+    backward): all trainable tensors (2 262 at n_block=8, 181 M elements) against fp64 autograd of the oracle."""
+    from oracle import grad_torch as G
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.hparams import default_hparams
+    from tf_flowavenet_amd.training import GradEngine
+    hp = default_hparams().replace(n_block=n_block)
+    p = W.synthetic_params(hp, 1234, actnorm="random")
+    inp = W.synthetic_inputs(hp, b, t)
+    loss0, lp0, ld0, g0 = G.loss_and_grads(p, inp["x"], inp["c"], hp)
+    loss, lp, ld, g = GradEngine(hp).loss_and_grads(p, torch.from_numpy(inp["x"]).reshape(b, t), torch.from_numpy(inp["c"]))
+    torch.cuda.synchronize()
+    assert abs(float(lp) - lp0) < 1e-3 * abs(lp0) and abs(float(ld) - ld0) < 1e-3 * max(1.0, abs(ld0))
+    assert sorted(g) == sorted(g0)
+    rels, dot, na, nb_ = [], 0.0, 0.0, 0.0
+    for k in sorted(g0):
+        a, r = g[k].detach().cpu().numpy().astype(np.float64).reshape(-1), g0[k].reshape(-1)
+        nr = np.linalg.norm(r)
+        if nr == 0:
+            assert not a.any(), k                      # dead res_conv of the last layer
+            continue
+        rel = np.linalg.norm(a - r) / nr
+        rels.append(rel)
+        assert rel < (GRAD_REL if nr >= SMALL_NORM else GRAD_REL_SMALL), (k, rel, nr)
+        dot += float(a @ r); na += float(a @ a); nb_ += float(r @ r)
+    assert len(rels) == len(g0) - 3 * hp.n_block * hp.n_flow
+    assert np.median(rels) < 4e-2, np.median(rels)
+    assert dot / np.sqrt(na * nb_) > 0.9999
 
 
 def test_gradient_is_reproducible_bit_for_bit():
@@ -219,7 +258,7 @@ def test_train_cli_loop_checkpoint_resume_and_synthesis(tmp_path):
 
 
 # ------------------------------------------------------------------ data-parallel step, 2 ranks on one GPU
-def _dp_worker(rank, world, port, out_dir):
+def _dp_worker(rank, world, port, out_dir, backend="gloo"):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -227,8 +266,12 @@ def _dp_worker(rank, world, port, out_dir):
     from conftest import small_hparams
     from tf_flowavenet_amd import weights as W
     from tf_flowavenet_amd.training import Trainer
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo moves CUDA tensors through the host
-    torch.cuda.set_device(0)
+    if backend == "nccl":             # one GPU per rank, RCCL over xGMI: the measured configuration
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:                             # gloo moves CUDA tensors through the host; both ranks share cuda:0
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
     hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
     inp = W.synthetic_inputs(hp, 4, 256)
     x = torch.from_numpy(inp["x"]).reshape(4, 256)[2 * rank:2 * rank + 2].cuda()
@@ -245,22 +288,26 @@ def _dp_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_step_matches_one_process_on_the_whole_batch(tmp_path):
-    """Two processes (gloo, both on cuda:0), two clips each: after DDI both hold rank 0's ActNorm
-    init, the all-reduced gradient equals world x the gradient of the 4-clip batch in one process,
-    and both ranks end the step with bit-identical weights (utils.py:34-60, train.py:75-81)."""
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_data_parallel_step_matches_one_process_on_the_whole_batch(tmp_path, backend):
+    """Two processes (gloo, both on cuda:0), two clips each: after DDI (per-flow moment all-reduce) both hold the
+    ActNorm init of the whole 4-clip batch - bit-identical on the two ranks and equal to the one-process init on the
+    concatenated batch -, the all-reduced gradient equals world x the gradient of the 4-clip batch in one process,
+    and both ranks end the step with bit-identical weights (model.py:30-83, utils.py:34-60, train.py:75-81)."""
     import os, socket, sys
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from conftest import small_hparams
     from tf_flowavenet_amd import weights as W
     from tf_flowavenet_amd.training import Trainer
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL with one GPU per rank needs two GPUs (the one-rank RCCL path is covered by tests/test_rccl.py)")
     ctx = mp.get_context("spawn")
 
     def run_pair(out):
         """Both ranks to completion -> exit codes (None = still running after the time limit, killed)."""
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()      # a fresh port per pair
-        procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(out)), daemon=True) for r in range(2)]
+        procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, str(out), backend), daemon=True) for r in range(2)]
         for p in procs:
             p.start()
         try:
@@ -294,6 +341,10 @@ def test_two_rank_data_parallel_step_matches_one_process_on_the_whole_batch(tmp_
     hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
     inp = W.synthetic_inputs(hp, 4, 256)
     tr = Trainer(hp, W.synthetic_params(hp, 11))
+    tr.ddi(torch.from_numpy(inp["x"]).reshape(4, 256), torch.from_numpy(inp["c"]))
+    w0_single = tr.opt.w.cpu().numpy()
+    assert not np.array_equal(w0_single, W.synthetic_params(hp, 11) and tr.opt.layout.flatten(W.synthetic_params(hp, 11)))   # DDI wrote something
+    np.testing.assert_allclose(r0["w0"], w0_single, rtol=0, atol=2e-4)     # ActNorm b / logs of the global batch
     tr.opt.w.copy_(torch.from_numpy(r0["w0"]))
     _, _, _, grads = tr.engine.loss_and_grads(tr.opt.master_views(), torch.from_numpy(inp["x"]).reshape(4, 256), torch.from_numpy(inp["c"]))
     gv = tr.opt.grad_views()

@@ -45,6 +45,9 @@ class ModelDesc(C.Structure):
     ]
 
 
+REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)      # fwn_reduce_fn(user, buf, n, stream)
+
+
 # name -> (restype, argtypes); every symbol include/fwn.h declares.
 class ScaleJob(C.Structure):
     _fields_ = [("v", C.c_void_p), ("g", C.c_void_p), ("k_src", C.c_int32), ("n_src", C.c_int32)]
@@ -106,6 +109,8 @@ SIGNATURES = {
     "fwn_split_planes": (C.c_int, [vp, i64, i64, vp, vp]),
     "fwn_merge_planes": (C.c_int, [vp, i64, i64, vp, vp]),
     "fwn_actnorm_ddi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "fwn_actnorm_moments": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "fwn_actnorm_from_moments": (C.c_int, [vp, C.c_int, vp, vp]),
     "fwn_front": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "fwn_gate": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "fwn_res": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, vp]),
@@ -149,6 +154,7 @@ SIGNATURES = {
     "fwn_workspace_bytes": (C.c_size_t, [C.POINTER(ModelDesc), i64, i64]),
     "fwn_model_forward": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp,
                                     C.c_int, vp]),
+    "fwn_model_forward_init": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp]),
     "fwn_model_reverse": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp]),
 }
 

@@ -91,6 +91,17 @@ int fwn_actnorm_ddi(const float* xa, const float* xb, int M, int Ch, float* an, 
     return check_launch("fwn_actnorm_ddi");
 }
 
+int fwn_actnorm_moments(const float* xa, const float* xb, int M, int Ch, double* mom, void* stream) {
+    REQUIRE(xa && xb && mom && M > 0 && Ch > 0, "fwn_actnorm_moments: bad argument");
+    fwn_launch_ddi_moments(xa, xb, M, Ch, mom, (hipStream_t)stream);
+    return check_launch("fwn_actnorm_moments");
+}
+int fwn_actnorm_from_moments(const double* mom, int Ch, float* an, void* stream) {
+    REQUIRE(mom && an && Ch > 0, "fwn_actnorm_from_moments: bad argument");
+    fwn_launch_ddi_from_moments(mom, Ch, an, (hipStream_t)stream);
+    return check_launch("fwn_actnorm_from_moments");
+}
+
 static int check_desc(const fwn_flow_desc* d) {
     REQUIRE(d, "flow desc is null");
     REQUIRE(d->Ch >= 1 && (d->Ch & (d->Ch - 1)) == 0, "flow desc: Ch=%d must be a power of two", d->Ch);
@@ -191,9 +202,10 @@ int fwn_tail_partials(int M) {
     return (M + rows - 1) / rows;
 }
 
-int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
-                 void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
-                 void* stream) {
+// ddi: 0 none, 1 local two-pass init, 2 moments -> reduce callback (may be NULL) -> tables
+static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
+                         void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
+                         double* mom, fwn_reduce_fn reduce, void* user, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(B > 0 && T > 0 && T % (2 * (int64_t)d->Ch) == 0, "fwn_flow_run: T=%lld not divisible by 2*Ch=%d",
@@ -206,7 +218,16 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
     hipStream_t st = (hipStream_t)stream;
     const int Ti = (int)(T / (2 * d->Ch));
     const int M = (int)(B * Ti);
-    if (ddi) fwn_launch_ddi(xa, xb, M, d->Ch, d->an, st);
+    if (ddi == 1) fwn_launch_ddi(xa, xb, M, d->Ch, d->an, st);
+    if (ddi == 2) {
+        REQUIRE(mom, "fwn_flow_run: no moment buffer");
+        fwn_launch_ddi_moments(xa, xb, M, d->Ch, mom, st);
+        rc = check_launch("fwn_actnorm_moments");
+        if (rc) return rc;
+        if (reduce && reduce(user, mom, 4 * d->Ch + 1, stream) != 0)
+            return fail(FWN_ERR_ARG, "fwn_model_forward_init: the reduce callback failed");
+        fwn_launch_ddi_from_moments(mom, d->Ch, d->an, st);
+    }
     fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h0, h1, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1, st);
     void* hc = h0;
     void* hn = h1;
@@ -222,6 +243,12 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
     fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
                     d->ezero, d->an, xa, xb, inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, st);
     return check_launch("fwn_flow_run");
+}
+
+int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
+                 void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
+                 void* stream) {
+    return flow_run_impl(d, B, T, xa, xb, ca, h0, h1, o, P, partial, inverse, ddi ? 1 : 0, nullptr, nullptr, nullptr, stream);
 }
 
 int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_partial, float* out2,
@@ -436,7 +463,7 @@ int fwn_clip_adam_dev(float* w, const float* g, float* m, float* v, int64_t n, c
 // Whole-model sequencing
 // ---------------------------------------------------------------------------------------------
 struct Carve {
-    size_t cplanes, up0, up1, planes, h0, h1, o, P, partial, total;
+    size_t cplanes, up0, up1, planes, h0, h1, o, P, partial, mom, total;
     int n_partial;
 };
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -507,6 +534,8 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
     c.P = off; off = align_up(off + pbytes);
     c.partial = off; off = align_up(off + (size_t)npart * 4);
     c.n_partial = npart;
+    // per-flow moment buffers of the data-parallel ActNorm init: 4 Ch + 1 doubles each, Ch <= 2^(n_block-1)
+    c.mom = off; off = align_up(off + (size_t)m->n_block * m->n_flow * (4 * ((size_t)1 << (m->n_block - 1)) + 1) * 8);
     c.total = off;
     return c;
 }
@@ -554,9 +583,9 @@ static int check_block_contiguity(const fwn_model_desc* m, int blk) {
     return FWN_OK;
 }
 
-int fwn_model_forward(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
-                      void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
-                      void* stream) {
+static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
+                              void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
+                              fwn_reduce_fn reduce, void* user, void* stream) {
     int rc = check_model(m, B, T);
     if (rc) return rc;
     REQUIRE(x && mel && workspace && out2, "fwn_model_forward: null pointer");
@@ -589,8 +618,9 @@ int fwn_model_forward(const fwn_model_desc* m, int64_t B, int64_t T, const float
             const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
             const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
-            rc = fwn_flow_run(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
-                              ws + c.h0, ws + c.h1, ws + c.o, P, partial + poff, 0, init, stream);
+            double* mom = (double*)(ws + c.mom) + (size_t)(i * m->n_flow + j) * (4 * ((size_t)1 << (m->n_block - 1)) + 1);
+            rc = flow_run_impl(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
+                               ws + c.h0, ws + c.h1, ws + c.o, P, partial + poff, 0, init, mom, reduce, user, stream);
             if (rc) return rc;
             poff += fwn_tail_partials((int)M);
             p ^= 1;   // change_order (model.py:190)
@@ -602,6 +632,18 @@ int fwn_model_forward(const fwn_model_desc* m, int64_t B, int64_t T, const float
         if (e != hipSuccess) return fail(FWN_ERR_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e));
     }
     return check_launch("fwn_model_forward");
+}
+
+int fwn_model_forward(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
+                      void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
+                      void* stream) {
+    return model_forward_impl(m, B, T, x, mel, workspace, workspace_bytes, out2, z_planes, init ? 1 : 0, nullptr, nullptr,
+                              stream);
+}
+int fwn_model_forward_init(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
+                           void* workspace, size_t workspace_bytes, float* out2, float* z_planes,
+                           fwn_reduce_fn reduce, void* user, void* stream) {
+    return model_forward_impl(m, B, T, x, mel, workspace, workspace_bytes, out2, z_planes, 2, reduce, user, stream);
 }
 
 int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float* z, const float* mel,

@@ -245,6 +245,46 @@ __global__ __launch_bounds__(256) void ddi_kernel(const float* __restrict__ xa, 
     }
 }
 
+// ---- the same init from moments summed over ranks (data-parallel DDI) -------------------------------
+// The reference lets its towers race on the assign (model.py:39 under train.py:43-57); here every rank adds its
+// per-channel sum and sum of squares, the caller all-reduces the 4 Ch + 1 doubles (the last one counts rows), and
+// every rank derives the same table: b = -mean, var((x + b)) = E[x^2] + 2 b E[x] + b^2 with the fp32-rounded b the
+// single-process kernel above also centres with.
+__global__ __launch_bounds__(256) void ddi_moments_kernel(const float* __restrict__ xa, const float* __restrict__ xb,
+                                                          int M, int Ch, double* __restrict__ mom) {
+    __shared__ double red[256];
+    const int role = blockIdx.x / Ch, tau = blockIdx.x % Ch;
+    const float* src = role ? xb : xa;
+    double s = 0.0, s2 = 0.0;
+    for (int r = threadIdx.x; r < M; r += 256) {
+        const double v = src[(size_t)r * Ch + tau];
+        s += v;
+        s2 += v * v;
+    }
+    const double t1 = block_sum(s, red), t2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        mom[(size_t)role * 2 * Ch + tau] = t1;
+        mom[(size_t)role * 2 * Ch + Ch + tau] = t2;
+        if (blockIdx.x == 0) mom[4 * (size_t)Ch] = (double)M;
+    }
+}
+__global__ void ddi_from_moments_kernel(const double* __restrict__ mom, int Ch, float* __restrict__ an) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * Ch) return;
+    const int role = i / Ch, tau = i % Ch;
+    const double n = mom[4 * (size_t)Ch];
+    const double mean = mom[(size_t)role * 2 * Ch + tau] / n, ex2 = mom[(size_t)role * 2 * Ch + Ch + tau] / n;
+    const float bshift = (float)(-mean);
+    const double b = (double)bshift;
+    const double var = fmax(ex2 + 2.0 * b * mean + b * b, 0.0);
+    const double den = sqrt(var) + 1e-7;
+    float* o = an + (size_t)role * 4 * Ch;
+    o[tau] = bshift;
+    o[Ch + tau] = (float)(1.0 / den);
+    o[2 * Ch + tau] = (float)den;
+    o[3 * Ch + tau] = (float)(-log(den));
+}
+
 // ---- prior + log-det finalisation: out2 = (log_p, logdet), model.py:342-347 -----------------
 __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ z, long n,
                                                      const float* __restrict__ partial, int n_partial,
@@ -366,6 +406,12 @@ void fwn_launch_split(const float* x, long B, long T, float* planes, hipStream_t
 }
 void fwn_launch_merge(const float* planes, long B, long T, float* x, hipStream_t st) {
     hipLaunchKernelGGL(merge_kernel, dim3(grid_for(B * T)), dim3(256), 0, st, planes, B, T, x);
+}
+void fwn_launch_ddi_moments(const float* xa, const float* xb, int M, int Ch, double* mom, hipStream_t st) {
+    hipLaunchKernelGGL(ddi_moments_kernel, dim3(2 * Ch), dim3(256), 0, st, xa, xb, M, Ch, mom);
+}
+void fwn_launch_ddi_from_moments(const double* mom, int Ch, float* an, hipStream_t st) {
+    hipLaunchKernelGGL(ddi_from_moments_kernel, dim3((2 * Ch + 63) / 64), dim3(64), 0, st, mom, Ch, an);
 }
 void fwn_launch_ddi(const float* xa, const float* xb, int M, int Ch, float* an, hipStream_t st) {
     hipLaunchKernelGGL(ddi_kernel, dim3(2 * Ch), dim3(256), 0, st, xa, xb, M, Ch, an);

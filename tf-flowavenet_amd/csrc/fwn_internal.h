@@ -26,6 +26,8 @@ void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, 
 void fwn_launch_split(const float* x, long B, long T, float* planes, hipStream_t st);
 void fwn_launch_merge(const float* planes, long B, long T, float* x, hipStream_t st);
 void fwn_launch_ddi(const float* xa, const float* xb, int M, int Ch, float* an, hipStream_t st);
+void fwn_launch_ddi_moments(const float* xa, const float* xb, int M, int Ch, double* mom, hipStream_t st);
+void fwn_launch_ddi_from_moments(const double* mom, int Ch, float* an, hipStream_t st);
 void fwn_launch_prior(const float* planes, long n, const float* partial, int n_partial, double inv_bt,
                       float* out2, hipStream_t st);
 

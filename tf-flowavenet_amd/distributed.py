@@ -40,6 +40,22 @@ def shard_bounds(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def allreduce_sum_(t, group=None):
+    """In-place sum of ``t`` over the ranks of ``group`` in the order of the current stream (the ActNorm moments of
+    a data-parallel init, ``FloWaveNet._forward_init_dp``).  RCCL reduces device tensors directly; a gloo group (CPU
+    tests, or several ranks sharing one GPU) goes through a host copy."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 def global_nll(log_p, logdet, local_clips: int, group=None):
     """Clip-weighted global mean of the per-rank (log_p, logdet); returns a 2-element tensor.
 

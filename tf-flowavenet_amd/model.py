@@ -25,7 +25,11 @@ from . import _lib, packing, weights
 
 
 class FloWaveNet:
-    def __init__(self, hparams, init=False, scope="FloWaveNet", device="cuda", cond_mode=0):
+    def __init__(self, hparams, init=False, scope="FloWaveNet", device="cuda", cond_mode=0, group=None):
+        """group: the ``torch.distributed`` process group a data-parallel job shards its batch over (None = the
+        default group when one is initialised).  It only matters for ``init=True``: the ActNorm data-dependent
+        init then uses the statistics of the GLOBAL batch (moments all-reduced flow by flow) so every rank ends
+        with the same parameters - the reference's towers race on that assign (model.py:39, train.py:43-57)."""
         if not hparams.affine:
             raise NotImplementedError("affine=False (additive coupling, model.py:136-139) is out of scope")
         if hparams.causality:
@@ -37,6 +41,7 @@ class FloWaveNet:
         self._init = bool(init)
         self._device = device
         self._cond_mode = cond_mode
+        self._group = group
         self._packed = None
         self._ws = {}
         self._lib = _lib.load()     # fails loudly when libfwn.so is missing
@@ -131,14 +136,49 @@ class FloWaveNet:
         wsp, wsn = self._workspace(b, t)
         out2 = torch.empty(2, dtype=torch.float32, device=self._device)
         zp = torch.empty(2, b, t // 2, dtype=torch.float32, device=self._device) if return_z else None
-        rc = self._lib.fwn_model_forward(C.byref(self._packed.model_desc), b, t, x32.data_ptr(), c32.data_ptr(),
-                                         wsp, wsn, out2.data_ptr(), zp.data_ptr() if return_z else None,
-                                         1 if self._init else 0, self._stream())
-        _lib.check(rc, "fwn_model_forward")
+        if self._init and self._dp_world() > 1:
+            self._forward_init_dp(b, t, x32, c32, wsp, wsn, out2, zp)
+        else:
+            rc = self._lib.fwn_model_forward(C.byref(self._packed.model_desc), b, t, x32.data_ptr(), c32.data_ptr(),
+                                             wsp, wsn, out2.data_ptr(), zp.data_ptr() if return_z else None,
+                                             1 if self._init else 0, self._stream())
+            _lib.check(rc, "fwn_model_forward")
         self._init = False       # the reference feeds init=True for one step only (train.py:221,229)
         if return_z:
             return out2[0], out2[1], zp
         return out2[0], out2[1]
+
+    def _dp_world(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self._group)
+
+    def _forward_init_dp(self, b, t, x32, c32, wsp, wsn, out2, zp):
+        """init=True on one rank of a data-parallel job: ``fwn_model_forward_init`` calls back before each flow's
+        ActNorm tables are derived; the callback all-reduces that flow's 4 Ch + 1 moment doubles (RCCL; they live
+        inside this pass's workspace tensor) in stream order."""
+        import torch
+        from . import distributed
+        ws = self._ws[(b, t, self._stream())]
+        base, failure = ws.data_ptr(), []
+
+        def reduce(user, buf, n, stream):
+            try:
+                off = int(buf) - base
+                distributed.allreduce_sum_(ws[off:off + 8 * n].view(torch.float64), self._group)
+                return 0
+            except BaseException as e:      # must not propagate through the C frame
+                failure.append(e)
+                return 1
+
+        cb = _lib.REDUCE_FN(reduce)
+        rc = self._lib.fwn_model_forward_init(C.byref(self._packed.model_desc), b, t, x32.data_ptr(), c32.data_ptr(),
+                                              wsp, wsn, out2.data_ptr(), zp.data_ptr() if zp is not None else None,
+                                              cb, None, self._stream())
+        if failure:
+            raise failure[0]
+        _lib.check(rc, "fwn_model_forward_init")
 
     def reverse(self, z, c, g=None):
         """z [B,T,1], c [B,T/hop,num_mels] -> x [B,T,1] fp32 (model.py:350-396)."""

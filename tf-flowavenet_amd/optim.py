@@ -88,6 +88,8 @@ class DataParallelAdam:
         self.device = device
         self.group = group
         self.bucket_elems = bucket_elems
+        # True: issue the collectives even in a one-rank group (tests / bench exercise the RCCL path on one GPU)
+        self.force_collectives = False
         self.clip, self.b1, self.b2, self.eps = clip, beta1, beta2, eps
         self.w = torch.from_numpy(self.layout.flatten(params)).to(device)
         self.g = torch.zeros_like(self.w)
@@ -123,7 +125,9 @@ class DataParallelAdam:
         """Start the all-reduce (sum) of ``g[lo:hi]`` now - called by the training step as soon as a
         block's gradients are complete, so the exchange overlaps the rest of the backward pass."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        if dist.get_world_size(self.group) == 1 and not self.force_collectives:
             return None
         return dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True)
 

@@ -798,22 +798,22 @@ class Trainer:
             graph = os.environ.get("FWN_TRAIN_GRAPH", "1") != "0"
         self.graph = bool(graph)
         self._recorded = {}
+        # False: skip the gradient exchange (bench.py's compute-only step time, to price the overlap)
+        self.exchange = True
 
     def ddi(self, x, c):
+        """ActNorm data-dependent init from the GLOBAL batch (train.py:221,229 with init=True): each rank pushes its
+        shard through the flows and the per-channel moments are all-reduced flow by flow (``FloWaveNet`` with
+        ``group``), so every rank derives bit-identical b / logs - the single-process result on the concatenated
+        batch up to summation order.  (The reference lets its towers race on this assign: SURVEY section 2.1 C2.)"""
         from .model import FloWaveNet
         import torch
         views = self.opt.master_views()
-        m = FloWaveNet(self.hp, init=True, device=self.device, cond_mode=1).load_params(views)
+        m = FloWaveNet(self.hp, init=True, device=self.device, cond_mode=1, group=self.opt.group).load_params(views)
         xx = torch.as_tensor(x).to(self.device)
         m.forward(xx.reshape(xx.shape[0], -1, 1), torch.as_tensor(c).to(self.device))
         for k, v in m.export_actnorm().items():
             views[k].copy_(torch.as_tensor(v).to(self.device).reshape(views[k].shape))
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.opt.group) > 1:
-            # every rank must start from the same ActNorm init: rank 0's statistics win (the reference
-            # lets its towers race on this assign)
-            dist.broadcast(self.opt.w, src=dist.get_global_rank(self.opt.group, 0) if self.opt.group is not None else 0,
-                           group=self.opt.group)
 
     def step(self, x, c):
         """-> (loss, log_p, logdet, grad_norm) device scalars; the masters are updated in place."""
@@ -857,7 +857,7 @@ class Trainer:
                     cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
 
                     def cut(i):
-                        if world == 1 and i >= 0:
+                        if world == 1 and i >= 0 and not self.opt.force_collectives:
                             return
                         cur[0].capture_end()
                         segs.append((cur[0], i))
@@ -895,7 +895,7 @@ class Trainer:
                     if w is not None:
                         w.wait()
             g.replay()
-            if i is not None:
+            if i is not None and self.exchange:
                 lo, hi = ranges["upsample" if i < 0 else i]
                 works.append(self.opt.allreduce_range(lo, hi))
         return rec["out"]
@@ -907,8 +907,9 @@ class Trainer:
         works = []
 
         def block_done(i):      # block i's gradients are final: its all-reduce runs under the remaining backward
-            lo, hi = ranges["upsample" if i < 0 else i]
-            works.append(self.opt.allreduce_range(lo, hi))
+            if self.exchange:
+                lo, hi = ranges["upsample" if i < 0 else i]
+                works.append(self.opt.allreduce_range(lo, hi))
 
         loss, log_p, logdet, grads = self.engine.loss_and_grads(params, x, c, grad_out=gv, on_block_done=block_done)
         gnorm = self.opt.step(works=works)
