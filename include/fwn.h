@@ -131,10 +131,13 @@ int fwn_cond(const void* ca, const void* Wc_base, float* P_base, int64_t w_strid
              int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, void* stream);
 /* K6'+K7+K8 tail: skip sum, final 1x1, ZeroConv1d, affine coupling, ActNorm, log-det partials
  * (modules.py:175-180,51-56; model.py:86-102,124-141,146-161).  o = [L][M][256].
- * partial (forward only, may be NULL) receives fwn_tail_partials(M) per-workgroup sums. */
+ * partial (forward only, may be NULL) receives fwn_tail_partials(M) partial sums.
+ * Large M: one register-chained kernel.  M <= 12288 rows: three GEMM launches whose weights are split over the
+ * workgroups by output column (a workgroup of the fused kernel streams all 0.4 - 0.5 MB of tail weights itself:
+ * 22 - 36 us whatever the row count); they keep S and U in `scratch` = [2][M][256] bf16 (may be NULL for larger M). */
 int fwn_tail_partials(int M);
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
-             int inverse, void* stream);
+             int inverse, void* scratch, void* stream);
 
 /* ---- one whole flow (replaces Flow.forward / Flow.reverse, model.py:185-202) ----
  * xa / xb: the planes holding in_a / in_b for this flow's swap parity, ca the matching

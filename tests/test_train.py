@@ -76,9 +76,13 @@ def test_weight_and_bias_gradient_via_transposes_and_split_k(m, ti, shifts):
 
 # ------------------------------------------------------------------ whole-model gradients
 # Per-tensor agreement with fp64 autograd, ||got - want|| / ||want||: activations and their gradients are bf16, so a
-# tensor agrees to a few %; only tensors whose norm is tiny next to the rest of the gradient (sums that cancel) may
-# deviate more.
-GRAD_REL, GRAD_REL_SMALL, SMALL_NORM = 0.1, 0.3, 1e-2
+# tensor agrees to a few % of its own norm plus a noise floor that scales with the whole gradient (sums that cancel:
+# a tensor whose norm is tiny next to the rest of the gradient may deviate more, never beyond 30 %).
+GRAD_REL, GRAD_FLOOR, GRAD_REL_MAX = 0.1, 2e-3, 0.3
+
+
+def grad_rel_allowed(norm_ref, norm_total):
+    return min(GRAD_REL_MAX, GRAD_REL + GRAD_FLOOR * norm_total / norm_ref)
 
 
 def _grad_case(cfg, b, t, seed):
@@ -113,6 +117,7 @@ def test_loss_and_all_parameter_gradients_match_autograd_oracle(cfg, b, t):
     assert abs(float(lp) - lp0) < 1e-3 * abs(lp0) and abs(float(ld) - ld0) < 1e-3 * max(1.0, abs(ld0))
     assert sorted(g) == sorted(g0)
     rels, dot, na, nb_ = [], 0.0, 0.0, 0.0
+    total = float(np.sqrt(sum(float((v * v).sum()) for v in g0.values())))
     for k in g0:
         a, r = g[k].cpu().numpy().astype(np.float64), g0[k]
         assert a.shape == r.shape, k
@@ -121,7 +126,7 @@ def test_loss_and_all_parameter_gradients_match_autograd_oracle(cfg, b, t):
             continue
         rel = np.linalg.norm(a - r) / np.linalg.norm(r)
         rels.append(rel)
-        assert rel < (GRAD_REL if np.linalg.norm(r) >= SMALL_NORM else GRAD_REL_SMALL), (k, rel, np.linalg.norm(r))
+        assert rel < grad_rel_allowed(np.linalg.norm(r), total), (k, rel, np.linalg.norm(r), total)
         dot += float((a * r).sum()); na += float((a * a).sum()); nb_ += float((r * r).sum())
     assert np.median(rels) < 3e-2, np.median(rels)
     assert dot / np.sqrt(na * nb_) > 0.999            # direction of the whole gradient
@@ -145,6 +150,7 @@ def test_full_width_model_gradients_match_autograd_oracle(n_block, b, t):
     assert abs(float(lp) - lp0) < 1e-3 * abs(lp0) and abs(float(ld) - ld0) < 1e-3 * max(1.0, abs(ld0))
     assert sorted(g) == sorted(g0)
     rels, dot, na, nb_ = [], 0.0, 0.0, 0.0
+    total = float(np.sqrt(sum(float((v * v).sum()) for v in g0.values())))
     for k in sorted(g0):
         a, r = g[k].detach().cpu().numpy().astype(np.float64).reshape(-1), g0[k].reshape(-1)
         nr = np.linalg.norm(r)
@@ -153,7 +159,7 @@ def test_full_width_model_gradients_match_autograd_oracle(n_block, b, t):
             continue
         rel = np.linalg.norm(a - r) / nr
         rels.append(rel)
-        assert rel < (GRAD_REL if nr >= SMALL_NORM else GRAD_REL_SMALL), (k, rel, nr)
+        assert rel < grad_rel_allowed(nr, total), (k, rel, nr, total)
         dot += float(a @ r); na += float(a @ a); nb_ += float(r @ r)
     assert len(rels) == len(g0) - 3 * hp.n_block * hp.n_flow
     assert np.median(rels) < 4e-2, np.median(rels)

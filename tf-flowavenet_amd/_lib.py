@@ -12,7 +12,8 @@ FWN_MAX_LAYERS = 8
 FWN_MAX_UPSAMPLE = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfwn.so")
+# FWN_LIB: developer override (tools/tune.py loads the -DFWN_TUNABLE build); the product is csrc/libfwn.so
+LIB_PATH = os.environ.get("FWN_LIB") or os.path.join(_HERE, "csrc", "libfwn.so")
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -117,7 +118,7 @@ SIGNATURES = {
     "fwn_cond": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, vp]),
     "fwn_tail_partials": (C.c_int, [C.c_int]),
-    "fwn_tail": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "fwn_tail": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_flow_run": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,
                                C.c_int, vp]),
     "fwn_prior_logp": (C.c_int, [vp, i64, vp, C.c_int, vp, vp]),

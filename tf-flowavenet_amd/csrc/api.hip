@@ -188,19 +188,19 @@ int fwn_cond(const void* ca, const void* Wc_base, float* P_base, int64_t w_strid
 }
 
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
-             int inverse, void* stream) {
+             int inverse, void* scratch, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(o && xa && xb && M > 0, "fwn_tail: bad argument");
+    REQUIRE(!fwn_tail_is_split(M) || scratch, "fwn_tail: M=%d runs the N-split tail: pass scratch [2][M][256] bf16", M);
+    REQUIRE(!scratch || ALIGNED16(scratch), "fwn_tail: scratch must be 16-byte aligned");
     fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
-                    d->ezero, d->an, xa, xb, partial, M, d->Ch, d->npt, inverse, (hipStream_t)stream);
+                    d->ezero, d->an, xa, xb, partial, M, d->Ch, d->npt, inverse, scratch,
+                    scratch ? (char*)scratch + (size_t)M * 512 : nullptr, (hipStream_t)stream);
     return check_launch("fwn_tail");
 }
 
-int fwn_tail_partials(int M) {
-    const int rows = fwn_tail_rows(M);
-    return (M + rows - 1) / rows;
-}
+int fwn_tail_partials(int M) { return M > 0 ? fwn_tail_npartials(M) : 0; }
 
 // ddi: 0 none, 1 local two-pass init, 2 moments -> reduce callback (may be NULL) -> tables
 static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
@@ -240,8 +240,9 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
             void* t = hc; hc = hn; hn = t;
         }
     }
+    // both h buffers are free once the last gate has run: the N-split tail (small M) keeps S and U there
     fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
-                    d->ezero, d->an, xa, xb, inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, st);
+                    d->ezero, d->an, xa, xb, inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, hn, hc, st);
     return check_launch("fwn_flow_run");
 }
 

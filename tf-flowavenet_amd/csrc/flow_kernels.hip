@@ -455,6 +455,147 @@ __global__ __launch_bounds__(64 * WM * WN) void cond_batch_kernel(CondBatch cb, 
     gemm_ring_body<BM, BN, WM, WN, BK, D, CondProb>(p, wg / ntn, wg % ntn);
 }
 
+
+// ---------------------------------------------------------------------------
+// N-split tail for small row counts (M <= FWN_TAIL_SPLIT_MAX).
+// The register-chained tail_kernel below streams ALL tail weights of a flow (0.4 - 0.5 MB) through every workgroup:
+// at ~57 GB/s per CU that alone is 9 - 13 us, and with few rows there is nothing to amortise it over (22 - 36 us per
+// launch at 4 .. 126 workgroups).  Below the threshold the tail runs as three ring GEMMs whose weights are split over
+// workgroups by output column instead:  S = ReLU(sum_l o_l Wskip_l + bs)  ->  U = ReLU(S Wfinal + bf)  ->
+// (log_s | t) = U Wzero, coupling + ActNorm (+ log-det partials) in the epilogue.
+// S and U keep the K order the packed Wfinal / Wzero expect (packing.acc_k_perm = bits 2 and 3 of the channel index
+// swapped - an involution), applied to the COLUMN of the 2-byte epilogue stores.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int swap_bits23(int c) { return (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1); }
+
+struct TailLinProb {      // Y' = ReLU(sum_l A_l[M][256] . W[:, l*256 ..]^T + bias), columns stored at swap_bits23(col)
+    static constexpr bool A_DMA = true;
+    static constexpr bool ALLOW_256 = false;
+    const bf16* A;        // [L][a_stride] rows of 256
+    const bf16* W;        // [256][L*256]
+    const float* bias;    // [256]
+    bf16* out;            // [M][256]
+    long a_stride;        // elements between layers of A
+    int L, M;
+    struct RowCtx { int row; };
+    struct ChunkCtx { uint32_t abase; int bcol; };
+    template <int BK> __device__ int nchunks() const { return L * FWN_HID / BK; }
+    __device__ RowCtx row_ctx(int row) const { return RowCtx{row}; }
+    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const {
+        constexpr int CPL = FWN_HID / BK;
+        const int l = q / CPL, k0 = (q % CPL) * BK;
+        return ChunkCtx{(uint32_t)(l * a_stride + k0), l * FWN_HID + k0};
+    }
+    __device__ srd_t a_srd(const ChunkCtx&) const { return make_srd(A, (uint32_t)(((size_t)(L - 1) * a_stride + (size_t)M * FWN_HID) * 2)); }
+    __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
+        return rc.row < M ? (cc.abase + (uint32_t)(rc.row * FWN_HID + c8 * 8)) * 2u : FWN_OOB;
+    }
+    __device__ srd_t b_srd(const ChunkCtx&) const { return make_srd(W, (uint32_t)(256u * L * FWN_HID * 2u)); }
+    __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
+        return (uint32_t)(n * L * FWN_HID + cc.bcol + c8 * 8) * 2u;
+    }
+    __device__ float acc_init(int col) const { return bias[col]; }
+    template <int MI>
+    __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
+        const int lr = lane & 31;
+        const srd_t so = make_srd(out, (uint32_t)((size_t)M * FWN_HID * 2));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = swap_bits23(ncol0 + ni * 32 + lr);
+            const uint32_t voff = (uint32_t)((mrow0 + 4 * (lane >> 5)) * FWN_HID + col) * 2u;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2), fmaxf(acc[mi][ni][r], 0.0f));
+        }
+    }
+};
+
+struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of one 32-channel pair tile (tile_n = pt)
+    static constexpr bool A_DMA = true;
+    static constexpr bool ALLOW_256 = false;
+    const bf16* U;        // [M][256], K in acc order
+    const bf16* Wz;       // [npt*64][256]
+    const float* bz;      // [npt*64]
+    const float* ez;      // [npt*64]
+    const float* an;      // [2][4][Ch]
+    float* xa;
+    float* xb;
+    float* partial;       // [mtiles*8] (forward) or nullptr
+    int M, Ch, npt, inverse;
+    struct RowCtx { int row; };
+    struct ChunkCtx { int k0; };
+    template <int BK> __device__ int nchunks() const { return FWN_HID / BK; }
+    __device__ RowCtx row_ctx(int row) const { return RowCtx{row}; }
+    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{q * BK}; }
+    __device__ srd_t a_srd(const ChunkCtx&) const { return make_srd(U, (uint32_t)((size_t)M * FWN_HID * 2)); }
+    __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
+        return rc.row < M ? (uint32_t)(rc.row * FWN_HID + cc.k0 + c8 * 8) * 2u : FWN_OOB;
+    }
+    __device__ srd_t b_srd(const ChunkCtx&) const { return make_srd(Wz, (uint32_t)(npt * 64u * FWN_HID * 2u)); }
+    __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
+        return (uint32_t)(n * FWN_HID + cc.k0 + c8 * 8) * 2u;
+    }
+    __device__ float acc_init(int col) const { return bz[col]; }     // ZeroConv bias: (acc + b) * exp(3 scale)
+    template <int MI>
+    __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
+        const int lr = lane & 31, pt = ncol0 >> 6;
+        const int tau = pt * 32 + lr;
+        const bool chok = tau < Ch;
+        const int tc = chok ? tau : 0;
+        const float els = ez[pt * 64 + lr], et = ez[pt * 64 + 32 + lr];
+        const float* an_a = an;
+        const float* an_b = an + 4 * Ch;
+        const float a_sh = an_a[tc], a_sc = an_a[Ch + tc], a_isc = an_a[2 * Ch + tc], a_l3 = an_a[3 * Ch + tc];
+        const float b_sh = an_b[tc], b_sc = an_b[Ch + tc], b_isc = an_b[2 * Ch + tc], b_l3 = an_b[3 * Ch + tc];
+        const uint32_t plane_bytes = (uint32_t)((size_t)M * Ch * 4);
+        const srd_t sxa = make_srd(xa, plane_bytes), sxb = make_srd(xb, plane_bytes);
+        const int rbase = mrow0 + 4 * (lane >> 5);
+        const uint32_t voff = chok ? (uint32_t)(rbase * Ch + tau) * 4u : FWN_OOB;     // rows past M fall off the descriptor
+        float lsum = 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float xbv[16], xav[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t so = (uint32_t)((mi * 32 + acc_row_c(r)) * Ch * 4);
+                xbv[r] = buf_load_f32(sxb, voff, so);
+                xav[r] = buf_load_f32(sxa, voff, so);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t so = (uint32_t)((mi * 32 + acc_row_c(r)) * Ch * 4);
+                const bool ok = chok && rbase + mi * 32 + acc_row_c(r) < M;
+                const float ls = acc[mi][0][r] * els, t = acc[mi][1][r] * et;
+                float ob, oa;
+                if (!inverse) {
+                    const float yb = (xbv[r] + b_sh) * b_sc;                  // ActNorm (model.py:86-94)
+                    ob = (yb - t) * __expf(-ls);                               // model.py:134
+                    oa = (xav[r] + a_sh) * a_sc;
+                    lsum += ok ? (a_l3 + b_l3 - ls) : 0.0f;                    // model.py:135 + :80
+                } else {
+                    const float yb = xbv[r] * __expf(ls) + t;                  // model.py:156
+                    ob = yb * b_isc - b_sh;                                    // ActNorm^-1 (model.py:97-102)
+                    oa = xav[r] * a_isc - a_sh;
+                }
+                buf_store_f32(sxb, voff, so, ob);
+                buf_store_f32(sxa, voff, so, oa);
+            }
+        }
+        if (partial) {          // one slot per (row tile, pair tile, wave row): fixed order, summed by prior_kernel
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) lsum += __shfl_xor(lsum, s);
+            const int tile_m = mrow0 >> 6, wm = (mrow0 >> 5) & 1;
+            if (lane == 0) {
+                partial[(tile_m * 4 + pt) * 2 + wm] = lsum;
+                if (pt == 0)
+                    for (int p2 = npt; p2 < 4; ++p2) partial[(tile_m * 4 + p2) * 2 + wm] = 0.0f;
+            }
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------
 // Tail: skip-sum GEMM -> ReLU -> final 1x1 -> ReLU -> ZeroConv1d -> coupling + ActNorm.
 // modules.py:175-180,51-56; model.py:86-102,124-141,146-161.
@@ -818,10 +959,26 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 // ---------------------------------------------------------------------------
 // Host-side launchers (called from the C-ABI in api.hip)
 // ---------------------------------------------------------------------------
+// Developer builds (-DFWN_TUNABLE, tools/tune.py) read the dispatch thresholds from the environment once; the product
+// build folds them to the constants below.
+#ifdef FWN_TUNABLE
+#include <stdlib.h>
+static int fwn_tune_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#define FWN_TUNE(name, dflt) ([]() -> int { static const int v = fwn_tune_env(#name, dflt); return v; }())
+#else
+#define FWN_TUNE(name, dflt) (dflt)
+#endif
 #ifndef FWN_TAIL256_MIN
 #define FWN_TAIL256_MIN (192 * 256)
 #endif
-int fwn_tail_rows(int M) { return M >= FWN_TAIL256_MIN ? 256 : 128; }   // rows per tail workgroup
+#ifndef FWN_TAIL_SPLIT_MAX
+#define FWN_TAIL_SPLIT_MAX 12288      // rows up to which the N-split tail (three ring GEMMs) replaces the fused tail
+#endif
+int fwn_tail_rows(int M) { return M >= FWN_TAIL256_MIN ? 256 : 128; }   // rows per fused-tail workgroup
+int fwn_tail_is_split(int M) { return M <= FWN_TUNE(FWN_TAIL_SPLIT_MAX, FWN_TAIL_SPLIT_MAX); }
+int fwn_tail_npartials(int M) {       // log-det partial slots one tail launch writes
+    return fwn_tail_is_split(M) ? ((M + 63) / 64) * 8 : (M + fwn_tail_rows(M) - 1) / fwn_tail_rows(M);
+}
 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -845,7 +1002,7 @@ static void launch_gemm128(const Prob& p, int M, int ntn, hipStream_t st) {
     hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, WM, WN, BK, D, Prob, KSP>),                        \
                        dim3(((M + BM - 1) / BM) * (N / BN)), dim3(64 * WM * WN * KSP), 0, st, p, N / BN)
 template <class Prob>
-static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
+static void launch_ring(const Prob& p, int M, int N, int ksteps, hipStream_t st) {
     // 16-wave workgroups (4 waves per SIMD) hide the barrier / LDS latency of the K loop best
     // (tools/bench_gemm.hip): 256x256 reaches ~0.8 PF on the block-1 gate, 8-wave tiles ~0.7.
     const int FILL = 192;    // workgroups needed before a fatter tile pays (256 CUs)
@@ -858,7 +1015,14 @@ static void launch_ring(const Prob& p, int M, int N, hipStream_t st) {
     } else if (((M + 63) / 64) * (N / 128) >= FILL) {
         RING_LAUNCH(64, 128, 2, 2, 64, 4);
     } else {
-        RING_LAUNCHK(64, 64, 2, 1, 64, 4, 2);   // 2-way intra-workgroup split-K: 4 waves per tile
+        // A launch this small is a latency chain: per K chunk every wave pays its DMA issues (~100+ cycles a piece), a
+        // barrier and an LDS round trip for a handful of MFMAs.  128-wide chunks halve the number of round trips and
+        // intra-workgroup split-K (4 wave groups taking alternate k-steps) spreads the DMA issues over 8 waves
+        // (tools/bench_gemm.hip, K = 768: 8.1 -> 6.7 us); K must be a multiple of 128 for the wide chunks.
+        const int mode = FWN_TUNE(FWN_SMALL_TILE, 2);
+        if (ksteps % 8 == 0 && mode == 2) RING_LAUNCHK(64, 64, 2, 1, 128, 4, 4);
+        else if (ksteps % 8 == 0 && mode == 1) RING_LAUNCHK(64, 64, 2, 1, 128, 4, 2);
+        else RING_LAUNCHK(64, 64, 2, 1, 64, 4, 2);
     }
 }
 
@@ -869,7 +1033,7 @@ void fwn_launch_front(const float* xa, const float* an_a, const void* W, const v
         const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
         hipLaunchKernelGGL(xprep_kernel, dim3(grid), dim3(256), 0, st, xa, an_a, M, Ch, apply_an, (bf16*)scratch);
         FrontRingProb rp{(const bf16*)scratch, (const bf16*)W2, bias, (bf16*)hout, M, Ti, Ch};
-        launch_ring(rp, M, 256, st);
+        launch_ring(rp, M, 256, 6 * Ch / 16, st);
         return;
     }
     FrontProb p{xa, an_a, (const bf16*)W, bias, (bf16*)hout, M, Ti, Ch, ilog2(Ch), kpad, apply_an};
@@ -898,13 +1062,13 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
             hipLaunchKernelGGL((gate_halo_kernel<256, 128, GateProb>), dim3(t256 * 4), dim3(1024), 0, st, p, 4);
         return;
     }
-    launch_ring(p, M, 512, st);
+    launch_ring(p, M, 512, (768 + (ca ? kcpad : 0)) / 16, st);
 }
 
 void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M,
                     hipStream_t st) {
     ResProb p{(const bf16*)o, (const bf16*)hin, (const bf16*)W, bias, (bf16*)hout, M};
-    launch_ring(p, M, 256, st);
+    launch_ring(p, M, 256, 16, st);
 }
 
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
@@ -934,8 +1098,20 @@ void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_
 
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
                      const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,
-                     float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse,
-                     hipStream_t st) {
+                     float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse, void* scratch_s,
+                     void* scratch_u, hipStream_t st) {
+    if (fwn_tail_is_split(M)) {          // scratch_s / scratch_u: [M][256] bf16 each (api.hip checks they are there)
+        bf16* S = (bf16*)scratch_s;
+        bf16* U = (bf16*)scratch_u;
+        TailLinProb p1{(const bf16*)o, (const bf16*)Ws, bs, S, o_stride, L, M};
+        launch_ring(p1, M, 256, L * 16, st);
+        TailLinProb p2{S, (const bf16*)Wf, bfin, U, 0, 1, M};
+        launch_ring(p2, M, 256, 16, st);
+        TailZeroProb p3{U, (const bf16*)Wz, bz, ez, an, xa, xb, partial, M, Ch, npt, inverse};
+        hipLaunchKernelGGL((gemm_ring_kernel<64, 64, 2, 1, 128, 3, TailZeroProb, 2>), dim3(((M + 63) / 64) * npt), dim3(256), 0,
+                           st, p3, npt);
+        return;
+    }
     TailArgs a{(const bf16*)o, (const bf16*)Ws, bs, (const bf16*)Wf, bfin, (const bf16*)Wz, bz, ez, an,
                xa, xb, partial, o_stride, L, M, Ch, npt, inverse};
     if (fwn_tail_rows(M) == 256)

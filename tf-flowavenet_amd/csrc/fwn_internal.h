@@ -13,10 +13,12 @@ void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_
                      int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, hipStream_t st);
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
                      const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,
-                     float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse,
-                     hipStream_t st);
+                     float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse, void* scratch_s,
+                     void* scratch_u, hipStream_t st);
 
-int fwn_tail_rows(int M);   // rows per tail workgroup (sizes the log-det partial buffer)
+int fwn_tail_rows(int M);        // rows per fused-tail workgroup
+int fwn_tail_is_split(int M);    // the N-split tail (three ring GEMMs; needs [2][M][256] bf16 scratch) serves this M
+int fwn_tail_npartials(int M);   // log-det partial slots a tail launch writes
 
 void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st);
 void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,

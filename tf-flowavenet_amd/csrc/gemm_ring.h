@@ -52,12 +52,13 @@ struct RingGeom {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_le(int pending_chunks) {
-    // pending_chunks (wave-uniform) in {0, 1, .., MAXC}: wait until at most pending*N DMAs remain
-    if (pending_chunks >= 4 && 4 * N <= 63) FWN_WAIT_VMCNT((4 * N <= 63 ? 4 * N : 63));      // ring depth 5
-    else if (pending_chunks >= 3) FWN_WAIT_VMCNT(3 * N);
-    else if (pending_chunks == 2) FWN_WAIT_VMCNT(2 * N);
-    else if (pending_chunks == 1) FWN_WAIT_VMCNT(N);
-    else FWN_WAIT_VMCNT(0);
+    // pending_chunks (wave-uniform) in {0, 1, .., 7}: wait until at most pending*N DMAs remain (vmcnt is a 6-bit
+    // counter: depths whose product exceeds 63 wait for the deepest count that still fits)
+#define FWN_VM_CASE(c)                                                                       \
+    if constexpr ((c) * N <= 63) { if (pending_chunks >= (c)) { FWN_WAIT_VMCNT((c) * N <= 63 ? (c) * N : 0); return; } }
+    FWN_VM_CASE(7) FWN_VM_CASE(6) FWN_VM_CASE(5) FWN_VM_CASE(4) FWN_VM_CASE(3) FWN_VM_CASE(2) FWN_VM_CASE(1)
+#undef FWN_VM_CASE
+    FWN_WAIT_VMCNT(0);
 }
 
 // KSP > 1: intra-workgroup split-K for small tiles - KSP wave groups take alternate k-steps of
@@ -76,7 +77,7 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
     constexpr int PB = BN / (G::PR * NWV);       // B pieces per wave per chunk
     static_assert(PA * G::PR * NWV == BM && PB * G::PR * NWV == BN, "pieces must divide evenly over waves");
     constexpr int PW = PA + PB;
-    static_assert(D >= 2 && D <= 5, "ring depth");
+    static_assert(D >= 2 && D <= 8, "ring depth");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT];
 
     const int tid = threadIdx.x;

@@ -42,7 +42,8 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8;
     const int T = 16128;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int blk = 0; blk < 8; ++blk) {
+    const int blk0 = argc > 2 ? atoi(argv[2]) : 0, blk1 = argc > 3 ? atoi(argv[3]) : 7;
+    for (int blk = blk0; blk <= blk1; ++blk) {
         const int Ch = 1 << blk, Ti = T / (2 * Ch), M = B * Ti, cin = 40 * 2 * Ch, kcpad = (cin + 63) / 64 * 64;
         const bool hoist = M < 4096;
         void* h = dalloc((size_t)M * 512, 1);
@@ -86,6 +87,14 @@ int main(int argc, char** argv) {
         if (M <= 4096) {
             GATE_CFG(64, 64, 2, 1, 64, 4);
             GATE_CFGK(64, 64, 2, 1, 64, 4, 2);
+            GATE_CFGK(64, 64, 2, 1, 64, 8, 2);
+            GATE_CFGK(64, 64, 2, 1, 128, 4, 2);
+            GATE_CFGK(64, 64, 2, 1, 128, 3, 2);
+            GATE_CFGK(64, 64, 2, 1, 128, 4, 4);
+            GATE_CFGK(64, 64, 2, 1, 128, 4, 8);
+            GATE_CFGK(32, 64, 1, 1, 128, 4, 8);
+            GATE_CFGK(32, 64, 1, 1, 128, 4, 4);
+            GATE_CFGK(64, 128, 2, 2, 128, 3, 4);
             GATE_CFGK(64, 64, 2, 1, 64, 4, 4);
             GATE_CFGK(64, 128, 2, 2, 64, 4, 2);
             GATE_CFGK(128, 128, 4, 2, 64, 3, 2);
@@ -100,8 +109,12 @@ int main(int argc, char** argv) {
             float* xa = (float*)dalloc((size_t)M * Ch * 4, 0);
             float* xb = (float*)dalloc((size_t)M * Ch * 4, 0);
             float* part = (float*)dalloc(1 << 16, 0);
-            timeit("tail", 2.0 * M * (512.0 * 256 + 256 * 256 + 256.0 * 2 * Ch), [&] {
-                fwn_launch_tail(o, (long)M * 256, 2, Ws, bias, Wf, bias, Wz, bz, bz, an, xa, xb, part, M, Ch, npt, 0, 0); });
+            void* scr = dalloc((size_t)M * 1024, 0);
+            timeit(fwn_tail_is_split(M) ? "tail (N-split, 3 launches)" : "tail (fused)", 2.0 * M * (512.0 * 256 + 256 * 256 + 256.0 * 2 * Ch), [&] {
+                fwn_launch_tail(o, (long)M * 256, 2, Ws, bias, Wf, bias, Wz, bz, bz, an, xa, xb, part, M, Ch, npt, 0, scr,
+                                (char*)scr + (size_t)M * 512, 0); });
+            CK(hipDeviceSynchronize());
+            CK(hipFree(scr));
             CK(hipDeviceSynchronize());
             for (void* q : {Ws, Wf, Wz, (void*)bz, (void*)an, (void*)xa, (void*)xb, (void*)part}) CK(hipFree(q));
         }
