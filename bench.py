@@ -171,6 +171,47 @@ def rtf_10s(model, hp, dev, world, iters=5):
             "samples_per_s_whole_job": world * t / sec, "n_gpus": world}
 
 
+def fp8_leg(hp, params, model_bf16, x, c, z, b, t):
+    """BASELINE configs[4]: the same workload with the dilated taps of the MFMA-bound gates (blocks 0-2 here) on the fp8
+    (e4m3, v_mfma_scale_f32_32x32x64_f8f6f4) path.  Secondary numbers: the headline stays bf16."""
+    import ctypes as C
+    import torch
+    from tf_flowavenet_amd import _lib
+    from tf_flowavenet_amd.model import FloWaveNet
+    lib = _lib.load()
+    m8 = FloWaveNet(hp, init=True, device=x.device, gate_fp8=True).load_params(params)
+    lp8, ld8 = m8.forward(x, c)
+    lpb, ldb = model_bf16.forward(x, c)
+
+    def timed(fn, n=8):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / n
+
+    fwd, inv = timed(lambda: m8.forward(x, c)), timed(lambda: m8.reverse(z, c))
+    d = m8._packed.flow_descs[0]
+    ti = t // 2
+    m = b * ti
+    h8 = torch.randint(0, 120, (m, 256), dtype=torch.uint8, device=x.device)       # e4m3 bytes of values in [0, 448)
+    ca = torch.rand(m, d.cin, device=x.device).to(torch.bfloat16)
+    o = torch.empty(m, 256, device=x.device, dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    gate_s = timed(lambda: _lib.check(lib.fwn_gate_fp8(C.byref(d), 0, h8.data_ptr(), ca.data_ptr(), o.data_ptr(), m, ti, st)), n=20)
+    flops = 2.0 * m * (768 + d.cin) * 512
+    return {"workload": "configs[4]: fp8 (e4m3) dilated taps in the gates of blocks 0-2, otherwise the configs[1] workload",
+            "fwd_ms": fwd * 1e3, "inv_ms": inv * 1e3, "fwd_samples_per_s": b * t / fwd, "inv_samples_per_s": b * t / inv,
+            "log_p": float(lp8), "log_p_bf16": float(lpb), "log_p_rel_diff_vs_bf16": abs(float(lp8) - float(lpb)) / abs(float(lpb)),
+            "logdet": float(ld8), "logdet_bf16": float(ldb),
+            "gate_launch_us": gate_s * 1e6, "gate_tflops": flops / gate_s / 1e12,
+            "gate_kernel": "gate_halo_kernel<256,256,GateProb,FP8> (block 0)"}
+
+
 def train_leg(hp, params, rank, world, dev, steps=10, batch=8, samples=6400, force_collectives=False):
     """BASELINE configs[2]: the data-parallel training step, `batch` crops of `samples` samples per GPU (global batch
     64 on 8 GPUs): gradients of -(log_p + logdet), RCCL all-reduce of the flat fp32 gradient started block by block
@@ -300,6 +341,7 @@ def main():
                     help="HIP streams per direction; successive (independent) steps rotate over them")
     ap.add_argument("--no-train", action="store_true", help="skip the configs[2] training-step leg")
     ap.add_argument("--no-rtf", action="store_true", help="skip the configs[3] 10 s clip leg")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] fp8 gate leg")
     ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--leg-timeout", type=int, default=240, help="seconds an optional leg may take")
     ap.add_argument("--force-collectives", action="store_true",
@@ -474,7 +516,7 @@ def main():
             out["cpu_baseline"] = None
         else:
             out["cpu_baseline"] = cpu_baseline(hp, params, t)
-    out["rtf_10s"] = out["train"] = None
+    out["rtf_10s"] = out["train"] = out["fp8"] = None
 
     def emit(note=None):
         if rank == 0:
@@ -490,6 +532,13 @@ def main():
             out["rtf_10s"] = rtf_10s(model, hp, dev, world)
         except Exception as e:
             out["rtf_10s"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        deadline.disarm()
+    if not args.no_fp8 and rank == 0:
+        deadline.arm(args.leg_timeout, "the configs[4] fp8 leg")
+        try:
+            out["fp8"] = fp8_leg(hp, params, model, x, c, z, b, t)
+        except Exception as e:
+            out["fp8"] = {"error": "%s: %s" % (type(e).__name__, e)}
         deadline.disarm()
     if not args.no_train:
         del model

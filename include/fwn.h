@@ -110,6 +110,10 @@ typedef struct fwn_flow_desc {
     const void* Wfinal;  const float* bfinal;               /* [256][256], [256]               */
     const void* Wzero;   const float* bzero; const float* ezero;   /* [npt*64][256], [npt*64]x2 */
     float* an;                                              /* [2][4][Ch] ActNorm (DDI writes)  */
+    /* fp8 dilated-conv path (BASELINE configs[4]); NULL = not packed.  Wd8[l]: the gate-packed rows of Wd[l] as OCP
+     * e4m3 bytes [512][768], stored as W * 2^wd8_exp[l] (one power-of-two scale per matrix, fwn_pack_e4m3). */
+    const void* Wd8[FWN_MAX_LAYERS];
+    int32_t wd8_exp[FWN_MAX_LAYERS];
 } fwn_flow_desc;
 
 /* ---- stage entry points (K4..K8), exposed so each kernel can be parity-tested alone ---- */
@@ -121,6 +125,21 @@ int fwn_front(const fwn_flow_desc* d, const float* xa, void* h_out, void* scratc
 /* K5 gated dilated layer `layer` (modules.py:113-124).  ca==NULL uses P (precomputed c_a@Wc). */
 int fwn_gate(const fwn_flow_desc* d, int layer, const void* h, const void* ca, const float* P, void* o,
              int M, int Ti, void* stream);
+/* K5 with the dilated taps in fp8 (v_mfma_scale_f32_32x32x64_f8f6f4): h8 = e4m3 copy of h [M][256] bytes
+ * (fwn_cast_e4m3, or written by the front / res kernels inside fwn_flow_run_fp8), weights d->Wd8[layer]; the 1x1
+ * conditioning conv stays bf16 in the same accumulators.  Exists for the MFMA-bound shapes only:
+ * fwn_gate_fp8_supported(M, layer) != 0 (M >= 12288 rows, dilation <= 3); other shapes return FWN_ERR_ARG. */
+int fwn_gate_fp8_supported(int M, int layer);
+int fwn_gate_fp8(const fwn_flow_desc* d, int layer, const void* h8, const void* ca, void* o, int M, int Ti, void* stream);
+/* bf16 [n] -> OCP e4m3 [n] (round to nearest even, saturating at +-448). */
+int fwn_cast_e4m3(const void* src_bf16, void* dst_u8, int64_t n, void* stream);
+/* e4m3 weight packing: fwn_wn_absmax folds max |v[k][n] scale[n] mul| of one source kernel into *amax (a device
+ * float, zero it first; scale may be NULL); fwn_pack_e4m3 then writes out[n'*ld_dst + k'] = e4m3(v[src_k[k']][src_n[n']]
+ * scale mul 2^e) with e = floor(log2(448 / *amax)) and stores e in *exp_out (device int32).  Index tables as in
+ * fwn_pack_bf16 (several source kernels may share one output matrix and one amax: filter and gate rows). */
+int fwn_wn_absmax(const float* v, const float* scale, int k_src, int n_src, float mul, float* amax, void* stream);
+int fwn_pack_e4m3(const float* v, const float* scale, const int32_t* src_k, const int32_t* src_n, int n_src, int k_dst,
+                  int n_dst, int64_t ld_dst, float mul, const float* amax, void* out_u8, int32_t* exp_out, void* stream);
 /* K6 residual 1x1 (modules.py:126-128): h_out = (h_in + res_conv(o)) * sqrt(0.5). */
 int fwn_res(const fwn_flow_desc* d, int layer, const void* o, const void* h_in, void* h_out, int M,
             void* stream);
@@ -147,6 +166,12 @@ int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float*
 int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
                  void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
                  void* stream);
+
+/* The same flow with the gated layers' dilated taps in fp8 wherever fwn_gate_fp8_supported says so (other layers /
+ * shapes run the bf16 kernels): h8a / h8b are [M][256]-byte scratch buffers for the e4m3 copies of h. */
+int fwn_flow_run_fp8(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
+                     void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
+                     void* h8a, void* h8b, void* stream);
 
 /* ---- mel front-end (preprocessing.py:58-69; librosa.feature.melspectrogram semantics) ----
  * wav [B][T] fp32 -> mel [B][1 + T/hop][n_mels] in [0, 1]: centred STFT (reflect padding, `window`
@@ -300,6 +325,7 @@ typedef struct fwn_model_desc {
     float up_bias[FWN_MAX_UPSAMPLE];
     const fwn_flow_desc* flows;               /* HOST array [n_block*n_flow] */
     int32_t cond_mode;                        /* 0 auto, 1 always fused in gate, 2 always hoisted */
+    int32_t gate_fp8;                         /* != 0: fp8 dilated taps where supported (needs flows[].Wd8) */
 } fwn_model_desc;
 
 size_t fwn_workspace_bytes(const fwn_model_desc* m, int64_t B, int64_t T);

@@ -33,9 +33,10 @@ CASES = {
     "full_b8f6_B1_T16128": (dict(), 1, 16128, "zeros", True),                       # configs[1], latency shape
     "full_b8f6_B8_T16128": (dict(), 8, 16128, "zeros", True),                       # configs[1], the bench.py workload
     "full_b8f6_T220672_10s": (dict(), 1, 220672, "zeros", True),                    # configs[3], 10 s @ 22.05 kHz
+    "hp8000_b5f6_B2_T16128": ("8k", 2, 16128, "zeros", True),                       # configs[4]: 8 kHz model at an fp8-gate size
 }
 # the large cases keep z / x_rev as float16 (|values| < 8: half an ulp <= 2e-3, inside the stated tolerances)
-FP16_CASES = ("full_b8f6_B8_T16128", "full_b8f6_T220672_10s")
+FP16_CASES = ("full_b8f6_B8_T16128", "full_b8f6_T220672_10s", "hp8000_b5f6_B2_T16128")
 
 
 def hp_of(over):

@@ -38,10 +38,23 @@ def test_version(lib):
     assert lib.fwn_version() == 100
 
 
-def test_struct_layout_matches_header():
-    # 6 int32 + (2 + 5*8 + 7 + 1) pointers
-    assert C.sizeof(_lib.FlowDesc) == 24 + 8 * (2 + 5 * _lib.FWN_MAX_LAYERS + 8 + 1)
-    assert _lib.ModelDesc.flows.offset % 8 == 0 and _lib.ModelDesc.up_w.offset == 40
+def test_struct_layout_matches_header(tmp_path):
+    """The ctypes mirrors against the C compiler's view of include/fwn.h: sizes and the offsets of the last members."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fwn.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fwn_flow_desc), offsetof(fwn_flow_desc, an), '
+                   'offsetof(fwn_flow_desc, Wd8), offsetof(fwn_flow_desc, wd8_exp), sizeof(fwn_model_desc), offsetof(fwn_model_desc, up_w), '
+                   'offsetof(fwn_model_desc, flows), offsetof(fwn_model_desc, gate_fp8)); return 0; }\n')
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    F, M = _lib.FlowDesc, _lib.ModelDesc
+    assert got == [C.sizeof(F), F.an.offset, F.Wd8.offset, F.wd8_exp.offset, C.sizeof(M), M.up_w.offset, M.flows.offset,
+                   M.gate_fp8.offset]
 
 
 def test_argument_validation_reports_errors(lib):

@@ -30,6 +30,7 @@ class FlowDesc(C.Structure):
         ("Wskip", vp), ("bskip", vp), ("Wfinal", vp), ("bfinal", vp),
         ("Wzero", vp), ("bzero", vp), ("ezero", vp),
         ("an", vp),
+        ("Wd8", vp * FWN_MAX_LAYERS), ("wd8_exp", i32 * FWN_MAX_LAYERS),
     ]
 
 
@@ -43,6 +44,7 @@ class ModelDesc(C.Structure):
         ("up_bias", C.c_float * FWN_MAX_UPSAMPLE),
         ("flows", C.POINTER(FlowDesc)),
         ("cond_mode", i32),
+        ("gate_fp8", i32),
     ]
 
 
@@ -114,6 +116,13 @@ SIGNATURES = {
     "fwn_actnorm_from_moments": (C.c_int, [vp, C.c_int, vp, vp]),
     "fwn_front": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "fwn_gate": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "fwn_gate_fp8_supported": (C.c_int, [C.c_int, C.c_int]),
+    "fwn_gate_fp8": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "fwn_cast_e4m3": (C.c_int, [vp, vp, i64, vp]),
+    "fwn_wn_absmax": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]),
+    "fwn_pack_e4m3": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, i64, C.c_float, vp, vp, vp, vp]),
+    "fwn_flow_run_fp8": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,
+                                   C.c_int, vp, vp, vp]),
     "fwn_res": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, vp]),
     "fwn_cond": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, vp]),

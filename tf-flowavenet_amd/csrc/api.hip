@@ -130,7 +130,7 @@ int fwn_front(const fwn_flow_desc* d, const float* xa, void* h_out, void* scratc
     REQUIRE(ALIGNED16(xa) && ALIGNED16(h_out), "fwn_front: buffers must be 16-byte aligned");
     REQUIRE(!scratch || ALIGNED16(scratch), "fwn_front: scratch must be 16-byte aligned");
     fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h_out, scratch, M, Ti, d->Ch, d->kfpad, apply_an,
-                     (hipStream_t)stream);
+                     nullptr, (hipStream_t)stream);
     return check_launch("fwn_front");
 }
 
@@ -166,13 +166,46 @@ int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void*
     return check_launch("fwn_gate_train");
 }
 
+int fwn_gate_fp8_supported(int M, int layer) {
+    return layer >= 0 && layer < FWN_MAX_LAYERS && M > 0 && fwn_gate_fp8_ok(M, dilation_of(layer)) ? 1 : 0;
+}
+int fwn_gate_fp8(const fwn_flow_desc* d, int layer, const void* h8, const void* ca, void* o, int M, int Ti, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(layer >= 0 && layer < d->L, "fwn_gate_fp8: layer %d out of range", layer);
+    REQUIRE(h8 && ca && o && M > 0 && Ti > 0 && M % Ti == 0, "fwn_gate_fp8: bad argument");
+    REQUIRE(d->Wd8[layer], "fwn_gate_fp8: the flow has no e4m3 weights (fwn_pack_e4m3)");
+    REQUIRE(fwn_gate_fp8_supported(M, layer), "fwn_gate_fp8: no fp8 kernel for M=%d, layer %d (needs M >= 12288, dilation <= 3)", M, layer);
+    REQUIRE(ALIGNED16(h8) && ALIGNED16(o) && ALIGNED16(ca) && ALIGNED16(d->Wd8[layer]), "fwn_gate_fp8: buffers must be 16-byte aligned");
+    fwn_launch_gate_fp8(h8, ca, d->Wd8[layer], d->wd8_exp[layer], d->Wc[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
+                        d->cin, d->kcpad, (hipStream_t)stream);
+    return check_launch("fwn_gate_fp8");
+}
+int fwn_cast_e4m3(const void* src_bf16, void* dst_u8, int64_t n, void* stream) {
+    REQUIRE(src_bf16 && dst_u8 && n > 0, "fwn_cast_e4m3: bad argument");
+    fwn_launch_cast_e4m3(src_bf16, dst_u8, (long)n, (hipStream_t)stream);
+    return check_launch("fwn_cast_e4m3");
+}
+int fwn_wn_absmax(const float* v, const float* scale, int k_src, int n_src, float mul, float* amax, void* stream) {
+    REQUIRE(v && amax && k_src > 0 && n_src > 0, "fwn_wn_absmax: bad argument");
+    fwn_launch_wn_absmax(v, scale, k_src, n_src, mul, amax, (hipStream_t)stream);
+    return check_launch("fwn_wn_absmax");
+}
+int fwn_pack_e4m3(const float* v, const float* scale, const int32_t* src_k, const int32_t* src_n, int n_src, int k_dst,
+                  int n_dst, int64_t ld_dst, float mul, const float* amax, void* out_u8, int32_t* exp_out, void* stream) {
+    REQUIRE(v && src_k && src_n && amax && out_u8 && exp_out, "fwn_pack_e4m3: null pointer");
+    REQUIRE(n_src > 0 && k_dst > 0 && n_dst > 0 && ld_dst >= k_dst, "fwn_pack_e4m3: bad shape");
+    fwn_launch_pack_e4m3(v, scale, src_k, src_n, n_src, k_dst, n_dst, (long)ld_dst, mul, amax, out_u8, exp_out, (hipStream_t)stream);
+    return check_launch("fwn_pack_e4m3");
+}
+
 int fwn_res(const fwn_flow_desc* d, int layer, const void* o, const void* h_in, void* h_out, int M,
             void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(layer >= 0 && layer < d->L - 1, "fwn_res: layer %d has no live res_conv", layer);
     REQUIRE(o && h_in && h_out && M > 0, "fwn_res: bad argument");
-    fwn_launch_res(o, h_in, d->Wres[layer], d->bres[layer], h_out, M, (hipStream_t)stream);
+    fwn_launch_res(o, h_in, d->Wres[layer], d->bres[layer], h_out, M, nullptr, (hipStream_t)stream);
     return check_launch("fwn_res");
 }
 
@@ -205,7 +238,7 @@ int fwn_tail_partials(int M) { return M > 0 ? fwn_tail_npartials(M) : 0; }
 // ddi: 0 none, 1 local two-pass init, 2 moments -> reduce callback (may be NULL) -> tables
 static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
                          void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
-                         double* mom, fwn_reduce_fn reduce, void* user, void* stream) {
+                         double* mom, fwn_reduce_fn reduce, void* user, void* h8a, void* h8b, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(B > 0 && T > 0 && T % (2 * (int64_t)d->Ch) == 0, "fwn_flow_run: T=%lld not divisible by 2*Ch=%d",
@@ -228,16 +261,29 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
             return fail(FWN_ERR_ARG, "fwn_model_forward_init: the reduce callback failed");
         fwn_launch_ddi_from_moments(mom, d->Ch, d->an, st);
     }
-    fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h0, h1, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1, st);
+    // fp8 dilated taps for layer l: e4m3 weights packed, the shape has an fp8 kernel, conditioning fused, and the
+    // producer of h (VALU front conv: Ch <= 16; res kernel) can write the e4m3 copy
+    auto fp8_layer = [&](int l) {
+        return h8a && h8b && ca && l < d->L && d->Wd8[l] && fwn_gate_fp8_ok(M, dilation_of(l)) && (l > 0 || d->Ch <= 16);
+    };
+    void* h8c = h8a;
+    void* h8n = h8b;
+    fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h0, h1, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1,
+                     fp8_layer(0) ? h8c : nullptr, st);
     void* hc = h0;
     void* hn = h1;
     for (int l = 0; l < d->L; ++l) {
         void* ol = (char*)o + (size_t)l * M * 256 * 2;
-        fwn_launch_gate(hc, ca, P ? P + (size_t)l * M * 512 : nullptr, d->Wd[l], d->Wc[l], d->bgate[l], ol, M,
-                        Ti, dilation_of(l), d->cin, d->kcpad, nullptr, st);
+        if (fp8_layer(l))
+            fwn_launch_gate_fp8(h8c, ca, d->Wd8[l], d->wd8_exp[l], d->Wc[l], d->bgate[l], ol, M, Ti, dilation_of(l), d->cin,
+                                d->kcpad, st);
+        else
+            fwn_launch_gate(hc, ca, P ? P + (size_t)l * M * 512 : nullptr, d->Wd[l], d->Wc[l], d->bgate[l], ol, M,
+                            Ti, dilation_of(l), d->cin, d->kcpad, nullptr, st);
         if (l + 1 < d->L) {
-            fwn_launch_res(ol, hc, d->Wres[l], d->bres[l], hn, M, st);
+            fwn_launch_res(ol, hc, d->Wres[l], d->bres[l], hn, M, fp8_layer(l + 1) ? h8n : nullptr, st);
             void* t = hc; hc = hn; hn = t;
+            t = h8c; h8c = h8n; h8n = t;
         }
     }
     // both h buffers are free once the last gate has run: the N-split tail (small M) keeps S and U there
@@ -249,7 +295,15 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
 int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
                  void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
                  void* stream) {
-    return flow_run_impl(d, B, T, xa, xb, ca, h0, h1, o, P, partial, inverse, ddi ? 1 : 0, nullptr, nullptr, nullptr, stream);
+    return flow_run_impl(d, B, T, xa, xb, ca, h0, h1, o, P, partial, inverse, ddi ? 1 : 0, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, stream);
+}
+int fwn_flow_run_fp8(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
+                     void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
+                     void* h8a, void* h8b, void* stream) {
+    REQUIRE(h8a && h8b && ALIGNED16(h8a) && ALIGNED16(h8b), "fwn_flow_run_fp8: h8 scratch buffers (16-byte aligned) required");
+    return flow_run_impl(d, B, T, xa, xb, ca, h0, h1, o, P, partial, inverse, ddi ? 1 : 0, nullptr, nullptr, nullptr, h8a, h8b,
+                         stream);
 }
 
 int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_partial, float* out2,
@@ -464,7 +518,7 @@ int fwn_clip_adam_dev(float* w, const float* g, float* m, float* v, int64_t n, c
 // Whole-model sequencing
 // ---------------------------------------------------------------------------------------------
 struct Carve {
-    size_t cplanes, up0, up1, planes, h0, h1, o, P, partial, mom, total;
+    size_t cplanes, up0, up1, planes, h0, h1, o, P, partial, mom, h8a, h8b, total;
     int n_partial;
 };
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -537,6 +591,8 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
     c.n_partial = npart;
     // per-flow moment buffers of the data-parallel ActNorm init: 4 Ch + 1 doubles each, Ch <= 2^(n_block-1)
     c.mom = off; off = align_up(off + (size_t)m->n_block * m->n_flow * (4 * ((size_t)1 << (m->n_block - 1)) + 1) * 8);
+    c.h8a = off; off = align_up(off + (m->gate_fp8 ? Mmax * 256 : 0));      // e4m3 copies of h (fp8 gate path)
+    c.h8b = off; off = align_up(off + (m->gate_fp8 ? Mmax * 256 : 0));
     c.total = off;
     return c;
 }
@@ -621,7 +677,8 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
             double* mom = (double*)(ws + c.mom) + (size_t)(i * m->n_flow + j) * (4 * ((size_t)1 << (m->n_block - 1)) + 1);
             rc = flow_run_impl(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
-                               ws + c.h0, ws + c.h1, ws + c.o, P, partial + poff, 0, init, mom, reduce, user, stream);
+                               ws + c.h0, ws + c.h1, ws + c.o, P, partial + poff, 0, init, mom, reduce, user,
+                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, stream);
             if (rc) return rc;
             poff += fwn_tail_partials((int)M);
             p ^= 1;   // change_order (model.py:190)
@@ -688,8 +745,9 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
             const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
             const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
-            rc = fwn_flow_run(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
-                              ws + c.h0, ws + c.h1, ws + c.o, P, nullptr, 1, 0, stream);
+            rc = flow_run_impl(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
+                               ws + c.h0, ws + c.h1, ws + c.o, P, nullptr, 1, 0, nullptr, nullptr, nullptr,
+                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, stream);
             if (rc) return rc;
         }
     }

@@ -50,6 +50,72 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ v, 
     }
 }
 
+static inline int grid_for(long total);
+// ---- e4m3 packing of the dilated conv weights (fp8 gate path, BASELINE configs[4]) ---------------------------------
+// One power-of-two scale per packed matrix: e = floor(log2(448 / max|W|)), bytes = e4m3(W 2^e); the gate kernel undoes
+// it with the MFMA's E8M0 scale operand.  absmax: max over all source elements of |v[k][n] scale[n] mul| (atomicMax on
+// the bit pattern of a non-negative float: exact and order-independent); amax must be zeroed before the first call.
+__global__ __launch_bounds__(256) void wn_absmax_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                        int n_src, long total, float mul, unsigned int* __restrict__ amax) {
+    float m = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float val = v[i] * mul;
+        if (scale) val *= scale[i % n_src];
+        m = fmaxf(m, fabsf(val));
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+}
+__device__ __forceinline__ int e4m3_exponent(float amax) {      // e with amax 2^e <= 448 < amax 2^(e+1)
+    if (!(amax > 0.0f)) return 0;
+    int e = (int)floorf(log2f(448.0f / amax));
+    while (ldexpf(amax, e) > 448.0f) --e;
+    while (ldexpf(amax, e + 1) <= 448.0f) ++e;
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+__global__ __launch_bounds__(256) void pack_e4m3_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                        const int* __restrict__ src_k, const int* __restrict__ src_n,
+                                                        int n_src, int k_dst, long ld_dst, long total, float mul,
+                                                        const float* __restrict__ amax, unsigned char* __restrict__ out,
+                                                        int* __restrict__ exp_out) {
+    const int e = e4m3_exponent(*amax);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *exp_out = e;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int kd = (int)(i % k_dst), nd = (int)(i / k_dst);
+        const int sk = src_k[kd], sn = src_n[nd];
+        if (sn < 0) continue;
+        float val = 0.0f;
+        if (sk >= 0) {
+            val = v[(size_t)sk * n_src + sn] * mul;
+            if (scale) val *= scale[sn];
+        }
+        out[(size_t)nd * ld_dst + kd] = (unsigned char)pack_e4m3x2(ldexpf(val, e), 0.0f);
+    }
+}
+// bf16 [n] -> e4m3 [n] (tests, and callers that hold only the bf16 h)
+__global__ __launch_bounds__(256) void cast_e4m3_kernel(const bf16* __restrict__ src, unsigned char* __restrict__ dst, long n) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (long)gridDim.x * 512) {
+        const float a = (float)src[i], b = i + 1 < n ? (float)src[i + 1] : 0.0f;
+        const unsigned int pk = pack_e4m3x2(a, b);
+        dst[i] = (unsigned char)pk;
+        if (i + 1 < n) dst[i + 1] = (unsigned char)(pk >> 8);
+    }
+}
+void fwn_launch_wn_absmax(const float* v, const float* scale, int k_src, int n_src, float mul, float* amax, hipStream_t st) {
+    const long total = (long)k_src * n_src;
+    hipLaunchKernelGGL(wn_absmax_kernel, dim3(grid_for(total)), dim3(256), 0, st, v, scale, n_src, total, mul, (unsigned int*)amax);
+}
+void fwn_launch_pack_e4m3(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src, int k_dst,
+                          int n_dst, long ld_dst, float mul, const float* amax, void* out, int* exp_out, hipStream_t st) {
+    const long total = (long)k_dst * n_dst;
+    hipLaunchKernelGGL(pack_e4m3_kernel, dim3(grid_for(total)), dim3(256), 0, st, v, scale, src_k, src_n, n_src, k_dst, ld_dst,
+                       total, mul, amax, (unsigned char*)out, exp_out);
+}
+void fwn_launch_cast_e4m3(const void* src, void* dst, long n, hipStream_t st) {
+    hipLaunchKernelGGL(cast_e4m3_kernel, dim3(grid_for((n + 1) / 2)), dim3(256), 0, st, (const bf16*)src, (unsigned char*)dst, n);
+}
+
 // ---- grouped form of the two kernels above: a whole model's weight-norm scales and packed copies
 // in two launches driven by device-resident job tables (a training step re-packs every weight from
 // the fp32 masters; the tables are built once because master and output pointers are stable).

@@ -45,6 +45,9 @@ __device__ __forceinline__ void buf_load16_lds(srd_t s, uint32_t voff, unsigned 
 __device__ __forceinline__ void buf_store_bf16(srd_t s, uint32_t voff, uint32_t soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)v), s, voff, soff, 0);
 }
+__device__ __forceinline__ void buf_store_u8(srd_t s, uint32_t voff, uint32_t soff, unsigned int v) {
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, s, voff, soff, 0);
+}
 __device__ __forceinline__ void buf_store_f32(srd_t s, uint32_t voff, uint32_t soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), s, voff, soff, 0);
 }
@@ -101,6 +104,14 @@ __device__ __forceinline__ f32x2 gated_unit2(f32x2 u, f32x2 v) {
     r.x = __builtin_amdgcn_rcpf(den.x);
     r.y = __builtin_amdgcn_rcpf(den.y);
     return (1.0f - a) * r;
+}
+
+// Two fp32 -> two OCP e4m3 bytes (v_cvt_pk_fp8_f32, round to nearest even), saturating at +-448 (e4m3fn has no
+// infinity: without the clamp an overflow would become NaN).  Low byte = a.
+__device__ __forceinline__ unsigned int pack_e4m3x2(float a, float b) {
+    a = fminf(fmaxf(a, -448.0f), 448.0f);
+    b = fminf(fmaxf(b, -448.0f), 448.0f);
+    return (unsigned int)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
 }
 
 __device__ __forceinline__ float fast_sigmoid(float x) {

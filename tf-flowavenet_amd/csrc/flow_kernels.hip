@@ -30,6 +30,7 @@ struct FrontProb {
     const float* bias;    // [256]
     bf16* hout;           // [M][256]
     int M, Ti, Ch, chlog, kpad, apply_an;
+    unsigned char* h8out = nullptr;   // [M][256] e4m3 copy for the fp8 gate (front_valu_kernel only)
     typedef RowCtxT RowCtx;
     struct ChunkCtx { int k0; int lo; };
     __device__ int nchunks() const { return 2 * (kpad / FWN_BK); }
@@ -149,6 +150,9 @@ __global__ __launch_bounds__(256) void front_valu_kernel(FrontProb p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) o.e[c] = (bf16)fmaxf(acc[r][c], 0.0f);
             *(uint2*)(p.hout + (size_t)row * FWN_HID + 4 * lane) = o.u;
+            if (p.h8out)         // quantise the bf16 value the bf16 path would read, not the fp32 one: one source of truth
+                *(unsigned int*)(p.h8out + (size_t)row * FWN_HID + 4 * lane) =
+                    pack_e4m3x2((float)o.e[0], (float)o.e[1]) | (pack_e4m3x2((float)o.e[2], (float)o.e[3]) << 16);
         }
     }
 }
@@ -232,6 +236,10 @@ struct GateProb {
     bf16* o;              // [M][256]
     int M, Ti, dil, cin, kcpad;
     bf16* aux = nullptr;  // training only: [M][512] = (tanh f | sigmoid g) kept for the backward pass
+    // fp8 dilated taps (gate_halo_kernel<.., FP8>): e4m3 copies of h and of the packed conv weights (stored as W 2^e)
+    const unsigned char* h8 = nullptr;    // [M][256]
+    const unsigned char* Wd8 = nullptr;   // [512][768]
+    int sb = 127;                         // E8M0 scale operand of the weights: 127 - e
     typedef RowCtxT RowCtx;
     struct ChunkCtx { int cond, acol, bcol, shift, kvalid; };
     template <int BK> __device__ int nchunks() const { return (3 * FWN_HID + (ca ? kcpad : 0)) / BK; }
@@ -344,6 +352,7 @@ struct ResProb {
     const float* bias;    // [256]
     bf16* hout;           // [M][256]
     int M;
+    unsigned char* h8out = nullptr;   // [M][256] e4m3 copy of hout for the next layer's fp8 gate
     struct RowCtx { int row; };
     struct ChunkCtx { int k0; };
     template <int BK> __device__ int nchunks() const { return FWN_HID / BK; }
@@ -378,6 +387,16 @@ struct ResProb {
                 for (int r = 0; r < 16; ++r)
                     buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
                                    (hv[r] + acc[mi][ni][r] + b) * 0.70710678118654752f);
+                if (h8out) {
+                    const srd_t s8 = make_srd(h8out, (uint32_t)((size_t)M * FWN_HID));
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const unsigned int pk = pack_e4m3x2((float)(bf16)((hv[r] + acc[mi][ni][r] + b) * 0.70710678118654752f),
+                                                            (float)(bf16)((hv[r + 1] + acc[mi][ni][r + 1] + b) * 0.70710678118654752f));
+                        buf_store_u8(s8, voff >> 1, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID), pk);
+                        buf_store_u8(s8, voff >> 1, (uint32_t)((mi * 32 + acc_row_c(r + 1)) * FWN_HID), pk >> 8);
+                    }
+                }
             }
         }
     }
@@ -1027,7 +1046,7 @@ static void launch_ring(const Prob& p, int M, int N, int ksteps, hipStream_t st)
 }
 
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,
-                      void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st) {
+                      void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, void* h8out, hipStream_t st) {
     if (Ch >= 32 && W2 && scratch) {
         const long total = (long)M * Ch;
         const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
@@ -1038,6 +1057,7 @@ void fwn_launch_front(const float* xa, const float* an_a, const void* W, const v
     }
     FrontProb p{xa, an_a, (const bf16*)W, bias, (bf16*)hout, M, Ti, Ch, ilog2(Ch), kpad, apply_an};
     if (Ch <= 16) {
+        p.h8out = (unsigned char*)h8out;
         if (M >= 64 * 512) hipLaunchKernelGGL((front_valu_kernel<16>), dim3((M + 63) / 64), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((front_valu_kernel<4>), dim3((M + 15) / 16), dim3(256), 0, st, p);
         return;
@@ -1065,9 +1085,25 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
     launch_ring(p, M, 512, (768 + (ca ? kcpad : 0)) / 16, st);
 }
 
-void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M,
+int fwn_gate_fp8_ok(int M, int dil) { return dil <= FWN_HALO_MAXDIL && ((M + 255) / 256) * 4 >= 192; }
+
+void fwn_launch_gate_fp8(const void* h8, const void* ca, const void* Wd8, int wexp, const void* Wc, const float* bias, void* o,
+                         int M, int Ti, int dil, int cin, int kcpad, hipStream_t st) {
+    GateProb p{nullptr, (const bf16*)ca, nullptr, nullptr, (const bf16*)Wc, bias, (bf16*)o, M, Ti, dil, cin, kcpad};
+    p.h8 = (const unsigned char*)h8;
+    p.Wd8 = (const unsigned char*)Wd8;
+    p.sb = 127 - wexp;
+    const int t256 = (M + 255) / 256;
+    if (t256 * 2 >= 192)
+        hipLaunchKernelGGL((gate_halo_kernel<256, 256, GateProb, true>), dim3(t256 * 2), dim3(1024), 0, st, p, 2);
+    else
+        hipLaunchKernelGGL((gate_halo_kernel<256, 128, GateProb, true>), dim3(t256 * 4), dim3(1024), 0, st, p, 4);
+}
+
+void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M, void* h8out,
                     hipStream_t st) {
     ResProb p{(const bf16*)o, (const bf16*)hin, (const bf16*)W, bias, (bf16*)hout, M};
+    p.h8out = (unsigned char*)h8out;
     launch_ring(p, M, 256, 16, st);
 }
 

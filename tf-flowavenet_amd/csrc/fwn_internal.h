@@ -2,12 +2,18 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// h8out (may be NULL): also write the e4m3 copy of the output the fp8 gate reads (front: Ch <= 16 only)
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,
-                      void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, hipStream_t st);
+                      void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, void* h8out, hipStream_t st);
 void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc,
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, void* aux,
                      hipStream_t st);
-void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M,
+// the gate with its dilated taps in fp8 (h8 e4m3 [M][256], Wd8 e4m3 [512][768] stored as W 2^wexp); fwn_gate_fp8_ok says
+// whether this shape has such a kernel (the tap-sharing tiles: M >= 12288 rows, dilation <= 3, conditioning fused)
+int fwn_gate_fp8_ok(int M, int dil);
+void fwn_launch_gate_fp8(const void* h8, const void* ca, const void* Wd8, int wexp, const void* Wc, const float* bias, void* o,
+                         int M, int Ti, int dil, int cin, int kcpad, hipStream_t st);
+void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M, void* h8out,
                     hipStream_t st);
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
                      int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, hipStream_t st);
@@ -23,6 +29,10 @@ int fwn_tail_npartials(int M);   // log-det partial slots a tail launch writes
 void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st);
 void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,
                      int k_dst, int n_dst, long ld_dst, void* out, hipStream_t st);
+void fwn_launch_wn_absmax(const float* v, const float* scale, int k_src, int n_src, float mul, float* amax, hipStream_t st);
+void fwn_launch_pack_e4m3(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src, int k_dst,
+                          int n_dst, long ld_dst, float mul, const float* amax, void* out, int* exp_out, hipStream_t st);
+void fwn_launch_cast_e4m3(const void* src, void* dst, long n, hipStream_t st);
 void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, float bias, const float* bias_dev, int s,
                          float* out_f32, void* out_planes, hipStream_t st);
 void fwn_launch_split(const float* x, long B, long T, float* planes, hipStream_t st);

@@ -21,6 +21,9 @@ _COMMON = dict(
     batch_size=8, gin_channels=-1, n_speakers=7,
     causal=False, n_flow=6, n_layer=2, affine=True, causality=False,
     tf_random_seed=75, temp=0.7,
+    # not in the reference: run the dilated taps of the gated layers on the fp8 (e4m3) MFMA path where the shape has
+    # such a kernel (BASELINE configs[4]); inference only, log_p stays within the 1e-3 tolerance (tests/test_fp8.py)
+    gate_fp8=False,
 )
 
 _22K = dict(n_fft=1024, hop_size=256, sample_rate=22050, fmax=7600, max_time_steps=6400,

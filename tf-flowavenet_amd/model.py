@@ -25,7 +25,7 @@ from . import _lib, packing, weights
 
 
 class FloWaveNet:
-    def __init__(self, hparams, init=False, scope="FloWaveNet", device="cuda", cond_mode=0, group=None):
+    def __init__(self, hparams, init=False, scope="FloWaveNet", device="cuda", cond_mode=0, group=None, gate_fp8=None):
         """group: the ``torch.distributed`` process group a data-parallel job shards its batch over (None = the
         default group when one is initialised).  It only matters for ``init=True``: the ActNorm data-dependent
         init then uses the statistics of the GLOBAL batch (moments all-reduced flow by flow) so every rank ends
@@ -42,6 +42,8 @@ class FloWaveNet:
         self._device = device
         self._cond_mode = cond_mode
         self._group = group
+        # fp8 (e4m3) dilated taps where the shape has such a kernel (BASELINE configs[4]); default: hparams.gate_fp8
+        self._gate_fp8 = bool(getattr(hparams, "gate_fp8", False) if gate_fp8 is None else gate_fp8)
         self._packed = None
         self._ws = {}
         self._lib = _lib.load()     # fails loudly when libfwn.so is missing
@@ -60,7 +62,7 @@ class FloWaveNet:
             got = tuple(getattr(params[name], "shape", None) or np.shape(params[name]))
             if got != tuple(shape):
                 raise ValueError("parameter %r has shape %r, expected %r" % (name, got, tuple(shape)))
-        self._packed = packing.pack_model(params, self._hparams, self._device, self._cond_mode)
+        self._packed = packing.pack_model(params, self._hparams, self._device, self._cond_mode, gate_fp8=self._gate_fp8)
         return self
 
     def init_synthetic(self, seed=1234, **kw):

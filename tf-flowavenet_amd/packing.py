@@ -311,6 +311,7 @@ class PackedModel:
         self.device = device
         self.tensors = []        # keeps every device buffer alive
         self.an = {}             # (i, j) -> fp32 [2][4][Ch] tensor
+        self.wd8 = {}            # (flow index * L + layer) -> uint8 [512][768] e4m3 gate weights (gate_fp8 only)
         self.flow_descs = (_lib.FlowDesc * (hp.n_block * hp.n_flow))()
         self.model_desc = _lib.ModelDesc()
         self.weight_bytes = 0
@@ -320,7 +321,8 @@ class PackedModel:
         return t
 
 
-def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | None" = None) -> PackedModel:
+def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | None" = None,
+               gate_fp8: bool = False) -> PackedModel:
     """Upload ``params`` (reference layouts, fp32) and run the packing kernels (K10).
     With ``plan`` (params must then be device tensors at stable addresses) the work is recorded into it
     and executed once; ``plan.refresh()`` repeats it after the parameters changed."""
@@ -413,6 +415,34 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
     fg, gch = gate_row_channel()
     gate_rows = [dev_i32("gate_rows%d" % s, lambda s=s: np.where(fg == s, gch, -1)) for s in (0, 1)]
     scale_buf = torch.empty(FILTER, dtype=torch.float32, device=dev)
+    if gate_fp8 and plan is not None:
+        raise ValueError("the fp8 gate path is inference-only (no PackPlan)")
+    # fp8 gate path: per (flow, layer) one e4m3 copy of the gate-packed dilated conv weights + its power-of-two exponent
+    fp8_exp = torch.zeros(max(1, hp.n_block * hp.n_flow * L), dtype=torch.int32, device=dev) if gate_fp8 else None
+    fp8_amax = torch.zeros_like(fp8_exp, dtype=torch.float32) if gate_fp8 else None
+    fp8_scales = torch.empty(2, FILTER, dtype=torch.float32, device=dev) if gate_fp8 else None
+    fp8_slots = []
+
+    def pack_gate_fp8(rp, d, l, slot):
+        """Wd8 = e4m3(GATE_MUL * weight-normed (Conv_filter | Conv_gate) * 2^e), gate-packed rows like Wd."""
+        wd8 = pm.keep(torch.zeros(GATE_N, 3 * FILTER, dtype=torch.uint8, device=dev))
+        pm.weight_bytes += wd8.numel()
+        srcs = []
+        for s_, nm in enumerate(("/Conv_filter", "/Conv_gate")):
+            v = torch.as_tensor(params[rp + nm + "/kernel"]).to(device=dev, dtype=torch.float32).contiguous()
+            g = torch.as_tensor(params[rp + nm + "/g"]).to(device=dev, dtype=torch.float32).contiguous()
+            _lib.check(lib.fwn_wn_scale(v.data_ptr(), g.data_ptr(), 3 * FILTER, FILTER, fp8_scales[s_].data_ptr(), stream), "fwn_wn_scale")
+            _lib.check(lib.fwn_wn_absmax(v.data_ptr(), fp8_scales[s_].data_ptr(), 3 * FILTER, FILTER, GATE_MUL[s_],
+                                         fp8_amax[slot:].data_ptr(), stream), "fwn_wn_absmax")
+            srcs.append(v)
+        for s_, v in enumerate(srcs):
+            _lib.check(lib.fwn_pack_e4m3(v.data_ptr(), fp8_scales[s_].data_ptr(), ident768.data_ptr(), gate_rows[s_].data_ptr(), FILTER,
+                                         3 * FILTER, GATE_N, 3 * FILTER, GATE_MUL[s_], fp8_amax[slot:].data_ptr(), wd8.data_ptr(),
+                                         fp8_exp[slot:].data_ptr(), stream), "fwn_pack_e4m3")
+            v.record_stream(torch.cuda.current_stream(dev))
+        d.Wd8[l] = wd8.data_ptr()
+        pm.wd8[slot] = wd8
+        fp8_slots.append((d, l, slot))
 
     def pack(name, src_k, src_n, k_dst, n_dst, out, ld_dst, col_off=0, weight_norm=True, mul=None):
         """Pack params[name + '/kernel'] into out[:, col_off: col_off + k_dst]; ``mul`` scales every
@@ -502,6 +532,8 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                     return np.where(fg == 0, bsum[0][gch], bsum[1][gch])
                 d.Wd[l] = wd.data_ptr()
                 d.Wc[l] = wc.data_ptr()
+                if gate_fp8:
+                    pack_gate_fp8(rp, d, l, (i * hp.n_flow + j) * L + l)
                 put(lambda v, d=d, l=l: d.bgate.__setitem__(l, v.data_ptr()), gate_bias,
                     dict(terms=[(rp + "/Conv_filter/bias", np.where(fg == 0, gch, -1)), (rp + "/filter_conv_c/bias", np.where(fg == 0, gch, -1)),
                                 (rp + "/Conv_gate/bias", np.where(fg == 0, -1, gch)), (rp + "/gate_conv_c/bias", np.where(fg == 0, -1, gch))],
@@ -571,5 +603,11 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
         pm.plan = plan
     md.flows = C.cast(pm.flow_descs, C.POINTER(_lib.FlowDesc))
     md.cond_mode = int(cond_mode)
+    md.gate_fp8 = 1 if gate_fp8 else 0
     torch.cuda.current_stream(dev).synchronize()
+    if gate_fp8:                                   # the exponents the pack kernels chose, in one copy
+        exps = fp8_exp.cpu().numpy()
+        for d, l, slot in fp8_slots:
+            d.wd8_exp[l] = int(exps[slot])
+        pm.fp8_exponents = exps
     return pm
