@@ -240,6 +240,9 @@ struct GateProb {
     const unsigned char* h8 = nullptr;    // [M][256]
     const unsigned char* Wd8 = nullptr;   // [512][768]
     int sb = 127;                         // E8M0 scale operand of the weights: 127 - e
+#ifdef FWN_STAMP
+    unsigned long long* stamps = nullptr; // diagnostic build only: [2 workgroups][16 waves][24 steps][4] s_memtime stamps
+#endif
     typedef RowCtxT RowCtx;
     struct ChunkCtx { int cond, acol, bcol, shift, kvalid; };
     template <int BK> __device__ int nchunks() const { return (3 * FWN_HID + (ca ? kcpad : 0)) / BK; }

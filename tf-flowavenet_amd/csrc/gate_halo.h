@@ -45,7 +45,15 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
     static_assert(AP * 8 > BM + 2 * FWN_HALO_MAXDIL, "the zero row must lie beyond the halo");
     constexpr int A_BYTES = AP * 1024, B_BYTES = BN * G::RB;
     constexpr int ZROW = AP * 8 - 1;                         // never staged: reads as zero
+#ifdef FWN_STAMP      // diagnostic build (tools/bench_gemm.hip): s_memtime stamps per wave and step, dumped to p.stamps
+    constexpr int STAMP_BYTES = 16 * 24 * 4 * 8;            // 16 waves x 24 steps x 4 stamps
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * A_BYTES + 2 * B_BYTES + STAMP_BYTES];
+    unsigned long long* const stamp = (unsigned long long*)(lds + 2 * A_BYTES + 2 * B_BYTES);
+#define FWN_STAMP_AT(step, k) do { if ((threadIdx.x & 63) == 0) stamp[((threadIdx.x >> 6) * 24 + (step)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FWN_STAMP_AT(step, k) do { } while (0)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * A_BYTES + 2 * B_BYTES];
+#endif
     unsigned char* const ldsA = lds;
     unsigned char* const ldsB = lds + 2 * A_BYTES;
 
@@ -231,9 +239,12 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
             // (tap 1, 2 of this slice; none when that step issued nothing or this step opens a slice)
             const bool a_next_conv = kc + 1 < NSL, a_next_cond = kc + 1 == NSL && ncond > 0;
             const bool prev_a = tap > 0 && (a_next_conv || (a_next_cond && tap - 1 < 2)) && (tap - 1 < 2 || wave == 0);
+            FWN_STAMP_AT(s, 0);
             if (prev_a) FWN_WAIT_VMCNT(1);
             else FWN_WAIT_VMCNT(0);
+            FWN_STAMP_AT(s, 1);
             __builtin_amdgcn_s_barrier();
+            FWN_STAMP_AT(s, 2);
             const unsigned char* lb = ldsB + (s & 1) * B_BYTES;
             auto hooks = [&](int ki) {
                 if (ki < PB && s + 1 < S) issueB(s + 1, ki);
@@ -244,6 +255,7 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
             };
             if constexpr (FP8) mma_step8(la, lb, rb[tap][0], rb[tap][MI - 1], xv[tap] ^ (lh << 4), hooks);   // xv = (lh ^ swizzle) << 4
             else mma_step(la, lb, rb[tap][0], rb[tap][MI - 1], xv[tap], 4, hooks);
+            FWN_STAMP_AT(s, 3);
         }
     }
     if constexpr (FP8) {
@@ -270,6 +282,13 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
             }
         });
     }
+#ifdef FWN_STAMP
+    FWN_STAMP_AT(20, 0);                                  // end of the K loop
+    if (p.stamps && blockIdx.x < 2) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * 24 * 4; i += blockDim.x) p.stamps[blockIdx.x * 16 * 24 * 4 + i] = stamp[i];
+    }
+#endif
     if (FWN_HABL == 4) {
         float sacc = 0.0f;
 #pragma unroll
