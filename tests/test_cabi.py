@@ -133,3 +133,32 @@ def test_training_primitives_validate_their_arguments(lib):
     assert b"power of two" in lib.fwn_last_error()
     assert lib.fwn_pack_jobs(None, 1, None, 0, None, 512, None) == -1
     assert lib.fwn_colsum_partials(1000, 8) > 0 and lib.fwn_upsample_bwd_partials(8, 25, 16) > 0
+
+
+def test_build_keeps_slp_vectorisation_off_and_the_valu_front_conv_free_of_swizzled_packed_math():
+    """ADVICE r1 / DESIGN 3.5: hipcc's SLP pass turned the scalar fp32 code of front_valu_kernel into v_pk_mul_f32 /
+    v_pk_add_f32 with op_sel swizzles, which returned wrong lanes whenever another kernel shared the CU.  The build
+    must carry -fno-slp-vectorize, and the shipped code object must not contain packed fp32 math in that kernel."""
+    import re
+    import shutil
+    import subprocess
+    mk = open(os.path.join(ROOT, "tf-flowavenet_amd", "csrc", "Makefile")).read()
+    flags = [ln for ln in mk.splitlines() if ln.startswith("CXXFLAGS")]
+    assert flags and "-fno-slp-vectorize" in flags[0]
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    import glob
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "libfwn.so")
+        shutil.copy(_lib.LIB_PATH, so)
+        subprocess.run([objdump, "--offloading", so], check=True, capture_output=True, cwd=tmp)     # extracts the code objects
+        dis = ""
+        for co in sorted(glob.glob(so + ".*gfx950")):
+            dis += subprocess.run([objdump, "-d", co], capture_output=True, text=True, check=True).stdout
+    blocks = re.split(r"\n(?=[0-9a-f]+ <)", dis)
+    front = [b for b in blocks if "front_valu_kernel" in b.split("\n", 1)[0]]
+    assert front, "front_valu_kernel not found in the code object"
+    for b in front:
+        assert "v_pk_mul_f32" not in b and "v_pk_add_f32" not in b and "v_pk_fma_f32" not in b

@@ -183,3 +183,20 @@ def test_8khz_model_with_fp8_gates_matches_golden():
     wav = model.reverse(torch.from_numpy(inp["z"]).cuda(), c).cpu().numpy()
     dw = np.abs(wav - g["x_rev"].astype(np.float32))
     assert dw.max() < 5e-2 and dw.mean() < 4e-3, (dw.max(), dw.mean())
+
+
+def test_fp8_passes_on_concurrent_streams_reproduce_the_serial_result(fp8_model):
+    """The fp8 kernels beside each other and beside the bf16 ones on four HIP streams (bench.py's lanes): every
+    overlapped pass equals the one-stream pass bit for bit."""
+    hp, model, x, c, z, _ = fp8_model
+    ref_wav = model.reverse(z, c).clone()
+    ref_nll = torch.stack(model.forward(x, c)).clone()
+    torch.cuda.synchronize()
+    lanes = [torch.cuda.Stream() for _ in range(4)]
+    outs = []
+    for k in range(12):
+        with torch.cuda.stream(lanes[k % 4]):
+            outs.append(("inv", model.reverse(z, c).clone()) if k % 2 else ("fwd", torch.stack(model.forward(x, c)).clone()))
+    torch.cuda.synchronize()
+    for kind, got in outs:
+        assert torch.equal(got, ref_wav if kind == "inv" else ref_nll), kind
