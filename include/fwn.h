@@ -347,6 +347,53 @@ int fwn_model_forward_init(const fwn_model_desc* m, int64_t B, int64_t T, const 
 int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float* z, const float* mel,
                       void* workspace, size_t workspace_bytes, float* x_out, void* stream);
 
+/* ---- training: loss = -(log_p + logdet) (train.py:56-60) and its gradient with respect to every trainable tensor
+ * (the one tf.gradients call of train.py:63-66) for one batch, in ONE call: training forward with what the backward
+ * needs kept per flow, then the flows in reverse (coupling, ZeroConv / final / skip / res, the gated layers with their
+ * dilated transposed convs, the conditioning gradient, the front conv, ActNorm), then the up-sampling convs.  The
+ * descriptors hold device pointers to (a) the inference packing of the parameters (fwn_model_desc, conditioning fused:
+ * cond_mode 1), (b) the natural-order / transposed bf16 copies the backward GEMMs read, (c) the fp32 masters in the
+ * reference's layouts and (d) where each gradient goes (e.g. views of one flat buffer that an RCCL all-reduce sums).
+ * Everything else lives in `workspace`.  on_block_done(user, i) is called on the host once every launch that writes
+ * block i's gradients has been enqueued (blocks finish last to first; -1 = the up-sampling convs): the hook a
+ * data-parallel step uses to start that block's all-reduce under the rest of the backward pass, or to cut a graph. */
+typedef struct fwn_conv_grad {          /* one trainable convolution */
+    const float* V; const float* g;     /* kernel [K][N] fp32 (reference layout, K = kernel_size * C_in), weight-norm g [N] or NULL */
+    float* dV; float* dg; float* db;    /* gradients of kernel, g (NULL iff g NULL) and bias */
+} fwn_conv_grad;
+typedef struct fwn_flow_train_desc {
+    const void* WfT;                            /* [Ch][768]   front conv, transposed: K = tap*256 + n          */
+    const void* WdT[FWN_MAX_LAYERS];            /* [256][1536] dilated filter|gate, K = tap*512 + (f|g)*256 + n */
+    const void* WcT[FWN_MAX_LAYERS];            /* [cin][512]  conditioning filter|gate                         */
+    const void* WresT[FWN_MAX_LAYERS];          /* [256][256]  layers 0..L-2                                    */
+    const void* Wskip;  const void* WskipT_all; /* [256][L*256], [L*256][256]                                   */
+    const void* Wfin;   const void* WfinT;      /* [256][256] natural K order, and transposed                   */
+    const void* Wz;     const void* WzT;        /* [2Ch][256] rows in plane order, [256][ldz]                   */
+    const float* bskip; const float* bfin; const float* bz; const float* ez;    /* tables in device channel order */
+    int32_t ldz, reserved;                      /* max(8, 2Ch)                                                  */
+    fwn_conv_grad front, final_, zero;          /* Conv_front, Conv_final, ZeroConv1d (g = NULL)                */
+    fwn_conv_grad filt[FWN_MAX_LAYERS], gate[FWN_MAX_LAYERS], res[FWN_MAX_LAYERS], skip[FWN_MAX_LAYERS],
+        filt_c[FWN_MAX_LAYERS], gate_c[FWN_MAX_LAYERS];
+    float* d_an_b; float* d_an_logs; float* d_zscale;    /* [2Ch] each, the parameters' order                  */
+} fwn_flow_train_desc;
+typedef struct fwn_train_desc {
+    const fwn_model_desc* model;                /* inference packing of the same parameters                     */
+    const fwn_flow_train_desc* flows;           /* HOST array [n_block * n_flow]                                */
+    /* per block (device): logical row of a weight gradient -> row of the GEMM that computed it; channel maps   */
+    const int32_t* cond_rows[16]; const int32_t* front_rows[16]; const int32_t* zinv32[16];
+    const int64_t* br[16]; const int64_t* zcol[16];
+    const float* up_bias_dev[FWN_MAX_UPSAMPLE]; /* the bias masters (device scalars)                            */
+    fwn_conv_grad up[FWN_MAX_UPSAMPLE];         /* V [2s][3], scalar g; dV, dg, db (bias)                       */
+    const float* an_logdet;                     /* device scalar: sum over flows of mean_C(3 logs) (model.py:80) */
+    int32_t zero_dead_res, reserved;            /* != 0: also zero the gradients of the dead last-layer res_conv */
+} fwn_train_desc;
+typedef void (*fwn_block_done_fn)(void* user, int block);
+size_t fwn_train_workspace_bytes(const fwn_train_desc* t, int64_t B, int64_t T);
+/* x [B][T] fp32, mel [B][T/hop][num_mels] fp32 -> out3 = (loss, log_p, logdet) fp32 on device + every gradient. */
+int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B, int64_t T, const float* x, const float* mel,
+                             void* workspace, size_t workspace_bytes, float* out3, fwn_block_done_fn on_block_done,
+                             void* user, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

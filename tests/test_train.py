@@ -166,6 +166,44 @@ def test_full_width_model_gradients_match_autograd_oracle(n_block, b, t):
     assert dot / np.sqrt(na * nb_) > 0.9999
 
 
+@pytest.mark.parametrize("cfg,b,t", [
+    (dict(n_block=2, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=8), 2, 128),
+    (dict(n_block=4, n_flow=2, n_layer=3, hop_size=32, upsample_scales=[4, 8], num_mels=16), 2, 512),
+    (dict(n_block=4, n_flow=2, n_layer=4, hop_size=16, upsample_scales=[4, 4], num_mels=16), 2, 512),     # two job groups per flow
+    ("full6", 2, 1024),                                                                                   # real widths, Ch = 32 front, hoisted cond
+])
+def test_the_c_sequenced_step_reproduces_the_python_sequenced_reference_bit_for_bit(cfg, b, t):
+    """fwn_train_loss_and_grads (csrc/train_api.hip: one C call per batch) against the same stage kernels sequenced from
+    Python (tests/dev/py_sequencing.py, the previous product path): loss, log_p, logdet and every gradient tensor are
+    identical in every bit - the C entry point changes who sequences the launches, not the arithmetic."""
+    import importlib.util, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.hparams import default_hparams
+    from tf_flowavenet_amd.training import GradEngine
+    spec = importlib.util.spec_from_file_location("py_sequencing", os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev", "py_sequencing.py"))
+    ref_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_mod)
+    hp = default_hparams().replace(n_block=6) if cfg == "full6" else small_hparams(**cfg)
+    p = W.synthetic_params(hp, 21, actnorm="random")
+    inp = W.synthetic_inputs(hp, b, t)
+    x, c = torch.from_numpy(inp["x"]).reshape(b, t).cuda(), torch.from_numpy(inp["c"]).cuda()
+    eng = GradEngine(hp)
+    loss, lp, ld, g = eng.loss_and_grads(p, x, c)
+    loss, lp, ld = float(loss), float(lp), float(ld)
+    g = {k: v.clone() for k, v in g.items()}
+    l0, lp0, ld0, g0 = ref_mod.loss_and_grads(eng, eng._tp, p, x, c)
+    assert (loss, lp, ld) == (float(l0), float(lp0), float(ld0))
+    assert sorted(g) == sorted(g0)
+    for k in g0:
+        a, r = g[k].reshape(-1), g0[k].reshape(-1)
+        if k.startswith("upsample_") and k.endswith("/g"):      # a 3-term sum: torch's reduction order is its own
+            assert torch.allclose(a, r, rtol=1e-6, atol=0), k
+        else:
+            assert torch.equal(a, r), k
+
+
 def test_gradient_is_reproducible_bit_for_bit():
     cfg = dict(n_block=2, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=8)
     _, _, _, (l1, _, _, g1) = _grad_case(cfg, 2, 128, 7)

@@ -49,6 +49,31 @@ class ModelDesc(C.Structure):
 
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)      # fwn_reduce_fn(user, buf, n, stream)
+BLOCK_DONE_FN = C.CFUNCTYPE(None, vp, C.c_int)             # fwn_block_done_fn(user, block)
+
+
+class ConvGrad(C.Structure):
+    """fwn_conv_grad (include/fwn.h)."""
+    _fields_ = [("V", vp), ("g", vp), ("dV", vp), ("dg", vp), ("db", vp)]
+
+
+class FlowTrainDesc(C.Structure):
+    """fwn_flow_train_desc (include/fwn.h)."""
+    _fields_ = [("WfT", vp), ("WdT", vp * FWN_MAX_LAYERS), ("WcT", vp * FWN_MAX_LAYERS), ("WresT", vp * FWN_MAX_LAYERS),
+                ("Wskip", vp), ("WskipT_all", vp), ("Wfin", vp), ("WfinT", vp), ("Wz", vp), ("WzT", vp),
+                ("bskip", vp), ("bfin", vp), ("bz", vp), ("ez", vp), ("ldz", i32), ("reserved", i32),
+                ("front", ConvGrad), ("final_", ConvGrad), ("zero", ConvGrad),
+                ("filt", ConvGrad * FWN_MAX_LAYERS), ("gate", ConvGrad * FWN_MAX_LAYERS), ("res", ConvGrad * FWN_MAX_LAYERS),
+                ("skip", ConvGrad * FWN_MAX_LAYERS), ("filt_c", ConvGrad * FWN_MAX_LAYERS), ("gate_c", ConvGrad * FWN_MAX_LAYERS),
+                ("d_an_b", vp), ("d_an_logs", vp), ("d_zscale", vp)]
+
+
+class TrainDesc(C.Structure):
+    """fwn_train_desc (include/fwn.h)."""
+    _fields_ = [("model", C.POINTER(ModelDesc)), ("flows", C.POINTER(FlowTrainDesc)),
+                ("cond_rows", vp * 16), ("front_rows", vp * 16), ("zinv32", vp * 16), ("br", vp * 16), ("zcol", vp * 16),
+                ("up_bias_dev", vp * FWN_MAX_UPSAMPLE), ("up", ConvGrad * FWN_MAX_UPSAMPLE),
+                ("an_logdet", vp), ("zero_dead_res", i32), ("reserved", i32)]
 
 
 # name -> (restype, argtypes); every symbol include/fwn.h declares.
@@ -165,6 +190,8 @@ SIGNATURES = {
     "fwn_model_forward": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp,
                                     C.c_int, vp]),
     "fwn_model_forward_init": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp, vp, vp, vp]),
+    "fwn_train_workspace_bytes": (C.c_size_t, [C.POINTER(TrainDesc), i64, i64]),
+    "fwn_train_loss_and_grads": (C.c_int, [C.POINTER(TrainDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, BLOCK_DONE_FN, vp, vp]),
     "fwn_model_reverse": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp]),
 }
 

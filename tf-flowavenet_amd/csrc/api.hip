@@ -18,6 +18,14 @@ static int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+// the same for the other translation units of the library (train_api.hip)
+int fwn_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
 static int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(FWN_ERR_HIP, "%s: %s", what, hipGetErrorString(e));

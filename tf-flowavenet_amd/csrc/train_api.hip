@@ -1,0 +1,560 @@
+// fwn_train_loss_and_grads: loss = -(log_p + logdet) (train.py:56-60) and its gradient with respect to every trainable
+// tensor of the reference (train.py:63-66, one tf.gradients call there) for one batch, sequenced here - training forward
+// with everything the backward needs kept per flow, then the flows in reverse - over the stage kernels of
+// flow_kernels.hip / train_kernels.hip.  No allocation, no synchronisation: every buffer is carved from the caller's
+// workspace (fwn_train_workspace_bytes), every launch goes to `stream`, so a caller may record the whole call into a
+// hipGraph.  DESIGN.md section 8 describes the arithmetic; the host side (tf-flowavenet_amd/training.py) only builds the
+// descriptors.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fwn.h"
+#include "common.h"
+#include "fwn_internal.h"
+
+int fwn_set_error(int code, const char* fmt, ...);      // api.hip: thread-local message of fwn_last_error()
+#define TREQUIRE(cond, ...) do { if (!(cond)) return fwn_set_error(FWN_ERR_ARG, __VA_ARGS__); } while (0)
+
+namespace {
+
+constexpr float SQH = 0.70710678118654752440f;          // sqrt(1/2), modules.py:128
+
+// ---- small kernels that replace the host-framework tensor ops of the Python sequencing -----------------------------
+__global__ __launch_bounds__(256) void scale_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, float s) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (src[i] + 0.0f) * s;
+}
+__global__ __launch_bounds__(256) void cast_bf16_kernel(bf16* __restrict__ dst, const float* __restrict__ src, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (bf16)src[i];
+}
+// mel planes [2][B][T][half] -> rows [B][T][2 half]: the gradient image (fp32) and the up-sampled conditioning (bf16 -> fp32)
+__global__ __launch_bounds__(256) void planes_to_rows_kernel(const float* __restrict__ dplanes, const bf16* __restrict__ cplanes,
+                                                             long BT, int half, float* __restrict__ dy, float* __restrict__ y) {
+    const long total = BT * 2 * half;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long bt = i / (2 * half);
+        const int w = (int)(i - bt * 2 * half), q = w / half, c = w - q * half;
+        const long src = ((long)q * BT + bt) * half + c;
+        dy[i] = dplanes[src];
+        y[i] = (float)cplanes[src];
+    }
+}
+__global__ void up_prepare_kernel(const float* __restrict__ g, float* __restrict__ g3) {
+    if (threadIdx.x < 3) g3[threadIdx.x] = g[0];        // the three kw columns share one scalar g (convolutional.py:186)
+}
+__global__ void up_finish_kernel(const float* __restrict__ dg3, const float* __restrict__ dwb, int s, float* __restrict__ dg,
+                                 float* __restrict__ dbias) {
+    if (threadIdx.x == 0) {
+        dg[0] = (dg3[0] + dg3[1]) + dg3[2];
+        dbias[0] = dwb[6 * s];
+    }
+}
+__global__ void finish_loss_kernel(const float* __restrict__ out2, const float* __restrict__ an_logdet, float* __restrict__ out3) {
+    if (threadIdx.x == 0) {
+        const float log_p = out2[0], logdet = out2[1] + an_logdet[0];
+        out3[0] = -(log_p + logdet);
+        out3[1] = log_p;
+        out3[2] = logdet;
+    }
+}
+inline unsigned grid_of(long n) { long b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+// ---- workspace carving (the same walk sizes the workspace and hands out the pointers) ------------------------------
+struct Bump {
+    char* base;
+    size_t off = 0;
+    explicit Bump(void* b) : base((char*)b) {}
+    void* take(size_t bytes) {
+        void* p = base ? base + off : nullptr;
+        off = (off + bytes + 255) & ~(size_t)255;
+        return p;
+    }
+};
+inline long roundup(long v, long m) { return (v + m - 1) / m * m; }
+inline int dilation_of(int layer) { int d = 1; for (int i = 0; i < layer; ++i) d *= 3; return d; }
+inline int hop_of(const fwn_model_desc* m) { int h = 1; for (int i = 0; i < m->n_up; ++i) h *= m->up_scale[i]; return h; }
+
+struct TnSpec { int kx, n, ntap; };
+inline int tn_group_splits(const TnSpec* sp, int n, int m) {          // training.tn_group_splits
+    const int e = fwn_tn_tile(m);
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (long)sp[i].ntap * ((sp[i].kx + e - 1) / e) * ((sp[i].n + e - 1) / e);
+    const long a = (m + 63) / 64, b = 256 / (tiles > 1 ? tiles : 1);
+    const long r = a < b ? a : b;
+    return (int)(r < 1 ? 1 : r);
+}
+
+struct FlowSaved {          // what the training forward keeps of one flow
+    void* h[FWN_MAX_LAYERS]; void* o[FWN_MAX_LAYERS]; void* aux[FWN_MAX_LAYERS];
+    void* s_act; void* u_act; float* z; float* part; int nb, p;
+};
+
+struct Plan {               // every buffer of one call
+    void* cplanes; float* ups[FWN_MAX_UPSAMPLE]; float* planes; float* gplanes; float* dcplanes; float* P;
+    float* partial_all; float* out2; float* an_dummy;
+    FlowSaved* saved;       // host array, owned by the caller of plan()
+    // backward temporaries, sized for the largest block and reused flow after flow
+    void* dz; float* dzz; void* du; void* ds; void* d_all; void* d_o[FWN_MAX_LAYERS]; void* dpre[FWN_MAX_LAYERS];
+    void* dh[FWN_MAX_LAYERS]; void* ya_bf; float* tn_part; double* wn_scratch; double* sg_scratch;
+    void* dyt; void* xt; float* fr_part;
+    float* up_dy; float* up_y; float* up_dx[2]; float* up_dwb; float* up_scr; float* up_g3; float* up_dv; float* up_dg3;
+    size_t total;
+    int npart;
+};
+
+// Number of fp32 elements of the grouped weight-gradient partials of one flow at block i (both groups of > 16 jobs included).
+long tn_partial_floats(const fwn_model_desc* md, int i, long m) {
+    const int ch = 1 << i, L = md->n_layer, half = md->num_mels / 2, cin = half * (2 << i);
+    const int ldz = 2 * ch > 8 ? 2 * ch : 8;
+    TnSpec sp[4 + 5 * FWN_MAX_LAYERS];
+    int n = 0;
+    sp[n++] = {256, ldz, 1};
+    sp[n++] = {256, 256, 1};
+    for (int l = 0; l < L; ++l) sp[n++] = {256, 256, 1};
+    for (int l = L - 1; l >= 0; --l) {
+        if (l < L - 1) sp[n++] = {256, 256, 1};
+        sp[n++] = {256, 512, 3};
+        sp[n++] = {cin, 512, 1};
+    }
+    if (ch % 8 == 0) sp[n++] = {ch, 256, 3};
+    long tot = 0;
+    for (int g0 = 0; g0 < n; g0 += FWN_MAX_GROUP) {
+        const int cnt = n - g0 < FWN_MAX_GROUP ? n - g0 : FWN_MAX_GROUP;
+        const int ns = tn_group_splits(sp + g0, cnt, (int)m);
+        for (int j = g0; j < g0 + cnt; ++j) tot += (long)ns * ((long)sp[j].ntap * sp[j].kx + 1) * sp[j].n;
+    }
+    return tot;
+}
+
+int front_small_nsplit(long mp, int rows1) {      // training.weight_grad_partials, the branch rows + 1 < 512
+    const long nchunks = mp / 64, n128 = 2;
+    const long b = (256 + (((rows1 + 63) / 64) * n128) - 1) / (((rows1 + 63) / 64) * n128);
+    const long r = nchunks < b ? nchunks : b;
+    return (int)(r < 1 ? 1 : r);
+}
+
+void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
+    const fwn_model_desc* md = t->model;
+    const int L = md->n_layer, half = md->num_mels / 2, nmel = 2 * half;
+    Bump b(ws);
+    pl.cplanes = b.take((size_t)2 * B * T * half * 2);
+    long H = T / hop_of(md);
+    for (int n = 0; n < md->n_up; ++n) {
+        H *= md->up_scale[n];
+        pl.ups[n] = n + 1 < md->n_up ? (float*)b.take((size_t)B * H * nmel * 4) : nullptr;      // output of stage n (fp32), except the last
+    }
+    pl.planes = (float*)b.take((size_t)B * T * 4);
+    pl.gplanes = (float*)b.take((size_t)B * T * 4);
+    pl.dcplanes = (float*)b.take((size_t)2 * B * T * half * 4);
+    size_t pbytes = 0;
+    int npart = 0;
+    long mmax = B * T / 2;
+    for (int i = 0; i < md->n_block; ++i) {
+        const long ch = 1L << i, m = B * T / (2 * ch);
+        if (m < 4096) { const size_t need = (size_t)md->n_flow * L * m * 512 * 4; if (need > pbytes) pbytes = need; }
+        for (int j = 0; j < md->n_flow; ++j) {
+            FlowSaved& s = pl.saved[i * md->n_flow + j];
+            for (int l = 0; l < L; ++l) {
+                s.h[l] = b.take((size_t)m * 256 * 2);
+                s.o[l] = b.take((size_t)m * 256 * 2);
+                s.aux[l] = b.take((size_t)m * 512 * 2);
+            }
+            s.s_act = b.take((size_t)m * 256 * 2);
+            s.u_act = b.take((size_t)m * 256 * 2);
+            s.z = (float*)b.take((size_t)m * 2 * ch * 4);
+            long nb = m * ch / 1024;
+            s.nb = (int)(nb < 1 ? 1 : nb > 256 ? 256 : nb);
+            npart += s.nb;
+        }
+    }
+    pl.P = (float*)b.take(pbytes);
+    pl.partial_all = (float*)b.take((size_t)npart * 4);
+    pl.npart = npart;
+    {   // partial slices in flow order
+        int off = 0;
+        for (int f = 0; f < md->n_block * md->n_flow; ++f) { pl.saved[f].part = pl.partial_all ? pl.partial_all + off : nullptr; off += pl.saved[f].nb; }
+    }
+    pl.out2 = (float*)b.take(16);
+    // backward temporaries: maxima over the blocks
+    size_t dz_b = 0, dzz_b = 0, ya_b = 0, tn_b = 0, wn_b = 0, sg_b = 0, dyt_b = 0, xt_b = 0, fr_b = 0;
+    for (int i = 0; i < md->n_block; ++i) {
+        const long ch = 1L << i, m = B * T / (2 * ch), cin = (long)half * (2 << i);
+        const long ldz = 2 * ch > 8 ? 2 * ch : 8;
+        dz_b = dz_b > (size_t)m * ldz * 2 ? dz_b : (size_t)m * ldz * 2;
+        dzz_b = dzz_b > (size_t)m * 2 * ch * 4 ? dzz_b : (size_t)m * 2 * ch * 4;
+        ya_b = ya_b > (size_t)m * ch * 2 ? ya_b : (size_t)m * ch * 2;
+        const size_t tnb = (size_t)tn_partial_floats(md, i, m) * 4;
+        tn_b = tn_b > tnb ? tn_b : tnb;
+        // weight-norm scratch of a group of <= 16 jobs: bounded by the 16 largest jobs (K/32 + 1) N 2 doubles; the
+        // conditioning convs dominate: (cin/32 + 1) 256 2 each; take all jobs of the flow as the bound
+        size_t wn = 0;
+        wn += (size_t)(256 / 32 + 1) * 256 * 2 * (1 + 2 * L);                         // final, skip, res
+        wn += (size_t)(768 / 32 + 1) * 256 * 2 * 2 * L;                               // filter, gate
+        wn += (size_t)(cin / 32 + 2) * 256 * 2 * 2 * L;                               // filter_c, gate_c
+        wn += (size_t)(3 * ch / 32 + 2) * 256 * 2 + 64;                               // front
+        wn_b = wn_b > wn * 8 ? wn_b : wn * 8;
+        const size_t sg = (size_t)fwn_small_grads_blocks(m, (int)ch) * 6 * ch * 8;
+        sg_b = sg_b > sg ? sg_b : sg;
+        if (ch % 8) {
+            const long mp = roundup(m, 64), rows1 = 3 * ch + 1;
+            dyt_b = dyt_b > (size_t)256 * mp * 2 ? dyt_b : (size_t)256 * mp * 2;
+            xt_b = xt_b > (size_t)rows1 * mp * 2 ? xt_b : (size_t)rows1 * mp * 2;
+            const size_t fr = (size_t)front_small_nsplit(mp, (int)rows1) * rows1 * 256 * 4;
+            fr_b = fr_b > fr ? fr_b : fr;
+        }
+    }
+    pl.dz = b.take(dz_b);
+    pl.dzz = (float*)b.take(dzz_b);
+    pl.du = b.take((size_t)mmax * 256 * 2);
+    pl.ds = b.take((size_t)mmax * 256 * 2);
+    pl.d_all = b.take((size_t)mmax * L * 256 * 2);
+    for (int l = 0; l < L; ++l) {
+        pl.d_o[l] = b.take((size_t)mmax * 256 * 2);
+        pl.dpre[l] = b.take((size_t)mmax * 512 * 2);
+        pl.dh[l] = b.take((size_t)mmax * 256 * 2);
+    }
+    pl.ya_bf = b.take(ya_b);
+    pl.tn_part = (float*)b.take(tn_b);
+    pl.wn_scratch = (double*)b.take(wn_b);
+    pl.sg_scratch = (double*)b.take(sg_b);
+    pl.dyt = b.take(dyt_b);
+    pl.xt = b.take(xt_b);
+    pl.fr_part = (float*)b.take(fr_b);
+    // up-sampling backward
+    pl.up_dy = (float*)b.take((size_t)B * T * nmel * 4);
+    pl.up_y = (float*)b.take((size_t)B * T * nmel * 4);
+    long Hs = T;
+    int smax = 2;
+    for (int n = 0; n < md->n_up; ++n) smax = md->up_scale[n] > smax ? md->up_scale[n] : smax;
+    for (int k = 0; k < 2; ++k) { pl.up_dx[k] = (float*)b.take((size_t)B * (T / md->up_scale[md->n_up - 1]) * nmel * 4); (void)Hs; }
+    pl.up_dwb = (float*)b.take((size_t)(6 * smax + 1) * 4);
+    pl.up_scr = (float*)b.take((size_t)64 * (6 * smax + 1) * 4);
+    pl.up_g3 = (float*)b.take(16);
+    pl.up_dv = (float*)b.take((size_t)2 * smax * 3 * 4);
+    pl.up_dg3 = (float*)b.take(16);
+    pl.total = b.off;
+}
+
+// ---- fwn_gemm descriptors (the keyword arguments of training.gemm) ---------------------------------------------------
+struct Seg { const void* x; long rows; int ld, k, shift, koff; };
+fwn_gemm_desc gemm_desc(const Seg* segs, int nseg, const void* W, int ldw, int N, long M, int Ti, void* Y, int ldy, bool out_f32) {
+    fwn_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    for (int s = 0; s < nseg; ++s) {
+        d.seg[s].x = segs[s].x; d.seg[s].rows = (int)segs[s].rows; d.seg[s].ld = segs[s].ld; d.seg[s].k = segs[s].k;
+        d.seg[s].shift = segs[s].shift; d.seg[s].koff = segs[s].koff;
+    }
+    d.nseg = nseg; d.M = (int)M; d.N = N; d.Ti = Ti;
+    d.W = W; d.ldw = ldw;
+    d.Y = Y; d.ldy = ldy; d.out_f32 = out_f32 ? 1 : 0;
+    d.nsplit = 1; d.oscale = 1.0f;
+    return d;
+}
+
+struct TnList {
+    fwn_tn_job job[4 + 5 * FWN_MAX_LAYERS];
+    int n = 0;
+    int add(const void* x, int ldx, const void* dy, int ldy, int kx, int N, int ntap, int shift0, int dshift) {
+        fwn_tn_job& q = job[n];
+        memset(&q, 0, sizeof(q));
+        q.x = x; q.dy = dy; q.ldx = ldx; q.Kx = kx; q.ntap = ntap; q.shift0 = shift0; q.dshift = dshift; q.ldy = ldy; q.N = N; q.bias_row = 1;
+        return n++;
+    }
+};
+struct WnItem { int tn; const float* part_direct; int part_nsplit; long part_stride; int part_rows, part_ld;   // tn < 0: part_direct
+                 const fwn_conv_grad* c; int k, n, col0; float scale; const int32_t* row_src; const int32_t* col_src; };
+
+}  // namespace
+
+extern "C" {
+
+size_t fwn_train_workspace_bytes(const fwn_train_desc* t, int64_t B, int64_t T) {
+    if (!t || !t->model || !t->flows || B <= 0 || T <= 0) return 0;
+    const fwn_model_desc* md = t->model;
+    if (md->n_block < 1 || md->n_block > 16 || md->n_flow < 1 || md->n_layer < 1 || md->n_layer > FWN_MAX_LAYERS) return 0;
+    if (T % hop_of(md) || T % (1L << md->n_block)) return 0;
+    if (md->n_block * md->n_flow > 256) return 0;
+    FlowSaved saved[256];
+    Plan pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.saved = saved;
+    plan(t, (long)B, (long)T, nullptr, pl);
+    return pl.total;
+}
+
+int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, const float* x, const float* mel, void* workspace,
+                             size_t workspace_bytes, float* out3, fwn_block_done_fn on_block_done, void* user, void* stream) {
+    TREQUIRE(t && t->model && t->flows && t->model->flows, "fwn_train_loss_and_grads: null descriptor");
+    TREQUIRE(x && mel && workspace && out3, "fwn_train_loss_and_grads: null pointer");
+    TREQUIRE((((uintptr_t)workspace) & 255) == 0, "fwn_train_loss_and_grads: workspace must be 256-byte aligned");
+    const fwn_model_desc* md = t->model;
+    const long B = (long)B_, T = (long)T_;
+    const int L = md->n_layer, half = md->num_mels / 2, nmel = 2 * half, NF = md->n_flow;
+    TREQUIRE(md->n_block >= 1 && md->n_block <= 16 && NF >= 1 && md->n_block * NF <= 256 && L >= 1 && L <= FWN_MAX_LAYERS,
+             "fwn_train_loss_and_grads: bad n_block / n_flow / n_layer");
+    TREQUIRE(B > 0 && T > 0 && T % hop_of(md) == 0 && T % (1L << md->n_block) == 0, "fwn_train_loss_and_grads: T must be a multiple of hop_size and 2^n_block");
+    TREQUIRE((int64_t)L * (B * T / 2) * 512 < ((int64_t)1 << 31), "fwn_train_loss_and_grads: B*T too large (2 GiB per activation buffer)");
+    TREQUIRE(t->an_logdet, "fwn_train_loss_and_grads: an_logdet (device scalar) required");
+    for (int i = 0; i < md->n_block; ++i)
+        TREQUIRE(t->cond_rows[i] && t->front_rows[i] && t->zinv32[i] && t->br[i] && t->zcol[i], "fwn_train_loss_and_grads: missing index table (block %d)", i);
+    FlowSaved saved[256];
+    Plan pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.saved = saved;
+    plan(t, B, T, workspace, pl);
+    if (workspace_bytes < pl.total) return fwn_set_error(FWN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, pl.total);
+    hipStream_t st = (hipStream_t)stream;
+
+    // ---------------- forward, keeping what the backward needs ----------------
+    {
+        long H = T / hop_of(md);
+        const float* in = mel;
+        for (int n = 0; n < md->n_up; ++n) {
+            const bool last = n == md->n_up - 1;
+            TREQUIRE(t->up_bias_dev[n], "fwn_train_loss_and_grads: up_bias_dev[%d] is null", n);
+            fwn_launch_upsample(in, (int)B, (int)H, nmel, md->up_w[n], 0.0f, t->up_bias_dev[n], md->up_scale[n], last ? nullptr : pl.ups[n],
+                                last ? pl.cplanes : nullptr, st);
+            H *= md->up_scale[n];
+            in = pl.ups[n];
+        }
+    }
+    fwn_launch_split(x, B, T, pl.planes, st);
+    const size_t plane_elems = (size_t)B * T / 2, cplane_elems = (size_t)B * T * half;
+    int p = 0;
+    for (int i = 0; i < md->n_block; ++i) {
+        const int ch = 1 << i;
+        const long ti = T / (2 * ch), m = B * ti;
+        const int cin = half * (2 << i);
+        const fwn_flow_desc* d0 = &md->flows[i * NF];
+        const bool hoist = m < 4096;
+        if (hoist)
+            for (int g_ = 0; g_ < 2 && g_ < NF; ++g_)
+                fwn_launch_cond((const bf16*)pl.cplanes + (size_t)(p ^ g_) * cplane_elems, d0->Wc[0], pl.P, (long)512 * d0->kcpad, m * 512, g_, 2,
+                                (NF - g_ + 1) / 2, L, (int)m, cin, d0->kcpad, st);
+        for (int j = 0; j < NF; ++j) {
+            const fwn_flow_desc* d = &md->flows[i * NF + j];
+            const fwn_flow_train_desc* td = &t->flows[i * NF + j];
+            FlowSaved& s = saved[i * NF + j];
+            s.p = p;
+            float* xa = pl.planes + (size_t)p * plane_elems;
+            float* xb = pl.planes + (size_t)(p ^ 1) * plane_elems;
+            const void* ca = (const bf16*)pl.cplanes + (size_t)p * cplane_elems;
+            fwn_ew_actnorm_fwd2(xa, xb, d->an, m * ch, ch, st);
+            fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, s.h[0], nullptr, (int)m, (int)ti, ch, d->kfpad, 0, nullptr, st);
+            for (int l = 0; l < L; ++l) {
+                const float* Pl = hoist ? pl.P + ((size_t)j * L + l) * m * 512 : nullptr;
+                fwn_launch_gate(s.h[l], hoist ? nullptr : ca, Pl, d->Wd[l], d->Wc[l], d->bgate[l], s.o[l], (int)m, (int)ti, dilation_of(l), d->cin,
+                                d->kcpad, s.aux[l], st);
+                if (l + 1 < L) fwn_launch_res(s.o[l], s.h[l], d->Wres[l], d->bres[l], s.h[l + 1], (int)m, nullptr, st);
+            }
+            {   // the tail un-fused: skip -> final -> ZeroConv as three GEMMs (s, u, Z are needed by the backward)
+                Seg segs[FWN_MAX_LAYERS];
+                for (int l = 0; l < L; ++l) segs[l] = {s.o[l], m, 256, 256, 0, l * 256};
+                fwn_gemm_desc g = gemm_desc(segs, L, td->Wskip, L * 256, 256, m, 0, s.s_act, 256, false);
+                g.bias = td->bskip; g.relu = 1;
+                fwn_gemm_launch(&g, st);
+                Seg s1{s.s_act, m, 256, 256, 0, 0};
+                g = gemm_desc(&s1, 1, td->Wfin, 256, 256, m, 0, s.u_act, 256, false);
+                g.bias = td->bfin; g.relu = 1;
+                fwn_gemm_launch(&g, st);
+                Seg s2{s.u_act, m, 256, 256, 0, 0};
+                g = gemm_desc(&s2, 1, td->Wz, 256, 2 * ch, m, 0, s.z, 2 * ch, true);
+                g.bias = td->bz;
+                fwn_gemm_launch(&g, st);
+            }
+            fwn_ew_coupling_fwd(xb, s.z, td->ez, m * ch, ch, s.part, s.nb, st);
+            p ^= 1;
+        }
+    }
+    fwn_launch_prior(pl.planes, B * T, pl.partial_all, pl.npart, 1.0 / (double)(B * T), pl.out2, st);
+    hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(64), 0, st, pl.out2, t->an_logdet, out3);
+
+    // ---------------- backward ----------------
+    // d loss / d z = z / (B T)   (log_p = mean 0.5 (-log 2 pi - z^2))
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_of(B * T)), dim3(256), 0, st, pl.gplanes, pl.planes, B * T, (float)(1.0 / (double)(B * T)));
+    if (hipMemsetAsync(pl.dcplanes, 0, (size_t)2 * B * T * half * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
+    for (int i = md->n_block - 1; i >= 0; --i) {
+        const int ch = 1 << i;
+        const long ti = T / (2 * ch), m = B * ti;
+        const int cin = half * (2 << i);
+        const int ldz = 2 * ch > 8 ? 2 * ch : 8;
+        for (int j = NF - 1; j >= 0; --j) {
+            const fwn_flow_desc* d = &md->flows[i * NF + j];
+            const fwn_flow_train_desc* td = &t->flows[i * NF + j];
+            const FlowSaved& s = saved[i * NF + j];
+            const int pp = s.p;
+            float* xa = pl.planes + (size_t)pp * plane_elems;          // y_a
+            float* xb = pl.planes + (size_t)(pp ^ 1) * plane_elems;    // out_b
+            float* ga = pl.gplanes + (size_t)pp * plane_elems;
+            float* gb = pl.gplanes + (size_t)(pp ^ 1) * plane_elems;
+            const void* ca = (const bf16*)pl.cplanes + (size_t)pp * cplane_elems;
+            float* dca = pl.dcplanes + (size_t)pp * cplane_elems;
+            // coupling
+            if (ldz > 2 * ch && hipMemsetAsync(pl.dz, 0, (size_t)m * ldz * 2, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
+            fwn_ew_coupling_bwd(gb, xb, s.z, td->ez, m * ch, ch, (float)(1.0 / (2.0 * (double)m * ch)), pl.dz, ldz, pl.dzz, st);
+            {
+                Seg a{pl.dz, m, ldz, ldz, 0, 0};
+                fwn_gemm_desc g = gemm_desc(&a, 1, td->WzT, ldz, 256, m, 0, pl.du, 256, false);
+                g.mask = s.u_act; g.ldmask = 256;
+                fwn_gemm_launch(&g, st);
+            }
+            TnList tn;
+            WnItem wn[4 + 7 * FWN_MAX_LAYERS];
+            int nwn = 0;
+            auto add_wn = [&](int tnj, const fwn_conv_grad* c, int k, int n, int col0, float scale, const int32_t* row_src, const int32_t* col_src) {
+                wn[nwn++] = WnItem{tnj, nullptr, 0, 0, 0, 0, c, k, n, col0, scale, row_src, col_src};
+            };
+            add_wn(tn.add(s.u_act, 256, pl.dz, ldz, 256, ldz, 1, 0, 0), &td->zero, 256, 2 * ch, 0, 1.0f, nullptr, t->zinv32[i]);
+            add_wn(tn.add(s.s_act, 256, pl.du, 256, 256, 256, 1, 0, 0), &td->final_, 256, 256, 0, 1.0f, nullptr, nullptr);
+            {
+                Seg a{pl.du, m, 256, 256, 0, 0};
+                fwn_gemm_desc g = gemm_desc(&a, 1, td->WfinT, 256, 256, m, 0, pl.ds, 256, false);
+                g.mask = s.s_act; g.ldmask = 256;
+                fwn_gemm_launch(&g, st);
+                Seg a2{pl.ds, m, 256, 256, 0, 0};
+                g = gemm_desc(&a2, 1, td->WskipT_all, 256, L * 256, m, 0, pl.d_all, L * 256, false);      // do_l = dS Wskip_l for every layer at once
+                fwn_gemm_launch(&g, st);
+            }
+            for (int l = 0; l < L; ++l) add_wn(tn.add(s.o[l], 256, pl.ds, 256, 256, 256, 1, 0, 0), &td->skip[l], 256, 256, 0, 1.0f, nullptr, nullptr);
+            const void* dh_next = nullptr;
+            for (int l = L - 1; l >= 0; --l) {
+                const int dil = dilation_of(l);
+                const void* d_ol = (const bf16*)pl.d_all + (size_t)l * 256;
+                int ld_do = L * 256;
+                if (dh_next) {      // h_{l+1} = (h_l + res(o_l)) sqrt(1/2)
+                    add_wn(tn.add(s.o[l], 256, dh_next, 256, 256, 256, 1, 0, 0), &td->res[l], 256, 256, 0, SQH, nullptr, nullptr);
+                    Seg a{dh_next, m, 256, 256, 0, 0};
+                    fwn_gemm_desc g = gemm_desc(&a, 1, td->WresT[l], 256, 256, m, 0, pl.d_o[l], 256, false);
+                    g.R = d_ol; g.ldr = ld_do; g.rscale = (float)(1.0 / 0.7071067811865476); g.oscale = SQH;
+                    fwn_gemm_launch(&g, st);
+                    d_ol = pl.d_o[l];
+                    ld_do = 256;
+                } else if (t->zero_dead_res) {      // dead res_conv of the last layer (modules.py:126-128): zero gradients
+                    const fwn_conv_grad& c = td->res[l];
+                    if (c.dV && hipMemsetAsync(c.dV, 0, (size_t)256 * 256 * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
+                    if (c.dg && hipMemsetAsync(c.dg, 0, 256 * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
+                    if (c.db && hipMemsetAsync(c.db, 0, 256 * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
+                }
+                fwn_ew_gate_bwd(d_ol, ld_do, s.aux[l], m * 256, pl.dpre[l], st);
+                const int jd = tn.add(s.h[l], 256, pl.dpre[l], 512, 256, 512, 3, -dil, dil);
+                add_wn(jd, &td->filt[l], 768, 256, 0, 1.0f, nullptr, nullptr);
+                add_wn(jd, &td->gate[l], 768, 256, 256, 1.0f, nullptr, nullptr);
+                const int jc = tn.add(ca, cin, pl.dpre[l], 512, cin, 512, 1, 0, 0);
+                add_wn(jc, &td->filt_c[l], cin, 256, 0, 1.0f, t->cond_rows[i], nullptr);
+                add_wn(jc, &td->gate_c[l], cin, 256, 256, 1.0f, t->cond_rows[i], nullptr);
+                {
+                    Seg a{pl.dpre[l], m, 512, 512, 0, 0};
+                    fwn_gemm_desc g = gemm_desc(&a, 1, td->WcT[l], 512, cin, m, 0, dca, cin, true);
+                    g.accumulate = 1;
+                    fwn_gemm_launch(&g, st);
+                    Seg sg[3];
+                    for (int tap = 0; tap < 3; ++tap) sg[tap] = {pl.dpre[l], m, 512, 512, -(tap - 1) * dil, tap * 512};
+                    g = gemm_desc(sg, 3, td->WdT[l], 1536, 256, m, (int)ti, pl.dh[l], 256, false);
+                    if (dh_next) { g.R = dh_next; g.ldr = 256; g.rscale = SQH; }
+                    if (l == 0) { g.mask = s.h[0]; g.ldmask = 256; }
+                    fwn_gemm_launch(&g, st);
+                }
+                dh_next = pl.dh[l];
+            }
+            // front conv
+            hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_of(m * ch)), dim3(256), 0, st, (bf16*)pl.ya_bf, xa, m * ch);
+            if (ch % 8 == 0) {
+                add_wn(tn.add(pl.ya_bf, ch, dh_next, 256, ch, 256, 3, -1, 1), &td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[i], nullptr);
+            } else {       // rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
+                const long mp = roundup(m, 64);
+                const int rows1 = 3 * ch + 1;
+                fwn_transpose_launch(dh_next, (int)m, 256, 256, 0, 0, 1, 0, pl.dyt, (int)mp, 0, st);
+                fwn_transpose_launch(pl.ya_bf, (int)m, ch, ch, -1, 1, 3, (int)ti, pl.xt, (int)mp, 1, st);
+                const int ns = front_small_nsplit(mp, rows1);
+                Seg a{pl.xt, rows1, (int)mp, (int)mp, 0, 0};
+                fwn_gemm_desc g = gemm_desc(&a, 1, pl.dyt, (int)mp, 256, rows1, 0, pl.fr_part, 256, true);
+                g.nsplit = ns; g.split_stride = (int64_t)rows1 * 256;
+                fwn_gemm_launch(&g, st);
+                wn[nwn++] = WnItem{-1, pl.fr_part, ns, (long)rows1 * 256, rows1, 256, &td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[i], nullptr};
+            }
+            // all weight gradients of the flow: grouped TN GEMM(s), then the grouped weight-norm backward(s)
+            {
+                float* part = pl.tn_part;
+                for (int g0 = 0; g0 < tn.n; g0 += FWN_MAX_GROUP) {
+                    const int cnt = tn.n - g0 < FWN_MAX_GROUP ? tn.n - g0 : FWN_MAX_GROUP;
+                    TnSpec sp[FWN_MAX_GROUP];
+                    for (int k = 0; k < cnt; ++k) sp[k] = {tn.job[g0 + k].Kx, tn.job[g0 + k].N, tn.job[g0 + k].ntap};
+                    const int ns = tn_group_splits(sp, cnt, (int)m);
+                    for (int k = 0; k < cnt; ++k) {
+                        fwn_tn_job& q = tn.job[g0 + k];
+                        const long size = ((long)q.ntap * q.Kx + 1) * q.N;
+                        q.part = part; q.split_stride = size; q.nsplit = ns;
+                        part += (size_t)ns * size;
+                    }
+                    fwn_tn_group_launch(tn.job + g0, cnt, (int)m, (int)ti, st);
+                }
+                for (int w0 = 0; w0 < nwn; w0 += FWN_MAX_GROUP) {
+                    const int cnt = nwn - w0 < FWN_MAX_GROUP ? nwn - w0 : FWN_MAX_GROUP;
+                    fwn_wn_job jobs[FWN_MAX_GROUP];
+                    for (int k = 0; k < cnt; ++k) {
+                        const WnItem& it = wn[w0 + k];
+                        fwn_wn_job& q = jobs[k];
+                        memset(&q, 0, sizeof(q));
+                        if (it.tn >= 0) {
+                            const fwn_tn_job& tj = tn.job[it.tn];
+                            q.part = tj.part; q.split_stride = tj.split_stride; q.nsplit = tj.nsplit; q.ldp = tj.N;
+                            q.bias_row = tj.ntap * tj.Kx;
+                        } else {
+                            q.part = it.part_direct; q.split_stride = it.part_stride; q.nsplit = it.part_nsplit; q.ldp = it.part_ld;
+                            q.bias_row = it.part_rows - 1;
+                        }
+                        q.row_src = it.row_src; q.col_src = it.col_src; q.col0 = it.col0; q.K = it.k; q.N = it.n; q.scale = it.scale;
+                        q.V = it.c->g ? it.c->V : nullptr; q.g = it.c->g; q.dV = it.c->dV; q.dg = it.c->g ? it.c->dg : nullptr; q.db = it.c->db;
+                        TREQUIRE(q.dV && (!q.g || (q.V && q.dg)), "fwn_train_loss_and_grads: flow (%d,%d): missing gradient / master pointer", i, j);
+                    }
+                    fwn_wn_group_launch(jobs, cnt, pl.wn_scratch, st);
+                }
+            }
+            {
+                Seg sg[3];
+                for (int tap = 0; tap < 3; ++tap) sg[tap] = {dh_next, m, 256, 256, -(tap - 1), tap * 256};
+                fwn_gemm_desc g = gemm_desc(sg, 3, td->WfT, 768, ch, m, (int)ti, ga, ch, true);
+                g.accumulate = 1;
+                fwn_gemm_launch(&g, st);
+            }
+            // ActNorm of both planes back to the flow's inputs, with its b / logs gradients and the ZeroConv scale gradient
+            TREQUIRE(td->d_an_b && td->d_an_logs && td->d_zscale, "fwn_train_loss_and_grads: flow (%d,%d): missing small gradient pointers", i, j);
+            fwn_small_grads_launch(ga, xa, gb, xb, pl.dzz, d->an, m, ch, (const long long*)t->br[i], (const long long*)t->zcol[i], pl.sg_scratch,
+                                   td->d_an_b, td->d_an_logs, td->d_zscale, st);
+            if (j == 0 && on_block_done) on_block_done(user, i);
+        }
+    }
+    // up-sampling transposed convolutions (model.py:301-311), last stage first
+    hipLaunchKernelGGL(planes_to_rows_kernel, dim3(grid_of(B * T * nmel)), dim3(256), 0, st, pl.dcplanes, (const bf16*)pl.cplanes, B * T, half, pl.up_dy,
+                       pl.up_y);
+    {
+        float* dy = pl.up_dy;
+        const float* y = pl.up_y;
+        for (int n = md->n_up - 1; n >= 0; --n) {
+            const int s_ = md->up_scale[n];
+            long hh = T / hop_of(md);
+            for (int k = 0; k < n; ++k) hh *= md->up_scale[k];                 // rows of the stage's input
+            const float* xin = n == 0 ? mel : pl.ups[n - 1];
+            float* dx = n > 0 ? pl.up_dx[n & 1] : nullptr;
+            const fwn_conv_grad& c = t->up[n];
+            TREQUIRE(c.V && c.g && c.dV && c.dg && c.db, "fwn_train_loss_and_grads: up-sampling stage %d: missing pointer", n);
+            fwn_up_bwd_launch(dy, y, xin, (int)B, (int)hh, nmel, s_, md->up_w[n], dx, pl.up_dwb, pl.up_scr, st);
+            hipLaunchKernelGGL(up_prepare_kernel, dim3(1), dim3(64), 0, st, c.g, pl.up_g3);
+            fwn_wn_job q;
+            memset(&q, 0, sizeof(q));
+            q.part = pl.up_dwb; q.split_stride = 0; q.nsplit = 1; q.ldp = 3; q.col0 = 0; q.bias_row = -1; q.K = 2 * s_; q.N = 3; q.scale = 1.0f;
+            q.V = c.V; q.g = pl.up_g3; q.dV = c.dV; q.dg = pl.up_dg3; q.db = nullptr;
+            fwn_wn_group_launch(&q, 1, pl.wn_scratch, st);
+            hipLaunchKernelGGL(up_finish_kernel, dim3(1), dim3(64), 0, st, pl.up_dg3, pl.up_dwb, s_, c.dg, c.db);
+            dy = dx;
+            y = xin;
+        }
+    }
+    if (on_block_done) on_block_done(user, -1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: %s", hipGetErrorString(e));
+    return FWN_OK;
+}
+
+}  // extern "C"
