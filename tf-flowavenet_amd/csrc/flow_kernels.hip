@@ -106,11 +106,13 @@ struct FrontProb {
 // tile would be > 90 % zero padding.  One workgroup = 4*R rows x 256 channels; a wave owns R rows
 // and each lane 4 channels; x (ActNorm applied, zero padded per clip) and the weights sit in LDS
 // as fp32, so the flow state enters the network at full precision.
-template <int R>
+// KMAX >= K = 3 Ch sizes the LDS images: with the 48-deep images of the widest case every block held 60 KB and two
+// workgroups (8 waves) per CU - too few stores in flight for an HBM-bound kernel; block 0 (K = 3) needs 4 KB.
+template <int R, int KMAX>
 __global__ __launch_bounds__(256) void front_valu_kernel(FrontProb p) {
     constexpr int ROWS = 4 * R;
-    __shared__ __attribute__((aligned(16))) float wt[48 * 256];     // [k][256]
-    __shared__ __attribute__((aligned(16))) float yt[48 * ROWS];    // [k][row]
+    __shared__ __attribute__((aligned(16))) float wt[KMAX * 256];     // [k][256]
+    __shared__ __attribute__((aligned(16))) float yt[KMAX * ROWS];    // [k][row]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = 3 * p.Ch;
@@ -1061,8 +1063,13 @@ void fwn_launch_front(const float* xa, const float* an_a, const void* W, const v
     FrontProb p{xa, an_a, (const bf16*)W, bias, (bf16*)hout, M, Ti, Ch, ilog2(Ch), kpad, apply_an};
     if (Ch <= 16) {
         p.h8out = (unsigned char*)h8out;
-        if (M >= 64 * 512) hipLaunchKernelGGL((front_valu_kernel<16>), dim3((M + 63) / 64), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((front_valu_kernel<4>), dim3((M + 15) / 16), dim3(256), 0, st, p);
+#define FRONT_VALU(R, KMAX, ROWS) hipLaunchKernelGGL((front_valu_kernel<R, KMAX>), dim3((M + ROWS - 1) / ROWS), dim3(256), 0, st, p)
+        const bool big = M >= 64 * 512;
+        if (Ch <= 2) { if (big) FRONT_VALU(16, 6, 64); else FRONT_VALU(4, 6, 16); }
+        else if (Ch <= 4) { if (big) FRONT_VALU(16, 12, 64); else FRONT_VALU(4, 12, 16); }
+        else if (Ch <= 8) { if (big) FRONT_VALU(16, 24, 64); else FRONT_VALU(4, 24, 16); }
+        else { if (big) FRONT_VALU(16, 48, 64); else FRONT_VALU(4, 48, 16); }
+#undef FRONT_VALU
         return;
     }
     launch_gemm128(p, M, 2, st);
