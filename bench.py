@@ -179,7 +179,7 @@ def fp8_leg(hp, params, model_bf16, x, c, z, b, t):
     from tf_flowavenet_amd import _lib
     from tf_flowavenet_amd.model import FloWaveNet
     lib = _lib.load()
-    m8 = FloWaveNet(hp, init=True, device=x.device, gate_fp8=True).load_params(params)
+    m8 = FloWaveNet(hp, init=True, device=x.device, gate_fp8=True, group=False).load_params(params)     # rank 0 only: local init
     lp8, ld8 = m8.forward(x, c)
     lpb, ldb = model_bf16.forward(x, c)
 
@@ -524,6 +524,11 @@ def main():
                 out["note"] = note
             print(json.dumps(out), flush=True)
 
+    def leg_failed(name, e):
+        import traceback
+        out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print("bench.py rank %d: the %s leg failed:\n%s" % (rank, name, traceback.format_exc()), file=sys.stderr, flush=True)
+
     # optional legs (all ranks take part; a failure or a stall is reported inside the line, never instead of it)
     deadline = Deadline(emit)
     if not args.no_rtf:
@@ -531,14 +536,14 @@ def main():
         try:
             out["rtf_10s"] = rtf_10s(model, hp, dev, world)
         except Exception as e:
-            out["rtf_10s"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            leg_failed("rtf_10s", e)
         deadline.disarm()
     if not args.no_fp8 and rank == 0:
         deadline.arm(args.leg_timeout, "the configs[4] fp8 leg")
         try:
             out["fp8"] = fp8_leg(hp, params, model, x, c, z, b, t)
         except Exception as e:
-            out["fp8"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            leg_failed("fp8", e)
         deadline.disarm()
     if not args.no_train:
         del model
@@ -548,7 +553,7 @@ def main():
             out["train"] = train_leg(hp, params, rank, world, dev, steps=args.train_steps,
                                      force_collectives=args.force_collectives)
         except Exception as e:
-            out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            leg_failed("train", e)
         deadline.disarm()
     emit()
     if world > 1 or args.force_collectives:

@@ -16,9 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*flags, timeout=900):
+def _bench(*flags, timeout=900, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.update(extra_env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                           "--train-steps", "4"] + list(flags), capture_output=True, text=True, timeout=timeout, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -80,6 +81,19 @@ def test_recorded_step_with_rccl_all_reduces_between_graph_segments_equals_the_e
         if p.is_alive():
             p.kill()
     assert same_outs and same_w and segments == 5, (same_outs, same_w, segments)
+
+
+def test_bench_two_ranks_sharing_the_gpu_run_every_leg_in_step():
+    """`bench.py --gpus 2` (its own launcher -> torch.distributed.run -> two ranks) with FWN_BENCH_SHARE_GPU=1: both ranks on
+    cuda:0, exchanges over gloo.  The multi-rank control flow of every leg - global ActNorm init, NLL all-reduce, the
+    rank-0-only fp8 leg beside the other rank's training collectives (a collective mismatch here once aborted rank 0),
+    per-block gradient all-reduces, the timing reductions - on the one GPU the test box has."""
+    rec = _bench("--gpus", "2", extra_env={"FWN_BENCH_SHARE_GPU": "1"})
+    assert rec["n_gpus"] == 2 and "note" not in rec
+    for leg in ("train", "rtf_10s", "fp8"):
+        assert rec[leg] is not None and "error" not in rec[leg], (leg, rec[leg])
+    assert rec["train"]["n_gpus"] == 2 and rec["train"]["global_batch"] == 16 and rec["train"]["allreduce_ms"] > 0
+    assert np.isfinite(rec["train"]["loss"]) and rec["rtf_10s"]["n_gpus"] == 2
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")

@@ -27,7 +27,7 @@ from . import _lib, packing, weights
 class FloWaveNet:
     def __init__(self, hparams, init=False, scope="FloWaveNet", device="cuda", cond_mode=0, group=None, gate_fp8=None):
         """group: the ``torch.distributed`` process group a data-parallel job shards its batch over (None = the
-        default group when one is initialised).  It only matters for ``init=True``: the ActNorm data-dependent
+        default group when one is initialised; False: none - a model only one rank builds).  It only matters for ``init=True``: the ActNorm data-dependent
         init then uses the statistics of the GLOBAL batch (moments all-reduced flow by flow) so every rank ends
         with the same parameters - the reference's towers race on that assign (model.py:39, train.py:43-57)."""
         if not hparams.affine:
@@ -152,8 +152,8 @@ class FloWaveNet:
 
     def _dp_world(self):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
-            return 1
+        if self._group is False or not (dist.is_available() and dist.is_initialized()):
+            return 1                    # group=False: this model lives on one rank only (its init uses the local batch)
         return dist.get_world_size(self._group)
 
     def _forward_init_dp(self, b, t, x32, c32, wsp, wsn, out2, zp):
