@@ -397,3 +397,14 @@ def test_checkpoints_survive_a_crash_mid_write_and_order_by_step(tmp_path):
     assert T.restore_checkpoint(str(tmp_path), fresh) == 1000
     assert float(S.load_checkpoint(str(tmp_path))["a/bias"][0]) == 1000.0
     assert T.restore_checkpoint(str(tmp_path / "nothing"), fresh) is None
+
+
+def test_synthesize_splits_batches_under_the_per_call_addressing_limit():
+    """B = 40 x 10 s is rejected by the C layer (2 GiB per activation buffer); the CLI must pick the batch
+    itself.  n_layer * (B T / 2) * 512 < 2^31 with the default hparams -> 4 194 303 samples per call."""
+    from tf_flowavenet_amd import synthesize as S
+    from tf_flowavenet_amd.hparams import default_hparams
+    hp = default_hparams()
+    assert S.max_clips_per_call(hp, 220672) == 19          # 10 s clips: 19 per call, 20 would exceed the limit
+    assert hp.n_layer * (19 * 220672 // 2) * 512 < 1 << 31 <= hp.n_layer * (20 * 220672 // 2) * 512
+    assert S.max_clips_per_call(hp, 16128) == 260 and S.max_clips_per_call(hp, 5_000_000) == 0

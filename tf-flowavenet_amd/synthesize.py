@@ -52,6 +52,13 @@ def load_checkpoint(saved_dir):
     raise FileNotFoundError("no readable checkpoint in %r (last error: %s)" % (saved_dir, last_error))
 
 
+def max_clips_per_call(hparams, t):
+    """How many clips of t samples one ``reverse`` call may take: every activation buffer is addressed with 32-bit
+    offsets below 2 GiB (csrc/api.hip check_model: n_layer * (B T / 2) * 512 and B * T * num_mels bytes)."""
+    lim = min(((1 << 31) - 1) // (hparams.n_layer * 256), ((1 << 31) - 1) // hparams.num_mels)
+    return int((lim - 1) // t)
+
+
 def write_wav(path, audio, sample_rate):
     pcm = np.clip(np.asarray(audio, dtype=np.float64), -1.0, 1.0)
     pcm = (pcm * 32767.0).round().astype("<i2")
@@ -78,10 +85,14 @@ def synthesize(args, hparams, model=None):
     align = max(1, (1 << hparams.n_block) // np.gcd(1 << hparams.n_block, hop))
     for frames, group in sorted(by_len.items()):
         pad = (-frames) % align                      # T must divide by 2^n_block (model.py:226)
-        for i in range(0, len(group), args.batch):
-            chunk = group[i:i + args.batch]
+        t = (frames + pad) * hop
+        per_call = min(int(args.batch), max_clips_per_call(hparams, t))      # long utterances: fewer clips per launch
+        if per_call < 1:
+            raise ValueError("an utterance of %d samples exceeds what one call can address (%d samples): split the mel"
+                             % (t, max_clips_per_call(hparams, 1)))
+        for i in range(0, len(group), per_call):
+            chunk = group[i:i + per_call]
             c = np.stack([np.pad(mels[n], ((0, pad), (0, 0)), mode="edge") for n in chunk])
-            t = (frames + pad) * hop
             z = torch.randn(len(chunk), t, 1, generator=gen) * hparams.temp     # synthesize.py:14
             wav = model.reverse(z.cuda(), torch.from_numpy(c).cuda()).squeeze(-1).cpu().numpy()
             for n, w in zip(chunk, wav):
