@@ -64,6 +64,17 @@ typedef struct fwn_pack_job {
 int fwn_pack_jobs(const fwn_scale_job* scale_jobs, int n_scale_jobs, const fwn_pack_job* pack_jobs, int n_pack_jobs,
                   float* scales, int scale_ld, void* stream);
 
+/* ---- small fp32 parameter tables straight from a flat vector of fp32 masters (a training step refreshes biases,
+ * ActNorm / ZeroConv tables and the up-sampling kernels on the device, inside its hipGraph):
+ * fwn_gather_tables: out[i] = F(post[i] * sum_t flat[idx[t*total + i]]) for i < total (idx < 0: term absent);
+ *                    mode[i] 0: identity, 1: exp, both in fp64 rounded once; 2 / 3: the same in fp32, terms in order
+ * fwn_sum_f32      : out[0] = sum_i in[i] (fixed order, fp64 accumulation)
+ * fwn_upsample_wn  : the weight-normed up-sampling kernel out[2s][3] = v / ||v||_(k per kw column) * g (convolutional.py:179-186) */
+int fwn_gather_tables(const float* flat, const int64_t* idx, int nterm, int64_t total, const double* post,
+                      const unsigned char* mode, float* out, void* stream);
+int fwn_sum_f32(const float* in, int64_t n, float* out, void* stream);
+int fwn_upsample_wn(const float* v, const float* g, int s, float* out, void* stream);
+
 /* ---- K1: one upsampling stage (replaces Conv2DTranspose.call + leaky_relu, model.py:301-311,
  * 398-404).  in [B][H][W] fp32, wk = weight-normed kernel [2s][3] fp32 (device), out rows H*s.
  * Exactly one of out_f32 ([B][H*s][W]) / out_cplanes (bf16 [2][B][H*s][W/2]) may be NULL. */

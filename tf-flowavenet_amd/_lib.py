@@ -132,6 +132,9 @@ SIGNATURES = {
     "fwn_last_error": (C.c_char_p, []),
     "fwn_wn_scale": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_pack_bf16": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, i64, vp, vp]),
+    "fwn_gather_tables": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, vp, vp]),
+    "fwn_sum_f32": (C.c_int, [vp, i64, vp, vp]),
+    "fwn_upsample_wn": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "fwn_upsample_stage": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_float, C.c_int, vp, vp, vp]),
     "fwn_upsample_stage_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp]),
     "fwn_split_planes": (C.c_int, [vp, i64, i64, vp, vp]),

@@ -63,6 +63,23 @@ int fwn_pack_jobs(const fwn_scale_job* scale_jobs, int n_scale_jobs, const fwn_p
     return check_launch("fwn_pack_jobs");
 }
 
+int fwn_gather_tables(const float* flat, const int64_t* idx, int nterm, int64_t total, const double* post,
+                      const unsigned char* mode, float* out, void* stream) {
+    REQUIRE(flat && idx && post && mode && out && nterm >= 1 && total > 0, "fwn_gather_tables: bad argument");
+    fwn_launch_gather_tables(flat, (const long long*)idx, nterm, (long)total, post, mode, out, (hipStream_t)stream);
+    return check_launch("fwn_gather_tables");
+}
+int fwn_sum_f32(const float* in, int64_t n, float* out, void* stream) {
+    REQUIRE(in && out && n > 0, "fwn_sum_f32: bad argument");
+    fwn_launch_sum_f32(in, (long)n, out, (hipStream_t)stream);
+    return check_launch("fwn_sum_f32");
+}
+int fwn_upsample_wn(const float* v, const float* g, int s, float* out, void* stream) {
+    REQUIRE(v && g && out && s > 0, "fwn_upsample_wn: bad argument");
+    fwn_launch_upsample_wn(v, g, s, out, (hipStream_t)stream);
+    return check_launch("fwn_upsample_wn");
+}
+
 int fwn_upsample_stage(const float* in, int B, int H, int W, const float* wk, float bias, int s,
                        float* out_f32, void* out_cplanes, void* stream) {
     REQUIRE(in && wk, "fwn_upsample_stage: null pointer");

@@ -116,6 +116,71 @@ void fwn_launch_cast_e4m3(const void* src, void* dst, long n, hipStream_t st) {
     hipLaunchKernelGGL(cast_e4m3_kernel, dim3(grid_for((n + 1) / 2)), dim3(256), 0, st, (const bf16*)src, (unsigned char*)dst, n);
 }
 
+// ---- small parameter tables straight from the flat fp32 masters (training: refreshed every step, on the device) ------
+// out[i] = F(post[i] * sum_t flat[idx[t][i]])  (idx < 0: term absent).  mode[i]: 0 = fp64 sum, identity; 1 = fp64 sum,
+// exp (both rounded once, the host path's arithmetic); 2 / 3 = the same two in fp32, terms added in order - the
+// arithmetic of the framework expressions these tables used to be computed with (bit-compatible with them).
+__global__ __launch_bounds__(256) void gather_tables_kernel(const float* __restrict__ flat, const long long* __restrict__ idx,
+                                                            int nterm, long total, const double* __restrict__ post,
+                                                            const unsigned char* __restrict__ mode, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int md = mode[i];
+        if (md < 2) {
+            double acc = 0.0;
+            for (int t = 0; t < nterm; ++t) {
+                const long long ix = idx[(size_t)t * total + i];
+                acc += ix >= 0 ? (double)flat[ix] : 0.0;
+            }
+            acc *= post[i];
+            out[i] = (float)(md ? exp(acc) : acc);
+        } else {
+            float acc = 0.0f;
+            bool first = true;
+            for (int t = 0; t < nterm; ++t) {
+                const long long ix = idx[(size_t)t * total + i];
+                if (ix < 0) continue;
+                acc = first ? flat[ix] : acc + flat[ix];
+                first = false;
+            }
+            const float pf = (float)post[i];
+            acc = md == 3 ? expf(pf * acc) : acc * pf;
+            out[i] = acc;
+        }
+    }
+}
+// out[0] = sum_i in[i] (one workgroup, fixed order, fp64 accumulation)
+__global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ in, long n, float* __restrict__ out) {
+    __shared__ double red[256];
+    double a = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) a += (double)in[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+// weight-normed up-sampling kernel (convolutional.py:179-186): out[k][kw] = v[k][kw] / sqrt(max(sum_k v[k][kw]^2, 1e-12)) * g
+__global__ void upsample_wn_kernel(const float* __restrict__ v, const float* __restrict__ g, int s, float* __restrict__ out) {
+    const int kw = threadIdx.x;
+    if (kw >= 3) return;
+    double ss = 0.0;
+    for (int k = 0; k < 2 * s; ++k) ss += (double)v[k * 3 + kw] * (double)v[k * 3 + kw];
+    const double nrm = sqrt(fmax(ss, 1e-12));
+    for (int k = 0; k < 2 * s; ++k) out[k * 3 + kw] = (float)((double)v[k * 3 + kw] / nrm * (double)g[0]);
+}
+void fwn_launch_gather_tables(const float* flat, const long long* idx, int nterm, long total, const double* post,
+                              const unsigned char* expflag, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_tables_kernel, dim3(grid_for(total)), dim3(256), 0, st, flat, idx, nterm, total, post, expflag, out);
+}
+void fwn_launch_sum_f32(const float* in, long n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, st, in, n, out);
+}
+void fwn_launch_upsample_wn(const float* v, const float* g, int s, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(upsample_wn_kernel, dim3(1), dim3(64), 0, st, v, g, s, out);
+}
+
 // ---- grouped form of the two kernels above: a whole model's weight-norm scales and packed copies
 // in two launches driven by device-resident job tables (a training step re-packs every weight from
 // the fp32 masters; the tables are built once because master and output pointers are stable).

@@ -33,6 +33,10 @@ void fwn_launch_wn_absmax(const float* v, const float* scale, int k_src, int n_s
 void fwn_launch_pack_e4m3(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src, int k_dst,
                           int n_dst, long ld_dst, float mul, const float* amax, void* out, int* exp_out, hipStream_t st);
 void fwn_launch_cast_e4m3(const void* src, void* dst, long n, hipStream_t st);
+void fwn_launch_gather_tables(const float* flat, const long long* idx, int nterm, long total, const double* post,
+                              const unsigned char* expflag, float* out, hipStream_t st);
+void fwn_launch_sum_f32(const float* in, long n, float* out, hipStream_t st);
+void fwn_launch_upsample_wn(const float* v, const float* g, int s, float* out, hipStream_t st);
 void fwn_launch_upsample(const float* in, int B, int H, int W, const float* wk, float bias, const float* bias_dev, int s,
                          float* out_f32, void* out_planes, hipStream_t st);
 void fwn_launch_split(const float* x, long B, long T, float* planes, hipStream_t st);

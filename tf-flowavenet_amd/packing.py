@@ -206,10 +206,9 @@ class PackPlan:
             return False
         total = int(self._tbuf.numel())
         nterm = max(len(r.get("terms", ())) for r in self.recipes)
-        idx = np.zeros((nterm, total), dtype=np.int64)
-        mask = np.zeros((nterm, total), dtype=np.float64)
+        idx = np.full((nterm, total), -1, dtype=np.int64)
         post = np.ones(total, dtype=np.float64)
-        expf = np.zeros(total, dtype=bool)
+        mode = np.zeros(total, dtype=np.uint8)
         self._up_jobs = []
         for (off, size), r in zip(self._toffs, self.recipes):
             if "upsample" in r:
@@ -217,38 +216,32 @@ class PackPlan:
                 continue
             for t, (name, ix) in enumerate(r["terms"]):
                 ix = np.broadcast_to(np.asarray(ix, dtype=np.int64).reshape(-1), (size,))
-                ok = ix >= 0
-                idx[t, off:off + size] = np.where(ok, int(params[name].storage_offset()) + ix, 0)
-                mask[t, off:off + size] = ok
+                idx[t, off:off + size] = np.where(ix >= 0, int(params[name].storage_offset()) + ix, -1)
             post[off:off + size] = np.broadcast_to(np.asarray(r.get("post", 1.0), dtype=np.float64).reshape(-1), (size,))
-            expf[off:off + size] = np.broadcast_to(np.asarray(r.get("exp", False), dtype=bool).reshape(-1), (size,))
+            mode[off:off + size] = np.broadcast_to(np.asarray(r.get("exp", False), dtype=bool).reshape(-1), (size,))
         dev = self.dev
         self._flat = base
-        self._didx = [torch.from_numpy(idx[t]).to(dev) for t in range(nterm)]
-        self._dmask = [torch.from_numpy(mask[t]).to(dev) for t in range(nterm)]
+        self._didx = torch.from_numpy(np.ascontiguousarray(idx)).to(dev)
         self._dpost = torch.from_numpy(post).to(dev)
-        self._dexp = torch.from_numpy(expf).to(dev)
+        self._dmode = torch.from_numpy(mode).to(dev)
+        self._nterm, self._ttotal = nterm, total
         self._up_params = params
         self._dev_ready = True
         return True
 
     def refresh_tables_device(self):
-        """The small tables recomputed from the masters ON the device (a few batched gathers in float64, the host
-        path's arithmetic): no device -> host -> device round trip, and the whole refresh can sit in a hipGraph."""
+        """The small tables recomputed from the masters ON the device: one ``fwn_gather_tables`` launch (fp64 like the
+        host path) + one ``fwn_upsample_wn`` per up-sampling stage, straight into the table buffer the descriptors
+        point at - no device -> host -> device round trip, and the whole refresh can sit in a hipGraph."""
         import torch
-        acc = None
-        for ix, mk in zip(self._didx, self._dmask):
-            term = self._flat[ix].double() * mk
-            acc = term if acc is None else acc + term
-        acc = acc * self._dpost
-        out = torch.where(self._dexp, torch.exp(acc), acc).float()
+        lib = _lib.load()
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        _lib.check(lib.fwn_gather_tables(self._flat.data_ptr(), self._didx.data_ptr(), self._nterm, self._ttotal,
+                                         self._dpost.data_ptr(), self._dmode.data_ptr(), self._tbuf.data_ptr(), st), "fwn_gather_tables")
+        P = self._up_params
         for n, off, size in self._up_jobs:          # weight-normed up-sampling kernels: v / ||v||_(k) * g per kw column
-            P = self._up_params
-            v = P["upsample_%d/kernel" % n].double()
-            nrm = torch.sqrt(torch.clamp((v * v).sum(dim=(0, 2), keepdim=True), min=1e-12))
-            w = v / nrm * P["upsample_%d/g" % n].double().reshape(-1)[0]
-            out[off:off + size] = w[:, :, 0, 0].reshape(-1).float()
-        self._tbuf.copy_(out)
+            v, g = P["upsample_%d/kernel" % n], P["upsample_%d/g" % n]
+            _lib.check(lib.fwn_upsample_wn(v.data_ptr(), g.data_ptr(), size // 6, self._tbuf[off:].data_ptr(), st), "fwn_upsample_wn")
 
     def _build(self):
         import torch

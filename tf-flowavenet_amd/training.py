@@ -266,43 +266,63 @@ class _TrainPack:
         self.an_logdet = None
 
     def _batched_tables(self):
+        """bskip (sum of the layers' skip biases), bz, ez = exp(3 scale) of every flow and the parameter-only part of
+        logdet, sum over flows of mean_C(3 logs) (model.py:86-94): ONE ``fwn_gather_tables`` launch over the flat
+        masters (fp32 arithmetic, the order of the framework expressions it replaced) + ``fwn_sum_f32``, into buffers
+        allocated once (the descriptors of the C step keep pointing at them)."""
         import torch
         hp, P = self.hp, self.params
         flat = self.plan._flat
+        lib = self.lib
         if getattr(self, "_bt", None) is None:          # gather tables into the flat master vector, built once
             off = lambda name: int(P[name].storage_offset())
-            skip = [[] for _ in range(hp.n_layer)]
+            L = hp.n_layer
+            skip = [[] for _ in range(L)]
             bz, ez, an3, anw, spans = [], [], [], [], {}
             zpos = 0
             for (i, j), t in self.flows.items():
                 wp = weights.flow_prefix(i, j) + "/WaveNet"
-                for l in range(hp.n_layer):
+                for l in range(L):
                     skip[l].append(off("%s/ResBlock_%d/skip_conv/bias" % (wp, l)) + np.arange(256))
                 zc = t["zcol"].cpu().numpy()
                 bz.append(off(wp + "/ZeroConv1d/bias") + zc)
                 ez.append(off(wp + "/ZeroConv1d/scale") + zc)
-                lg = off(weights.flow_prefix(i, j) + "/ActNorm/logs") + np.arange(2 << i)
-                an3.append(lg)
+                an3.append(off(weights.flow_prefix(i, j) + "/ActNorm/logs") + np.arange(2 << i))
                 anw.append(np.full(2 << i, 3.0 / (2 << i)))          # sum over both planes of mean_C(3 logs)
                 spans[(i, j)] = (zpos, zpos + len(zc))
                 zpos += len(zc)
-            dev_i = lambda a: torch.from_numpy(np.concatenate(a).astype(np.int64)).to(self.dev)
-            self._bt = dict(skip=[dev_i(a) for a in skip], bz=dev_i(bz), ez=dev_i(ez), an3=dev_i(an3),
-                            anw=torch.from_numpy(np.concatenate(anw).astype(np.float32)).to(self.dev), spans=spans)
+            skip = [np.concatenate(a) for a in skip]
+            bz, ez, an3, anw = np.concatenate(bz), np.concatenate(ez), np.concatenate(an3), np.concatenate(anw)
+            n_s, n_z, n_a = len(skip[0]), len(bz), len(an3)
+            total = n_s + 2 * n_z + n_a
+            idx = np.full((L, total), -1, dtype=np.int64)
+            for l in range(L):
+                idx[l, :n_s] = skip[l]
+            idx[0, n_s:n_s + n_z] = bz
+            idx[0, n_s + n_z:n_s + 2 * n_z] = ez
+            idx[0, n_s + 2 * n_z:] = an3
+            post = np.ones(total)
+            post[n_s + n_z:n_s + 2 * n_z] = 3.0
+            post[n_s + 2 * n_z:] = anw
+            mode = np.full(total, 2, dtype=np.uint8)
+            mode[n_s + n_z:n_s + 2 * n_z] = 3
+            out = torch.empty(total, dtype=torch.float32, device=self.dev)
+            self._bt = dict(idx=torch.from_numpy(idx).to(self.dev), post=torch.from_numpy(post).to(self.dev),
+                            mode=torch.from_numpy(mode).to(self.dev), out=out, L=L, total=total, spans=spans,
+                            bskip=out[:n_s], bz=out[n_s:n_s + n_z], ez=out[n_s + n_z:n_s + 2 * n_z], anp=out[n_s + 2 * n_z:],
+                            an_logdet=torch.empty(1, dtype=torch.float32, device=self.dev))
+            for f, ((i, j), t) in enumerate(self.flows.items()):
+                wp = weights.flow_prefix(i, j) + "/WaveNet"
+                lo, hi = spans[(i, j)]
+                t["bskip"] = self._bt["bskip"][f * 256:(f + 1) * 256]
+                t["bfin"] = self._f32(wp + "/Conv_final/bias")
+                t["bz"], t["ez"] = self._bt["bz"][lo:hi], self._bt["ez"][lo:hi]
         bt = self._bt
-        bskip = flat[bt["skip"][0]]
-        for l in range(1, hp.n_layer):
-            bskip = bskip + flat[bt["skip"][l]]
-        bz_all = flat[bt["bz"]]
-        ez_all = torch.exp(3.0 * flat[bt["ez"]])
-        # sum over flows of mean_C(3 logs) of both ActNorm planes: the parameter-only part of logdet (model.py:86-94)
-        self.an_logdet = (flat[bt["an3"]] * bt["anw"]).sum()
-        for f, ((i, j), t) in enumerate(self.flows.items()):
-            wp = weights.flow_prefix(i, j) + "/WaveNet"
-            lo, hi = bt["spans"][(i, j)]
-            t["bskip"] = bskip[f * 256:(f + 1) * 256]
-            t["bfin"] = self._f32(wp + "/Conv_final/bias")
-            t["bz"], t["ez"] = bz_all[lo:hi], ez_all[lo:hi]
+        st = _stream(flat)
+        _lib.check(lib.fwn_gather_tables(flat.data_ptr(), bt["idx"].data_ptr(), bt["L"], bt["total"], bt["post"].data_ptr(),
+                                         bt["mode"].data_ptr(), bt["out"].data_ptr(), st), "fwn_gather_tables")
+        _lib.check(lib.fwn_sum_f32(bt["anp"].data_ptr(), bt["anp"].numel(), bt["an_logdet"].data_ptr(), st), "fwn_sum_f32")
+        self.an_logdet = bt["an_logdet"]
 
     def _pack_flow_plan(self, i, j):
         """The backward's transposed / natural-order copies as jobs of the plan (transposed packing:
