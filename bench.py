@@ -51,7 +51,7 @@ def flop_per_sample(hp):
     return total
 
 
-def cpu_baseline(hp, params, t, budget_s=25.0):
+def cpu_baseline(hp, params, t, budget_s=20.0, max_passes=16):
     """torch-CPU fp32 restatement (oracle/flowavenet_torch.py) timed on a bounded sample."""
     import torch
     from oracle import flowavenet_torch as ot
@@ -66,19 +66,20 @@ def cpu_baseline(hp, params, t, budget_s=25.0):
     times = []
     t_start = time.perf_counter()
     with torch.no_grad():
-        for it in range(4):
+        for it in range(max_passes + 1):
             t0 = time.perf_counter()
             ot.forward(fp, x, c, hp)
             ot.reverse(fp, z, c, hp)
             dt = time.perf_counter() - t0
             if it > 0:
                 times.append(dt)
-            if time.perf_counter() - t_start > budget_s and times:
+            if time.perf_counter() - t_start > budget_s and len(times) >= 3:
                 break
     med = float(np.median(times))
     return {"value": 2.0 * t / med, "unit": "samples/s", "cores": ncore, "kind": "port",
             "sample": "torch-CPU fp32 restatement (TF 1.12 unavailable), full n_block=%d model, B=1, T=%d, "
-                      "forward+inverse, median of %d timed passes after 1 warm-up" % (hp.n_block, t, len(times))}
+                      "forward+inverse, median of %d timed passes after 1 warm-up (spread %.0f%%)"
+                      % (hp.n_block, t, len(times), 100.0 * (max(times) - min(times)) / med)}
 
 
 def gate_roofline(model, hp, b, t, iters=30):
