@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FWN_VERSION 100            /* 0.1.0 */
+#define FWN_VERSION 200            /* 0.2.0: fwn_tail takes scratch; training, fp8 and multi-rank init entry points */
 #define FWN_MAX_LAYERS 8
 #define FWN_MAX_UPSAMPLE 4
 

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version(lib):
-    assert lib.fwn_version() == 100
+    assert lib.fwn_version() == 200
 
 
 def test_struct_layout_matches_header(tmp_path):

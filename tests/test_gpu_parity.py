@@ -45,7 +45,7 @@ def check_scalars(log_p, logdet, lp0, ld0):
 
 def test_native_library_is_loaded():
     lib = _lib.load()
-    assert lib.fwn_version() == 100
+    assert lib.fwn_version() == 200
     assert os.path.basename(_lib.LIB_PATH) == "libfwn.so" and os.path.exists(_lib.LIB_PATH)
     assert any("libfwn.so" in line for line in open("/proc/self/maps"))
 
