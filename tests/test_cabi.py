@@ -96,7 +96,7 @@ def test_plain_c_program_binds_the_abi(lib, tmp_path):
     exe = _build_c_consumer(tmp_path)
     out = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
-    assert "C ABI ok: version 100" in out.stdout
+    assert "C ABI ok: version 200" in out.stdout
 
 
 @pytest.mark.gpu
