@@ -204,6 +204,38 @@ def test_the_c_sequenced_step_reproduces_the_python_sequenced_reference_bit_for_
             assert torch.equal(a, r), k
 
 
+@pytest.mark.parametrize("cfg,b,t", [
+    (dict(n_block=4, n_flow=2, n_layer=3, hop_size=32, upsample_scales=[4, 8], num_mels=16), 2, 512),
+    ("full6", 2, 1024),
+])
+def test_side_stream_weight_gradients_equal_the_one_stream_call_bit_for_bit(cfg, b, t, monkeypatch):
+    """fwn_train_desc.side_stream moves each block's weight-gradient GEMMs and weight-norm backward to a second stream
+    under the next block's data-gradient chain: same kernels on per-flow copies of the temporaries - same bits; and the
+    block callbacks still arrive last block first, each after its gradients are enqueued on the caller's stream."""
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.hparams import default_hparams
+    from tf_flowavenet_amd.training import GradEngine
+    hp = default_hparams().replace(n_block=6) if cfg == "full6" else small_hparams(**cfg)
+    p = W.synthetic_params(hp, 23, actnorm="random")
+    inp = W.synthetic_inputs(hp, b, t)
+    x, c = torch.from_numpy(inp["x"]).reshape(b, t).cuda(), torch.from_numpy(inp["c"]).cuda()
+    res = {}
+    for side in ("0", "1"):
+        monkeypatch.setenv("FWN_TRAIN_SIDE", side)
+        eng = GradEngine(hp)
+        order = []
+        for rep in range(2):        # the second call reuses the workspace and the event pool
+            order.clear()
+            loss, lp, ld, g = eng.loss_and_grads(p, x, c, on_block_done=order.append)
+            torch.cuda.synchronize()
+        assert order == list(range(hp.n_block - 1, -1, -1)) + [-1]
+        res[side] = (float(loss), float(lp), float(ld), {k: v.clone() for k, v in g.items()})
+    assert res["0"][:3] == res["1"][:3]
+    for k in res["0"][3]:
+        assert torch.equal(res["0"][3][k], res["1"][3][k]), k
+
+
 def test_gradient_is_reproducible_bit_for_bit():
     cfg = dict(n_block=2, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=8)
     _, _, _, (l1, _, _, g1) = _grad_case(cfg, 2, 128, 7)

@@ -9,6 +9,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
+#include <vector>
 
 #include "../../include/fwn.h"
 #include "common.h"
@@ -75,6 +77,27 @@ inline long roundup(long v, long m) { return (v + m - 1) / m * m; }
 inline int dilation_of(int layer) { int d = 1; for (int i = 0; i < layer; ++i) d *= 3; return d; }
 inline int hop_of(const fwn_model_desc* m) { int h = 1; for (int i = 0; i < m->n_up; ++i) h *= m->up_scale[i]; return h; }
 
+// Fork / join markers of the side stream: created on first use (the eager first call), reused by every later call - a
+// recorded call creates nothing.  One pool per host thread and device.
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t next = 0;
+    hipEvent_t get() {
+        if (next == ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ev.push_back(e);
+        }
+        return ev[next++];
+    }
+};
+EventPool* event_pool() {
+    thread_local std::map<int, EventPool> pools;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    return &pools[dev];
+}
+
 struct TnSpec { int kx, n, ntap; };
 inline int tn_group_splits(const TnSpec* sp, int n, int m) {          // training.tn_group_splits
     const int e = fwn_tn_tile(m);
@@ -90,14 +113,17 @@ struct FlowSaved {          // what the training forward keeps of one flow
     void* s_act; void* u_act; float* z; float* part; int nb, p;
 };
 
+struct BwdSet { void* dz; void* du; void* ds; void* dpre[FWN_MAX_LAYERS]; void* dh[FWN_MAX_LAYERS]; void* ya_bf; };
 struct Plan {               // every buffer of one call
     void* cplanes; float* ups[FWN_MAX_UPSAMPLE]; float* planes; float* gplanes; float* dcplanes; float* P;
     float* partial_all; float* out2; float* an_dummy;
     FlowSaved* saved;       // host array, owned by the caller of plan()
     // backward temporaries, sized for the largest block and reused flow after flow
-    void* dz; float* dzz; void* du; void* ds; void* d_all; void* d_o[FWN_MAX_LAYERS]; void* dpre[FWN_MAX_LAYERS];
-    void* dh[FWN_MAX_LAYERS]; void* ya_bf; float* tn_part; double* wn_scratch; double* sg_scratch;
+    float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; double* wn_scratch; double* sg_scratch; double* up_wn;
     void* dyt; void* xt; float* fr_part;
+    // the ones the weight-gradient GEMMs read.  One set without a side stream; with one, a set per (block parity, flow of
+    // the block): block i's weight gradients run on the side stream while the main stream differentiates block i - 1
+    std::vector<BwdSet> sets;
     float* up_dy; float* up_y; float* up_dx[2]; float* up_dwb; float* up_scr; float* up_g3; float* up_dv; float* up_dg3;
     size_t total;
     int npart;
@@ -204,19 +230,27 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
             fr_b = fr_b > fr ? fr_b : fr;
         }
     }
-    pl.dz = b.take(dz_b);
     pl.dzz = (float*)b.take(dzz_b);
-    pl.du = b.take((size_t)mmax * 256 * 2);
-    pl.ds = b.take((size_t)mmax * 256 * 2);
     pl.d_all = b.take((size_t)mmax * L * 256 * 2);
-    for (int l = 0; l < L; ++l) {
-        pl.d_o[l] = b.take((size_t)mmax * 256 * 2);
-        pl.dpre[l] = b.take((size_t)mmax * 512 * 2);
-        pl.dh[l] = b.take((size_t)mmax * 256 * 2);
+    for (int l = 0; l < L; ++l) pl.d_o[l] = b.take((size_t)mmax * 256 * 2);
+    const int nsets = t->side_stream ? 2 * md->n_flow : 1;
+    pl.sets.resize(nsets);
+    for (int k = 0; k < nsets; ++k) {
+        // parity 1 sets serve blocks 1, 3, ..: half the rows of block 0
+        const long mset = (t->side_stream && k >= md->n_flow) ? (mmax + 1) / 2 : mmax;
+        BwdSet& w = pl.sets[k];
+        w.dz = b.take(dz_b);
+        w.du = b.take((size_t)mset * 256 * 2);
+        w.ds = b.take((size_t)mset * 256 * 2);
+        for (int l = 0; l < L; ++l) {
+            w.dpre[l] = b.take((size_t)mset * 512 * 2);
+            w.dh[l] = b.take((size_t)mset * 256 * 2);
+        }
+        w.ya_bf = b.take(ya_b);
     }
-    pl.ya_bf = b.take(ya_b);
     pl.tn_part = (float*)b.take(tn_b);
     pl.wn_scratch = (double*)b.take(wn_b);
+    pl.up_wn = (double*)b.take(1024 * 8);
     pl.sg_scratch = (double*)b.take(sg_b);
     pl.dyt = b.take(dyt_b);
     pl.xt = b.take(xt_b);
@@ -276,8 +310,7 @@ size_t fwn_train_workspace_bytes(const fwn_train_desc* t, int64_t B, int64_t T) 
     if (T % hop_of(md) || T % (1L << md->n_block)) return 0;
     if (md->n_block * md->n_flow > 256) return 0;
     FlowSaved saved[256];
-    Plan pl;
-    memset(&pl, 0, sizeof(pl));
+    Plan pl{};
     pl.saved = saved;
     plan(t, (long)B, (long)T, nullptr, pl);
     return pl.total;
@@ -299,8 +332,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     for (int i = 0; i < md->n_block; ++i)
         TREQUIRE(t->cond_rows[i] && t->front_rows[i] && t->zinv32[i] && t->br[i] && t->zcol[i], "fwn_train_loss_and_grads: missing index table (block %d)", i);
     FlowSaved saved[256];
-    Plan pl;
-    memset(&pl, 0, sizeof(pl));
+    Plan pl{};
     pl.saved = saved;
     plan(t, B, T, workspace, pl);
     if (workspace_bytes < pl.total) return fwn_set_error(FWN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, pl.total);
@@ -371,6 +403,86 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(64), 0, st, pl.out2, t->an_logdet, out3);
 
     // ---------------- backward ----------------
+    // The data gradients of a flow are one dependent chain of small launches; its weight gradients (grouped TN GEMM,
+    // weight-norm backward) hang off that chain and nothing on it waits for them.  With t->side_stream they are deferred
+    // per block: block i's run on the side stream, forked once, under the main stream's chain through block i - 1, and
+    // are joined before on_block_done(i).  Without it they follow their flow on the one stream.
+    hipStream_t side = (hipStream_t)t->side_stream;
+    EventPool* evp = nullptr;
+    if (side) {
+        evp = event_pool();
+        TREQUIRE(evp, "fwn_train_loss_and_grads: hipEventCreate failed");
+        evp->next = 0;
+    }
+    struct Deferred {
+        TnList tn; WnItem wn[4 + 7 * FWN_MAX_LAYERS]; int nwn; long m, ti; int ch, i; bool small_front; const BwdSet* w; const void* dh0;
+        const fwn_flow_train_desc* td;
+    };
+    std::vector<Deferred> pending;        // the flows of the block whose weight gradients are still to be enqueued
+    int pending_block = -1;               // block whose weight gradients run on the side stream, not yet joined
+    auto weight_grads = [&](Deferred& D, hipStream_t s_) -> int {
+        const long m = D.m, ti = D.ti;
+        const int ch = D.ch;
+        TnList& tn = D.tn;
+        if (D.small_front) {       // rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
+            const long mp = roundup(m, 64);
+            const int rows1 = 3 * ch + 1;
+            fwn_transpose_launch(D.dh0, (int)m, 256, 256, 0, 0, 1, 0, pl.dyt, (int)mp, 0, s_);
+            fwn_transpose_launch(D.w->ya_bf, (int)m, ch, ch, -1, 1, 3, (int)ti, pl.xt, (int)mp, 1, s_);
+            const int ns = front_small_nsplit(mp, rows1);
+            Seg a{pl.xt, rows1, (int)mp, (int)mp, 0, 0};
+            fwn_gemm_desc g = gemm_desc(&a, 1, pl.dyt, (int)mp, 256, rows1, 0, pl.fr_part, 256, true);
+            g.nsplit = ns; g.split_stride = (int64_t)rows1 * 256;
+            fwn_gemm_launch(&g, s_);
+            D.wn[D.nwn++] = WnItem{-1, pl.fr_part, ns, (long)rows1 * 256, rows1, 256, &D.td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[D.i], nullptr};
+        }
+        // all weight gradients of the flow: grouped TN GEMM(s), then the grouped weight-norm backward(s)
+        float* part = pl.tn_part;
+        for (int g0 = 0; g0 < tn.n; g0 += FWN_MAX_GROUP) {
+            const int cnt = tn.n - g0 < FWN_MAX_GROUP ? tn.n - g0 : FWN_MAX_GROUP;
+            TnSpec sp[FWN_MAX_GROUP];
+            for (int k = 0; k < cnt; ++k) sp[k] = {tn.job[g0 + k].Kx, tn.job[g0 + k].N, tn.job[g0 + k].ntap};
+            const int ns = tn_group_splits(sp, cnt, (int)m);
+            for (int k = 0; k < cnt; ++k) {
+                fwn_tn_job& q = tn.job[g0 + k];
+                const long size = ((long)q.ntap * q.Kx + 1) * q.N;
+                q.part = part; q.split_stride = size; q.nsplit = ns;
+                part += (size_t)ns * size;
+            }
+            fwn_tn_group_launch(tn.job + g0, cnt, (int)m, (int)ti, s_);
+        }
+        for (int w0 = 0; w0 < D.nwn; w0 += FWN_MAX_GROUP) {
+            const int cnt = D.nwn - w0 < FWN_MAX_GROUP ? D.nwn - w0 : FWN_MAX_GROUP;
+            fwn_wn_job jobs[FWN_MAX_GROUP];
+            for (int k = 0; k < cnt; ++k) {
+                const WnItem& it = D.wn[w0 + k];
+                fwn_wn_job& q = jobs[k];
+                memset(&q, 0, sizeof(q));
+                if (it.tn >= 0) {
+                    const fwn_tn_job& tj = tn.job[it.tn];
+                    q.part = tj.part; q.split_stride = tj.split_stride; q.nsplit = tj.nsplit; q.ldp = tj.N;
+                    q.bias_row = tj.ntap * tj.Kx;
+                } else {
+                    q.part = it.part_direct; q.split_stride = it.part_stride; q.nsplit = it.part_nsplit; q.ldp = it.part_ld;
+                    q.bias_row = it.part_rows - 1;
+                }
+                q.row_src = it.row_src; q.col_src = it.col_src; q.col0 = it.col0; q.K = it.k; q.N = it.n; q.scale = it.scale;
+                q.V = it.c->g ? it.c->V : nullptr; q.g = it.c->g; q.dV = it.c->dV; q.dg = it.c->g ? it.c->dg : nullptr; q.db = it.c->db;
+                TREQUIRE(q.dV && (!q.g || (q.V && q.dg)), "fwn_train_loss_and_grads: block %d: missing gradient / master pointer", D.i);
+            }
+            fwn_wn_group_launch(jobs, cnt, pl.wn_scratch, s_);
+        }
+        return FWN_OK;
+    };
+    // side stream: everything enqueued on `st` so far happens before what `side` gets next
+    auto fork_side = [&]() -> bool {
+        hipEvent_t e = evp->get();
+        return e && hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
+    };
+    auto join_side = [&]() -> bool {
+        hipEvent_t e = evp->get();
+        return e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(st, e, 0) == hipSuccess;
+    };
     // d loss / d z = z / (B T)   (log_p = mean 0.5 (-log 2 pi - z^2))
     hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_of(B * T)), dim3(256), 0, st, pl.gplanes, pl.planes, B * T, (float)(1.0 / (double)(B * T)));
     if (hipMemsetAsync(pl.dcplanes, 0, (size_t)2 * B * T * half * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
@@ -383,6 +495,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             const fwn_flow_desc* d = &md->flows[i * NF + j];
             const fwn_flow_train_desc* td = &t->flows[i * NF + j];
             const FlowSaved& s = saved[i * NF + j];
+            const BwdSet& w = side ? pl.sets[(size_t)(i & 1) * NF + j] : pl.sets[0];
             const int pp = s.p;
             float* xa = pl.planes + (size_t)pp * plane_elems;          // y_a
             float* xb = pl.planes + (size_t)(pp ^ 1) * plane_elems;    // out_b
@@ -391,32 +504,33 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             const void* ca = (const bf16*)pl.cplanes + (size_t)pp * cplane_elems;
             float* dca = pl.dcplanes + (size_t)pp * cplane_elems;
             // coupling
-            if (ldz > 2 * ch && hipMemsetAsync(pl.dz, 0, (size_t)m * ldz * 2, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
-            fwn_ew_coupling_bwd(gb, xb, s.z, td->ez, m * ch, ch, (float)(1.0 / (2.0 * (double)m * ch)), pl.dz, ldz, pl.dzz, st);
+            if (ldz > 2 * ch && hipMemsetAsync(w.dz, 0, (size_t)m * ldz * 2, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
+            fwn_ew_coupling_bwd(gb, xb, s.z, td->ez, m * ch, ch, (float)(1.0 / (2.0 * (double)m * ch)), w.dz, ldz, pl.dzz, st);
             {
-                Seg a{pl.dz, m, ldz, ldz, 0, 0};
-                fwn_gemm_desc g = gemm_desc(&a, 1, td->WzT, ldz, 256, m, 0, pl.du, 256, false);
+                Seg a{w.dz, m, ldz, ldz, 0, 0};
+                fwn_gemm_desc g = gemm_desc(&a, 1, td->WzT, ldz, 256, m, 0, w.du, 256, false);
                 g.mask = s.u_act; g.ldmask = 256;
                 fwn_gemm_launch(&g, st);
             }
-            TnList tn;
-            WnItem wn[4 + 7 * FWN_MAX_LAYERS];
-            int nwn = 0;
+            pending.emplace_back();
+            Deferred& D = pending.back();
+            D.nwn = 0; D.m = m; D.ti = ti; D.ch = ch; D.i = i; D.w = &w; D.td = td;
+            TnList& tn = D.tn;
             auto add_wn = [&](int tnj, const fwn_conv_grad* c, int k, int n, int col0, float scale, const int32_t* row_src, const int32_t* col_src) {
-                wn[nwn++] = WnItem{tnj, nullptr, 0, 0, 0, 0, c, k, n, col0, scale, row_src, col_src};
+                D.wn[D.nwn++] = WnItem{tnj, nullptr, 0, 0, 0, 0, c, k, n, col0, scale, row_src, col_src};
             };
-            add_wn(tn.add(s.u_act, 256, pl.dz, ldz, 256, ldz, 1, 0, 0), &td->zero, 256, 2 * ch, 0, 1.0f, nullptr, t->zinv32[i]);
-            add_wn(tn.add(s.s_act, 256, pl.du, 256, 256, 256, 1, 0, 0), &td->final_, 256, 256, 0, 1.0f, nullptr, nullptr);
+            add_wn(tn.add(s.u_act, 256, w.dz, ldz, 256, ldz, 1, 0, 0), &td->zero, 256, 2 * ch, 0, 1.0f, nullptr, t->zinv32[i]);
+            add_wn(tn.add(s.s_act, 256, w.du, 256, 256, 256, 1, 0, 0), &td->final_, 256, 256, 0, 1.0f, nullptr, nullptr);
             {
-                Seg a{pl.du, m, 256, 256, 0, 0};
-                fwn_gemm_desc g = gemm_desc(&a, 1, td->WfinT, 256, 256, m, 0, pl.ds, 256, false);
+                Seg a{w.du, m, 256, 256, 0, 0};
+                fwn_gemm_desc g = gemm_desc(&a, 1, td->WfinT, 256, 256, m, 0, w.ds, 256, false);
                 g.mask = s.s_act; g.ldmask = 256;
                 fwn_gemm_launch(&g, st);
-                Seg a2{pl.ds, m, 256, 256, 0, 0};
+                Seg a2{w.ds, m, 256, 256, 0, 0};
                 g = gemm_desc(&a2, 1, td->WskipT_all, 256, L * 256, m, 0, pl.d_all, L * 256, false);      // do_l = dS Wskip_l for every layer at once
                 fwn_gemm_launch(&g, st);
             }
-            for (int l = 0; l < L; ++l) add_wn(tn.add(s.o[l], 256, pl.ds, 256, 256, 256, 1, 0, 0), &td->skip[l], 256, 256, 0, 1.0f, nullptr, nullptr);
+            for (int l = 0; l < L; ++l) add_wn(tn.add(s.o[l], 256, w.ds, 256, 256, 256, 1, 0, 0), &td->skip[l], 256, 256, 0, 1.0f, nullptr, nullptr);
             const void* dh_next = nullptr;
             for (int l = L - 1; l >= 0; --l) {
                 const int dil = dilation_of(l);
@@ -436,80 +550,37 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                     if (c.dg && hipMemsetAsync(c.dg, 0, 256 * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
                     if (c.db && hipMemsetAsync(c.db, 0, 256 * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
                 }
-                fwn_ew_gate_bwd(d_ol, ld_do, s.aux[l], m * 256, pl.dpre[l], st);
-                const int jd = tn.add(s.h[l], 256, pl.dpre[l], 512, 256, 512, 3, -dil, dil);
+                fwn_ew_gate_bwd(d_ol, ld_do, s.aux[l], m * 256, w.dpre[l], st);
+                const int jd = tn.add(s.h[l], 256, w.dpre[l], 512, 256, 512, 3, -dil, dil);
                 add_wn(jd, &td->filt[l], 768, 256, 0, 1.0f, nullptr, nullptr);
                 add_wn(jd, &td->gate[l], 768, 256, 256, 1.0f, nullptr, nullptr);
-                const int jc = tn.add(ca, cin, pl.dpre[l], 512, cin, 512, 1, 0, 0);
+                const int jc = tn.add(ca, cin, w.dpre[l], 512, cin, 512, 1, 0, 0);
                 add_wn(jc, &td->filt_c[l], cin, 256, 0, 1.0f, t->cond_rows[i], nullptr);
                 add_wn(jc, &td->gate_c[l], cin, 256, 256, 1.0f, t->cond_rows[i], nullptr);
                 {
-                    Seg a{pl.dpre[l], m, 512, 512, 0, 0};
+                    Seg a{w.dpre[l], m, 512, 512, 0, 0};
                     fwn_gemm_desc g = gemm_desc(&a, 1, td->WcT[l], 512, cin, m, 0, dca, cin, true);
                     g.accumulate = 1;
                     fwn_gemm_launch(&g, st);
                     Seg sg[3];
-                    for (int tap = 0; tap < 3; ++tap) sg[tap] = {pl.dpre[l], m, 512, 512, -(tap - 1) * dil, tap * 512};
-                    g = gemm_desc(sg, 3, td->WdT[l], 1536, 256, m, (int)ti, pl.dh[l], 256, false);
+                    for (int tap = 0; tap < 3; ++tap) sg[tap] = {w.dpre[l], m, 512, 512, -(tap - 1) * dil, tap * 512};
+                    g = gemm_desc(sg, 3, td->WdT[l], 1536, 256, m, (int)ti, w.dh[l], 256, false);
                     if (dh_next) { g.R = dh_next; g.ldr = 256; g.rscale = SQH; }
                     if (l == 0) { g.mask = s.h[0]; g.ldmask = 256; }
                     fwn_gemm_launch(&g, st);
                 }
-                dh_next = pl.dh[l];
+                dh_next = w.dh[l];
             }
             // front conv
-            hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_of(m * ch)), dim3(256), 0, st, (bf16*)pl.ya_bf, xa, m * ch);
-            if (ch % 8 == 0) {
-                add_wn(tn.add(pl.ya_bf, ch, dh_next, 256, ch, 256, 3, -1, 1), &td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[i], nullptr);
-            } else {       // rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
-                const long mp = roundup(m, 64);
-                const int rows1 = 3 * ch + 1;
-                fwn_transpose_launch(dh_next, (int)m, 256, 256, 0, 0, 1, 0, pl.dyt, (int)mp, 0, st);
-                fwn_transpose_launch(pl.ya_bf, (int)m, ch, ch, -1, 1, 3, (int)ti, pl.xt, (int)mp, 1, st);
-                const int ns = front_small_nsplit(mp, rows1);
-                Seg a{pl.xt, rows1, (int)mp, (int)mp, 0, 0};
-                fwn_gemm_desc g = gemm_desc(&a, 1, pl.dyt, (int)mp, 256, rows1, 0, pl.fr_part, 256, true);
-                g.nsplit = ns; g.split_stride = (int64_t)rows1 * 256;
-                fwn_gemm_launch(&g, st);
-                wn[nwn++] = WnItem{-1, pl.fr_part, ns, (long)rows1 * 256, rows1, 256, &td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[i], nullptr};
-            }
-            // all weight gradients of the flow: grouped TN GEMM(s), then the grouped weight-norm backward(s)
-            {
-                float* part = pl.tn_part;
-                for (int g0 = 0; g0 < tn.n; g0 += FWN_MAX_GROUP) {
-                    const int cnt = tn.n - g0 < FWN_MAX_GROUP ? tn.n - g0 : FWN_MAX_GROUP;
-                    TnSpec sp[FWN_MAX_GROUP];
-                    for (int k = 0; k < cnt; ++k) sp[k] = {tn.job[g0 + k].Kx, tn.job[g0 + k].N, tn.job[g0 + k].ntap};
-                    const int ns = tn_group_splits(sp, cnt, (int)m);
-                    for (int k = 0; k < cnt; ++k) {
-                        fwn_tn_job& q = tn.job[g0 + k];
-                        const long size = ((long)q.ntap * q.Kx + 1) * q.N;
-                        q.part = part; q.split_stride = size; q.nsplit = ns;
-                        part += (size_t)ns * size;
-                    }
-                    fwn_tn_group_launch(tn.job + g0, cnt, (int)m, (int)ti, st);
-                }
-                for (int w0 = 0; w0 < nwn; w0 += FWN_MAX_GROUP) {
-                    const int cnt = nwn - w0 < FWN_MAX_GROUP ? nwn - w0 : FWN_MAX_GROUP;
-                    fwn_wn_job jobs[FWN_MAX_GROUP];
-                    for (int k = 0; k < cnt; ++k) {
-                        const WnItem& it = wn[w0 + k];
-                        fwn_wn_job& q = jobs[k];
-                        memset(&q, 0, sizeof(q));
-                        if (it.tn >= 0) {
-                            const fwn_tn_job& tj = tn.job[it.tn];
-                            q.part = tj.part; q.split_stride = tj.split_stride; q.nsplit = tj.nsplit; q.ldp = tj.N;
-                            q.bias_row = tj.ntap * tj.Kx;
-                        } else {
-                            q.part = it.part_direct; q.split_stride = it.part_stride; q.nsplit = it.part_nsplit; q.ldp = it.part_ld;
-                            q.bias_row = it.part_rows - 1;
-                        }
-                        q.row_src = it.row_src; q.col_src = it.col_src; q.col0 = it.col0; q.K = it.k; q.N = it.n; q.scale = it.scale;
-                        q.V = it.c->g ? it.c->V : nullptr; q.g = it.c->g; q.dV = it.c->dV; q.dg = it.c->g ? it.c->dg : nullptr; q.db = it.c->db;
-                        TREQUIRE(q.dV && (!q.g || (q.V && q.dg)), "fwn_train_loss_and_grads: flow (%d,%d): missing gradient / master pointer", i, j);
-                    }
-                    fwn_wn_group_launch(jobs, cnt, pl.wn_scratch, st);
-                }
+            hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_of(m * ch)), dim3(256), 0, st, (bf16*)w.ya_bf, xa, m * ch);
+            D.dh0 = dh_next;
+            D.small_front = ch % 8 != 0;
+            if (!D.small_front)
+                add_wn(tn.add(w.ya_bf, ch, dh_next, 256, ch, 256, 3, -1, 1), &td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[i], nullptr);
+            if (!side) {
+                const int rc = weight_grads(D, st);
+                if (rc != FWN_OK) return rc;
+                pending.clear();
             }
             {
                 Seg sg[3];
@@ -522,7 +593,22 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             TREQUIRE(td->d_an_b && td->d_an_logs && td->d_zscale, "fwn_train_loss_and_grads: flow (%d,%d): missing small gradient pointers", i, j);
             fwn_small_grads_launch(ga, xa, gb, xb, pl.dzz, d->an, m, ch, (const long long*)t->br[i], (const long long*)t->zcol[i], pl.sg_scratch,
                                    td->d_an_b, td->d_an_logs, td->d_zscale, st);
-            if (j == 0 && on_block_done) on_block_done(user, i);
+            if (!side && j == 0 && on_block_done) on_block_done(user, i);
+        }
+        if (side) {
+            // the previous block's weight gradients ran under this block's chain: join them, report that block, then
+            // hand this block's to the side stream
+            if (pending_block >= 0) {
+                TREQUIRE(join_side(), "fwn_train_loss_and_grads: joining the side stream failed");
+                if (on_block_done) on_block_done(user, pending_block);
+            }
+            TREQUIRE(fork_side(), "fwn_train_loss_and_grads: forking the side stream failed");
+            for (size_t k = 0; k < pending.size(); ++k) {
+                const int rc = weight_grads(pending[k], side);
+                if (rc != FWN_OK) return rc;
+            }
+            pending.clear();
+            pending_block = i;
         }
     }
     // up-sampling transposed convolutions (model.py:301-311), last stage first
@@ -545,11 +631,15 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             memset(&q, 0, sizeof(q));
             q.part = pl.up_dwb; q.split_stride = 0; q.nsplit = 1; q.ldp = 3; q.col0 = 0; q.bias_row = -1; q.K = 2 * s_; q.N = 3; q.scale = 1.0f;
             q.V = c.V; q.g = pl.up_g3; q.dV = c.dV; q.dg = pl.up_dg3; q.db = nullptr;
-            fwn_wn_group_launch(&q, 1, pl.wn_scratch, st);
+            fwn_wn_group_launch(&q, 1, pl.up_wn, st);
             hipLaunchKernelGGL(up_finish_kernel, dim3(1), dim3(64), 0, st, pl.up_dg3, pl.up_dwb, s_, c.dg, c.db);
             dy = dx;
             y = xin;
         }
+    }
+    if (side && pending_block >= 0) {       // block 0's weight gradients ran under the up-sampling backward
+        TREQUIRE(join_side(), "fwn_train_loss_and_grads: joining the side stream failed");
+        if (on_block_done) on_block_done(user, pending_block);
     }
     if (on_block_done) on_block_done(user, -1);
     hipError_t e = hipGetLastError();

@@ -11,6 +11,7 @@ arithmetic step runs in ``libfwn.so`` and there is no fallback path (DESIGN.md s
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 from . import _lib
 
@@ -631,7 +632,14 @@ class GradEngine:
                 f.bskip, f.bfin, f.bz, f.ez = (x_.data_ptr() for x_ in tabs)
                 t["_tabs_alive"] = tabs
         td.an_logdet = an_ld.data_ptr()
-        wkey = (B, T, str(dev))
+        # the weight gradients of a block run on a second stream under the next block's chain (fwn.h fwn_train_desc.side_stream)
+        if os.environ.get("FWN_TRAIN_SIDE", "1") != "0":
+            if getattr(self, "_side", None) is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(dev)
+            td.side_stream = self._side.cuda_stream
+        else:
+            td.side_stream = None
+        wkey = (B, T, str(dev), bool(td.side_stream))
         if getattr(self, "_ws_key", None) != wkey:
             need = int(lib.fwn_train_workspace_bytes(C.byref(td), B, T))
             if need == 0:
