@@ -417,6 +417,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     struct Deferred {
         TnList tn; WnItem wn[4 + 7 * FWN_MAX_LAYERS]; int nwn; long m, ti; int ch, i; bool small_front; const BwdSet* w; const void* dh0;
         const fwn_flow_train_desc* td;
+        fwn_gemm_desc dca[FWN_MAX_LAYERS]; int ndca;      // conditioning-gradient GEMMs (accumulate into the mel image: order kept)
     };
     std::vector<Deferred> pending;        // the flows of the block whose weight gradients are still to be enqueued
     int pending_block = -1;               // block whose weight gradients run on the side stream, not yet joined
@@ -424,6 +425,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         const long m = D.m, ti = D.ti;
         const int ch = D.ch;
         TnList& tn = D.tn;
+        for (int k = 0; k < D.ndca; ++k) fwn_gemm_launch(&D.dca[k], s_);
         if (D.small_front) {       // rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
             const long mp = roundup(m, 64);
             const int rows1 = 3 * ch + 1;
@@ -514,7 +516,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             }
             pending.emplace_back();
             Deferred& D = pending.back();
-            D.nwn = 0; D.m = m; D.ti = ti; D.ch = ch; D.i = i; D.w = &w; D.td = td;
+            D.nwn = 0; D.m = m; D.ti = ti; D.ch = ch; D.i = i; D.w = &w; D.td = td; D.ndca = 0;
             TnList& tn = D.tn;
             auto add_wn = [&](int tnj, const fwn_conv_grad* c, int k, int n, int col0, float scale, const int32_t* row_src, const int32_t* col_src) {
                 D.wn[D.nwn++] = WnItem{tnj, nullptr, 0, 0, 0, 0, c, k, n, col0, scale, row_src, col_src};
@@ -561,7 +563,9 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                     Seg a{w.dpre[l], m, 512, 512, 0, 0};
                     fwn_gemm_desc g = gemm_desc(&a, 1, td->WcT[l], 512, cin, m, 0, dca, cin, true);
                     g.accumulate = 1;
-                    fwn_gemm_launch(&g, st);
+                    // nothing in the flow chain reads the conditioning gradient: with a side stream it leaves the chain
+                    if (side) D.dca[D.ndca++] = g;
+                    else fwn_gemm_launch(&g, st);
                     Seg sg[3];
                     for (int tap = 0; tap < 3; ++tap) sg[tap] = {w.dpre[l], m, 512, 512, -(tap - 1) * dil, tap * 512};
                     g = gemm_desc(sg, 3, td->WdT[l], 1536, 256, m, (int)ti, w.dh[l], 256, false);
@@ -611,6 +615,10 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             pending_block = i;
         }
     }
+    if (side && pending_block >= 0) {       // the first block's: the conditioning gradient is complete only now
+        TREQUIRE(join_side(), "fwn_train_loss_and_grads: joining the side stream failed");
+        if (on_block_done) on_block_done(user, pending_block);
+    }
     // up-sampling transposed convolutions (model.py:301-311), last stage first
     hipLaunchKernelGGL(planes_to_rows_kernel, dim3(grid_of(B * T * nmel)), dim3(256), 0, st, pl.dcplanes, (const bf16*)pl.cplanes, B * T, half, pl.up_dy,
                        pl.up_y);
@@ -636,10 +644,6 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             dy = dx;
             y = xin;
         }
-    }
-    if (side && pending_block >= 0) {       // block 0's weight gradients ran under the up-sampling backward
-        TREQUIRE(join_side(), "fwn_train_loss_and_grads: joining the side stream failed");
-        if (on_block_done) on_block_done(user, pending_block);
     }
     if (on_block_done) on_block_done(user, -1);
     hipError_t e = hipGetLastError();
