@@ -398,8 +398,9 @@ typedef struct fwn_train_desc {
     const float* an_logdet;                     /* device scalar: sum over flows of mean_C(3 logs) (model.py:80) */
     int32_t zero_dead_res, reserved;            /* != 0: also zero the gradients of the dead last-layer res_conv */
     /* Optional second hipStream_t (NULL: one stream).  The weight gradients of block i (grouped TN GEMMs + weight-norm
-     * backward) then run on it under the data-gradient chain of block i - 1 and are joined into `stream` before
-     * on_block_done(i); the workspace grows by the per-flow copies of the temporaries they read.  Same results. */
+     * backward) and its conditioning-gradient GEMMs then run on it under the data-gradient chain of block i - 1 and are
+     * joined into `stream` before on_block_done(i); the workspace grows by per-flow copies of the temporaries they
+     * read.  Same results. */
     void* side_stream;
 } fwn_train_desc;
 typedef void (*fwn_block_done_fn)(void* user, int block);

@@ -275,7 +275,7 @@ void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack
                           int scale_ld, hipStream_t st) {
     if (nsjobs > 0)
         hipLaunchKernelGGL(wn_scale_jobs_kernel, dim3(nsjobs, (scale_ld + 31) / 32), dim3(1024), 0, st, sjobs, scales, scale_ld);
-    if (njobs > 0) hipLaunchKernelGGL(pack_jobs_kernel, dim3(njobs, 160), dim3(256), 0, st, jobs, scales, scale_ld);
+    if (njobs > 0) hipLaunchKernelGGL(pack_jobs_kernel, dim3(njobs, FWN_TUNE(FWN_PACK_Y, 160)), dim3(256), 0, st, jobs, scales, scale_ld);
 }
 
 // ---- one Conv2DTranspose(filters=1, kernel (2s,3), strides (s,1), 'same') + LeakyReLU(0.4) --

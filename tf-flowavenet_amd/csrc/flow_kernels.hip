@@ -983,15 +983,6 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 // ---------------------------------------------------------------------------
 // Host-side launchers (called from the C-ABI in api.hip)
 // ---------------------------------------------------------------------------
-// Developer builds (-DFWN_TUNABLE, tools/tune.py) read the dispatch thresholds from the environment once; the product
-// build folds them to the constants below.
-#ifdef FWN_TUNABLE
-#include <stdlib.h>
-static int fwn_tune_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
-#define FWN_TUNE(name, dflt) ([]() -> int { static const int v = fwn_tune_env(#name, dflt); return v; }())
-#else
-#define FWN_TUNE(name, dflt) (dflt)
-#endif
 #ifndef FWN_TAIL256_MIN
 #define FWN_TAIL256_MIN (192 * 256)
 #endif

@@ -1,6 +1,16 @@
 // Internal launcher prototypes shared by the kernel translation units and api.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+// Developer builds (-DFWN_TUNABLE, tools/tune.py) read dispatch thresholds from the environment once; the product
+// build folds them to their defaults.
+#ifdef FWN_TUNABLE
+#include <stdlib.h>
+static inline int fwn_tune_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#define FWN_TUNE(name, dflt) ([]() -> int { static const int v = fwn_tune_env(#name, dflt); return v; }())
+#else
+#define FWN_TUNE(name, dflt) (dflt)
+#endif
+
 
 // h8out (may be NULL): also write the e4m3 copy of the output the fp8 gate reads (front: Ch <= 16 only)
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,

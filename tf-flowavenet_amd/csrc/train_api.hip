@@ -121,8 +121,8 @@ struct Plan {               // every buffer of one call
     // backward temporaries, sized for the largest block and reused flow after flow
     float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; double* wn_scratch; double* sg_scratch; double* up_wn;
     void* dyt; void* xt; float* fr_part;
-    // the ones the weight-gradient GEMMs read.  One set without a side stream; with one, a set per (block parity, flow of
-    // the block): block i's weight gradients run on the side stream while the main stream differentiates block i - 1
+    // the ones the weight-gradient GEMMs read.  One set without a side stream; with one, a set per flow: its weight
+    // gradients run on the side stream while the main stream goes on differentiating
     std::vector<BwdSet> sets;
     float* up_dy; float* up_y; float* up_dx[2]; float* up_dwb; float* up_scr; float* up_g3; float* up_dv; float* up_dg3;
     size_t total;
@@ -233,11 +233,11 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
     pl.dzz = (float*)b.take(dzz_b);
     pl.d_all = b.take((size_t)mmax * L * 256 * 2);
     for (int l = 0; l < L; ++l) pl.d_o[l] = b.take((size_t)mmax * 256 * 2);
-    const int nsets = t->side_stream ? 2 * md->n_flow : 1;
+    // one set per flow with a side stream (a set stays live until its block is joined), sized for the flow's block
+    const int nsets = t->side_stream ? md->n_block * md->n_flow : 1;
     pl.sets.resize(nsets);
     for (int k = 0; k < nsets; ++k) {
-        // parity 1 sets serve blocks 1, 3, ..: half the rows of block 0
-        const long mset = (t->side_stream && k >= md->n_flow) ? (mmax + 1) / 2 : mmax;
+        const long mset = t->side_stream ? B * T / (2L << (k / md->n_flow)) : mmax;
         BwdSet& w = pl.sets[k];
         w.dz = b.take(dz_b);
         w.du = b.take((size_t)mset * 256 * 2);
@@ -404,9 +404,13 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
 
     // ---------------- backward ----------------
     // The data gradients of a flow are one dependent chain of small launches; its weight gradients (grouped TN GEMM,
-    // weight-norm backward) hang off that chain and nothing on it waits for them.  With t->side_stream they are deferred
-    // per block: block i's run on the side stream, forked once, under the main stream's chain through block i - 1, and
-    // are joined before on_block_done(i).  Without it they follow their flow on the one stream.
+    // weight-norm backward) and the conditioning gradient hang off that chain and nothing on it waits for them.  With
+    // t->side_stream they run there, block by block: block i's under the main stream's chain through block i - 1, joined
+    // before on_block_done(i).  Measured alternatives, all slower: handing over flow by flow (every fork / join is a
+    // cross-queue edge), issuing a block's side launches one flow at a time between the next chain's flows, never
+    // joining before the end.  The two queues overlap only partly (tools/diag/train_timeline.py: a chain launch of a few
+    // workgroups waits behind the dispatch of a side kernel that fills the chip - tools/probe/queue_overlap.hip).
+    // Without a side stream they follow their flow on the one stream.
     hipStream_t side = (hipStream_t)t->side_stream;
     EventPool* evp = nullptr;
     if (side) {
@@ -485,6 +489,22 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         hipEvent_t e = evp->get();
         return e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(st, e, 0) == hipSuccess;
     };
+    auto join_pending = [&]() -> bool {      // the block handed over last: join it into `st`, then report it
+        if (pending_block < 0) return true;
+        if (!join_side()) return false;
+        if (on_block_done) on_block_done(user, pending_block);
+        pending_block = -1;
+        return true;
+    };
+    auto hand_over = [&]() -> int {          // fork, then everything in `pending` to the side stream
+        if (!fork_side()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: forking the side stream failed");
+        for (size_t k = 0; k < pending.size() && !FWN_TUNE(FWN_SKIP_WG, 0); ++k) {
+            const int rc = weight_grads(pending[k], side);
+            if (rc != FWN_OK) return rc;
+        }
+        pending.clear();
+        return FWN_OK;
+    };
     // d loss / d z = z / (B T)   (log_p = mean 0.5 (-log 2 pi - z^2))
     hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_of(B * T)), dim3(256), 0, st, pl.gplanes, pl.planes, B * T, (float)(1.0 / (double)(B * T)));
     if (hipMemsetAsync(pl.dcplanes, 0, (size_t)2 * B * T * half * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
@@ -497,7 +517,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             const fwn_flow_desc* d = &md->flows[i * NF + j];
             const fwn_flow_train_desc* td = &t->flows[i * NF + j];
             const FlowSaved& s = saved[i * NF + j];
-            const BwdSet& w = side ? pl.sets[(size_t)(i & 1) * NF + j] : pl.sets[0];
+            const BwdSet& w = side ? pl.sets[(size_t)i * NF + j] : pl.sets[0];
             const int pp = s.p;
             float* xa = pl.planes + (size_t)pp * plane_elems;          // y_a
             float* xb = pl.planes + (size_t)(pp ^ 1) * plane_elems;    // out_b
@@ -598,27 +618,16 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             fwn_small_grads_launch(ga, xa, gb, xb, pl.dzz, d->an, m, ch, (const long long*)t->br[i], (const long long*)t->zcol[i], pl.sg_scratch,
                                    td->d_an_b, td->d_an_logs, td->d_zscale, st);
             if (!side && j == 0 && on_block_done) on_block_done(user, i);
-        }
-        if (side) {
-            // the previous block's weight gradients ran under this block's chain: join them, report that block, then
-            // hand this block's to the side stream
-            if (pending_block >= 0) {
-                TREQUIRE(join_side(), "fwn_train_loss_and_grads: joining the side stream failed");
-                if (on_block_done) on_block_done(user, pending_block);
-            }
-            TREQUIRE(fork_side(), "fwn_train_loss_and_grads: forking the side stream failed");
-            for (size_t k = 0; k < pending.size(); ++k) {
-                const int rc = weight_grads(pending[k], side);
+            if (side && j == 0) {      // this block's weight gradients: under the next block's chain
+                if (!join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");
+                const int rc = hand_over();
                 if (rc != FWN_OK) return rc;
+                pending_block = i;
             }
-            pending.clear();
-            pending_block = i;
         }
     }
-    if (side && pending_block >= 0) {       // the first block's: the conditioning gradient is complete only now
-        TREQUIRE(join_side(), "fwn_train_loss_and_grads: joining the side stream failed");
-        if (on_block_done) on_block_done(user, pending_block);
-    }
+    // the first block's: the conditioning gradient is complete only now
+    if (side && !join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");
     // up-sampling transposed convolutions (model.py:301-311), last stage first
     hipLaunchKernelGGL(planes_to_rows_kernel, dim3(grid_of(B * T * nmel)), dim3(256), 0, st, pl.dcplanes, (const bf16*)pl.cplanes, B * T, half, pl.up_dy,
                        pl.up_y);

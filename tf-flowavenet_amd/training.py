@@ -514,6 +514,16 @@ class GradEngine:
         tp.plan.upload_tables()
 
     # ------------------------------------------------------------------ helpers
+    def _side_stream(self, dev):
+        """The second stream of a step (FWN_TRAIN_SIDE=0: none): each block's weight gradients run on it under the next
+        block's backward chain."""
+        import torch
+        if os.environ.get("FWN_TRAIN_SIDE", "1") == "0":
+            return None
+        if getattr(self, "_side", None) is None:            # an engine serves one device
+            self._side = torch.cuda.Stream(torch.device(dev))
+        return self._side
+
     def _call(self, name, *args):
         _lib.check(getattr(self.lib, name)(*args), name)
 
@@ -633,12 +643,8 @@ class GradEngine:
                 t["_tabs_alive"] = tabs
         td.an_logdet = an_ld.data_ptr()
         # the weight gradients of a block run on a second stream under the next block's chain (fwn.h fwn_train_desc.side_stream)
-        if os.environ.get("FWN_TRAIN_SIDE", "1") != "0":
-            if getattr(self, "_side", None) is None or self._side.device != dev:
-                self._side = torch.cuda.Stream(dev)
-            td.side_stream = self._side.cuda_stream
-        else:
-            td.side_stream = None
+        side = self._side_stream(dev)
+        td.side_stream = side.cuda_stream if side is not None else None
         wkey = (B, T, str(dev), bool(td.side_stream))
         if getattr(self, "_ws_key", None) != wkey:
             need = int(lib.fwn_train_workspace_bytes(C.byref(td), B, T))

@@ -1,0 +1,31 @@
+"""Diagnostic: the step's weight re-packing alone (PackPlan.run_kernels of the full training model): time and bytes."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from tf_flowavenet_amd import weights as W
+from tf_flowavenet_amd.hparams import default_hparams
+from tf_flowavenet_amd.training import Trainer
+
+hp = default_hparams()
+tr = Trainer(hp, W.synthetic_params(hp, 5), device="cuda", graph=False)
+inp = W.synthetic_inputs(hp, 2, 1024)
+x, c = torch.from_numpy(inp["x"]).reshape(2, 1024).cuda(), torch.from_numpy(inp["c"]).cuda()
+tr.ddi(x, c)
+tr.step(x, c)
+plan = tr.engine._tp.plan
+rd = wr = 0
+for (v, sk, sn, out, ld, n_src, kd, nd, slot, trn, mul, late) in plan.jobs:
+    rd += kd * nd * 4
+    wr += kd * nd * 2
+print("jobs", len(plan.jobs), "late", sum(1 for j in plan.jobs if j[-1]), "scale jobs", len(plan.sjobs), "read MB %.0f write MB %.0f" % (rd / 1e6, wr / 1e6))
+def timed(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+t = timed(plan.run_kernels)
+print("run_kernels %.3f ms  -> %.2f TB/s" % (t, (rd + wr) / t / 1e9))

@@ -1,0 +1,48 @@
+"""Diagnostic: per-queue timeline of the LAST training step in a rocprofv3 kernel trace (tools/bench_train.py under
+rocprofv3 --kernel-trace): busy time per queue, overlap, and the gaps of the main queue.
+usage: train_timeline.py <kernel_trace.csv> [out.csv]"""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+print("columns:", list(rows[0].keys()))
+for r in rows:
+    r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+rows.sort(key=lambda r: r["s"])
+# a step starts at each wn_scale_jobs_kernel (first kernel of the packing refresh)
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("wn_scale_jobs_kernel")]
+a, b = starts[-2], starts[-1]
+step = rows[a:b]
+t0 = step[0]["s"]
+print("step: %d kernels, %.3f ms" % (len(step), (step[-1]["e"] - t0) / 1e6))
+qs = collections.defaultdict(list)
+for r in step:
+    qs[r["Queue_Id"]].append(r)
+for q, rs in qs.items():
+    busy = sum(r["e"] - r["s"] for r in rs) / 1e6
+    print("queue %s: %d kernels, busy %.3f ms, first at %.3f, last end %.3f" % (q, len(rs), busy, (rs[0]["s"] - t0) / 1e6, (rs[-1]["e"] - t0) / 1e6))
+main = max(qs.values(), key=len)
+others = [r for q, rs in qs.items() if rs is not main for r in rs]
+# per 1 ms window: main busy, side busy
+T = (step[-1]["e"] - t0) / 1e6
+nb = int(T) + 1
+mb, sb = [0.0] * nb, [0.0] * nb
+def add(arr, r):
+    s, e = (r["s"] - t0) / 1e6, (r["e"] - t0) / 1e6
+    k = int(s)
+    while s < e and k < nb:
+        seg = min(e, k + 1) - s
+        arr[k] += seg
+        s += seg; k += 1
+for r in main: add(mb, r)
+for r in others: add(sb, r)
+print("per-ms window: main busy | side busy")
+for k in range(nb):
+    print("%3d  %.2f  %.2f" % (k, mb[k], sb[k]))
+# largest gaps on the main queue
+gaps = sorted(((main[i + 1]["s"] - main[i]["e"]) / 1e3, (main[i]["e"] - t0) / 1e6, main[i]["Kernel_Name"][:40], main[i + 1]["Kernel_Name"][:40]) for i in range(len(main) - 1))[-12:]
+print("largest main-queue gaps (us, at ms, after, before):")
+for g in gaps:
+    print("  %.1f us at %.3f ms  %s -> %s" % g)
+if len(sys.argv) > 2:
+    with open(sys.argv[2], "w") as f:
+        for r in step:
+            f.write("%s,%s,%.2f,%.2f,%s\n" % (r["Queue_Id"], r["Kernel_Name"].split("(")[0][:50].replace(",", ";"), (r["s"] - t0) / 1e3, (r["e"] - r["s"]) / 1e3, r["Grid_Size_X"]))
