@@ -46,42 +46,52 @@ struct LinProb {
     __device__ float acc_init(int) const { return 0.0f; }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
-        // Branch-free: rows past M and columns past N get an out-of-range buffer offset (loads read 0,
-        // stores are dropped), so the residual / mask / accumulate loads of a tile issue back to back
-        // instead of one dependent load per element.
+        // Branch-free: an absent operand (no residual / mask / accumulate / bias) gets a zero-sized buffer descriptor, rows
+        // past M and columns past N an out-of-range offset - loads read 0, stores are dropped - so the loads of a tile
+        // issue back to back.  (Written as `ptr ? load : 0` every load sat in its own branch behind an s_waitcnt
+        // vmcnt(0): 32 serial round trips per operand, +8 us on a 64 x 128 tile.)
         const int lr = lane & 31;
         const int rbase = mrow0 + 4 * (lane >> 5);
         const srd_t sR = make_srd(g.R ? g.R : g.W, g.R ? (uint32_t)((size_t)g.M * g.ldr * 2) : 0u);
         const srd_t sM = make_srd(g.mask ? g.mask : g.W, g.mask ? (uint32_t)((size_t)g.M * g.ldmask * 2) : 0u);
+        const srd_t sB = make_srd(g.bias ? (const void*)g.bias : g.W, g.bias ? (uint32_t)g.N * 4u : 0u);
         const uint32_t ybytes = (uint32_t)((size_t)g.M * g.ldy * (g.out_f32 ? 4 : 2));
         const srd_t sY = make_srd(g.out_f32 ? (const void*)y32 : (const void*)g.Y, ybytes);
+        const srd_t sYa = make_srd(g.out_f32 ? (const void*)y32 : (const void*)g.Y, (g.out_f32 && g.accumulate) ? ybytes : 0u);
+        const float mdef = g.mask ? 0.0f : 1.0f;                    // no mask: every element passes
+        const float floor_ = g.relu ? 0.0f : -__builtin_inff();
+        const uint32_t ysz = g.out_f32 ? 4u : 2u;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = ncol0 + ni * 32 + lr;
             const bool cok = col < g.N;
-            const float b = (g.bias && cok) ? g.bias[col] : 0.0f;
+            const float b = buf_load_f32(sB, cok ? (uint32_t)col * 4u : FWN_OOB, 0u);
             const uint32_t vR = cok ? (uint32_t)(rbase * g.ldr + col) * 2u : FWN_OOB;
             const uint32_t vM = cok ? (uint32_t)(rbase * g.ldmask + col) * 2u : FWN_OOB;
-            const uint32_t vY = cok ? (uint32_t)(rbase * g.ldy + col) * (g.out_f32 ? 4u : 2u) : FWN_OOB;
+            const uint32_t vY = cok ? (uint32_t)(rbase * g.ldy + col) * ysz : FWN_OOB;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
-                float rv[16], mv[16], yv[16];
+                float rv[16], mv[16], yv[16], out[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = mi * 32 + acc_row_c(r);
-                    rv[r] = g.R ? buf_load_bf16(sR, vR, (uint32_t)(ro * g.ldr * 2)) : 0.0f;
-                    mv[r] = g.mask ? buf_load_bf16(sM, vM, (uint32_t)(ro * g.ldmask * 2)) : 1.0f;
-                    yv[r] = (g.out_f32 && g.accumulate) ? buf_load_f32(sY, vY, (uint32_t)(ro * g.ldy * 4)) : 0.0f;
+                    rv[r] = buf_load_bf16(sR, vR, (uint32_t)(ro * g.ldr * 2));
+                    mv[r] = buf_load_bf16(sM, vM, (uint32_t)(ro * g.ldmask * 2));
+                    yv[r] = buf_load_f32(sYa, vY, (uint32_t)(ro * g.ldy * 4));
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ro = mi * 32 + acc_row_c(r);
                     float v = acc[mi][ni][r] + b + g.rscale * rv[r];
-                    v = mv[r] > 0.0f ? v : 0.0f;
-                    if (g.relu) v = fmaxf(v, 0.0f);
-                    v = v * g.oscale + yv[r];
-                    if (g.out_f32) buf_store_f32(sY, vY, (uint32_t)(ro * g.ldy * 4), v);
-                    else buf_store_bf16(sY, vY, (uint32_t)(ro * g.ldy * 2), v);
+                    v = (mv[r] + mdef) > 0.0f ? v : 0.0f;
+                    v = fmaxf(v, floor_);
+                    out[r] = v * g.oscale + yv[r];
+                }
+                if (g.out_f32) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) buf_store_f32(sY, vY, (uint32_t)((mi * 32 + acc_row_c(r)) * g.ldy * 4), out[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) buf_store_bf16(sY, vY, (uint32_t)((mi * 32 + acc_row_c(r)) * g.ldy * 2), out[r]);
                 }
             }
         }
