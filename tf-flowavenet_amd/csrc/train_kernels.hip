@@ -416,26 +416,59 @@ __global__ __launch_bounds__(256) void wn_group_kernel(const WnGroup grp, double
             // (one memory round trip per split instead of one per row and split); each element still sums its
             // splits in ascending order
             size_t off[8];
-            float d[8];
+            float d[8], v[8];
             bool ok[8];
+            int kk[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = kc * 32 + w + 4 * i;
                 ok[i] = k < q.K;
-                const int kk = ok[i] ? k : q.K - 1;
-                off[i] = (size_t)(q.row_src ? q.row_src[kk] : kk) * q.ldp + sn;
+                kk[i] = ok[i] ? k : q.K - 1;
                 d[i] = 0.0f;
             }
-            for (int s_ = 0; s_ < q.nsplit; ++s_) {
-                const float* ps = q.part + (size_t)s_ * q.split_stride;
+            // one uniform branch per table / operand, not one per load: the loads inside issue back to back
+            if (q.row_src) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) d[i] += ps[off[i]];
+                for (int i = 0; i < 8; ++i) off[i] = (size_t)q.row_src[kk[i]] * q.ldp + sn;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) off[i] = (size_t)kk[i] * q.ldp + sn;
             }
-            float v[8];
+            if (q.g) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kk = min(kc * 32 + w + 4 * i, q.K - 1);
-                v[i] = q.g ? q.V[(size_t)kk * q.N + n] : 0.0f;
+                for (int i = 0; i < 8; ++i) v[i] = q.V[(size_t)kk[i] * q.N + n];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = 0.0f;
+            }
+            // splits four at a time: 32 loads in flight, added in ascending split order as before
+            int s_ = 0;
+            for (; s_ + 4 <= q.nsplit; s_ += 4) {
+                float t[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* ps = q.part + (size_t)(s_ + u) * q.split_stride;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t[u][i] = ps[off[i]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d[i] += t[u][i];
+            }
+            if (s_ < q.nsplit) {        // the last 1..3 splits in one round trip as well
+                float t[3][8];
+                const int rem = q.nsplit - s_;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const float* ps = q.part + (size_t)(s_ + (u < rem ? u : 0)) * q.split_stride;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t[u][i] = ps[off[i]];
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d[i] = u < rem ? d[i] + t[u][i] : d[i];
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
