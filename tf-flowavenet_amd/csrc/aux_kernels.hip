@@ -206,31 +206,39 @@ __global__ __launch_bounds__(1024) void wn_scale_jobs_kernel(const fwn_scale_job
     if (kg == 0 && n < j.n_src)
         scales[(size_t)blockIdx.x * scale_ld + n] = (float)((double)j.g[n] / sqrt(fmax(red[0][nl], 1e-12)));
 }
-__global__ __launch_bounds__(256) void pack_jobs_kernel(const fwn_pack_job* __restrict__ jobs,
-                                                        const float* __restrict__ scales, int scale_ld) {
-    __shared__ float tile[64][65];
-    const fwn_pack_job j = jobs[blockIdx.x];
-    const float* sc = j.scale_slot >= 0 ? scales + (size_t)j.scale_slot * scale_ld : nullptr;
+// Every load is unconditional (indices clamped into range, the result selected afterwards): written as
+// `valid ? v[..] : 0` each load sat in its own branch behind an s_waitcnt vmcnt(0) - one memory round trip per element.
+template <bool HAS_SC>
+__device__ __forceinline__ void pack_job_body(const fwn_pack_job& j, const float* __restrict__ sc, float (*tile)[65], int by, int ny) {
     bf16* out = (bf16*)j.out;
+    const int kmax = j.k_dst - 1, nmax = j.n_dst - 1;
+    // (scale * mul) first, like fwn_pack_bf16 fed a pre-multiplied scale: same bf16 bits
+    // the job's pointers come from a table in memory: tell the compiler they are global (global_load, not flat_load)
+    typedef const __attribute__((address_space(1))) float* gf32;
+    typedef const __attribute__((address_space(1))) int* gi32;
+    const gf32 jv = (gf32)j.v, scg = (gf32)sc;
+    const gi32 jsk = (gi32)j.src_k, jsn = (gi32)j.src_n;
     auto value = [&](int kd, int nd, bool& skip) {
-        const int sk = j.src_k[kd], sn = j.src_n[nd];
-        skip = sn < 0;
-        // (scale * mul) first, like fwn_pack_bf16 fed a pre-multiplied scale: same bf16 bits
-        return (sk >= 0 && sn >= 0) ? j.v[(size_t)sk * j.n_src + sn] * (sc ? sc[sn] * j.mul : j.mul) : 0.0f;
+        const int sk = jsk[min(kd, kmax)], sn = jsn[min(nd, nmax)];
+        skip = sn < 0 || nd > nmax;
+        const int snc = max(sn, 0);
+        const float v = jv[(size_t)max(sk, 0) * j.n_src + snc];
+        const float m = HAS_SC ? scg[snc] * j.mul : j.mul;
+        // a factor, not a select: a select on a loaded value is turned back into a branch around the load
+        const float okf = (sk >= 0 && sn >= 0 && kd <= kmax && nd <= nmax) ? 1.0f : 0.0f;
+        return v * m * okf;
     };
     if (j.transposed) {          // out[k][n], n contiguous like the source: straight through, 4 columns per thread
         const int n4 = (j.n_dst + 3) / 4;
         const long total = (long)j.k_dst * n4;
         const bool vec = (j.ld_dst & 3) == 0 && (((uintptr_t)out) & 7) == 0;
-        for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        for (long i = (long)by * 256 + threadIdx.x; i < total; i += (long)ny * 256) {
             const int kd = (int)(i / n4), nd0 = (int)(i % n4) * 4;
             float v[4];
             bool skip[4], any_skip = false;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                skip[e] = true;
-                v[e] = 0.0f;
-                if (nd0 + e < j.n_dst) v[e] = value(kd, nd0 + e, skip[e]);
+                v[e] = value(kd, nd0 + e, skip[e]);
                 any_skip = any_skip || skip[e];
             }
             bf16* o = out + (size_t)kd * j.ld_dst + nd0;
@@ -251,25 +259,35 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const fwn_pack_job* __re
     // (n fastest) and the bf16 writes (k fastest) are coalesced
     const int tk = (j.k_dst + 63) / 64, tn = (j.n_dst + 63) / 64;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    for (int t = blockIdx.y; t < tk * tn; t += gridDim.y) {
+    for (int t = by; t < tk * tn; t += ny) {
         const int k0 = (t % tk) * 64, n0 = (t / tk) * 64;
         __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < 16; ++r) {
-            const int kd = k0 + ly + 4 * r, nd = n0 + lx;
-            bool skip = true;
-            float val = 0.0f;
-            if (kd < j.k_dst && nd < j.n_dst) val = value(kd, nd, skip);
-            tile[ly + 4 * r][lx] = val;
+        float val[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {      // 16 independent gathers in flight
+            bool skip;
+            val[r] = value(k0 + ly + 4 * r, n0 + lx, skip);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[ly + 4 * r][lx] = val[r];
         __syncthreads();
-#pragma unroll 4
+        // output rows whose source column is -1 belong to another job of the same matrix: left alone
+        int sno[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sno[r] = jsn[min(n0 + ly + 4 * r, nmax)];
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int nd = n0 + ly + 4 * r, kd = k0 + lx;
-            // output rows whose source column is -1 belong to another job of the same matrix: left alone
-            if (kd < j.k_dst && nd < j.n_dst && j.src_n[nd] >= 0) out[(size_t)nd * j.ld_dst + kd] = (bf16)tile[lx][ly + 4 * r];
+            if (kd < j.k_dst && nd < j.n_dst && sno[r] >= 0) out[(size_t)nd * j.ld_dst + kd] = (bf16)tile[lx][ly + 4 * r];
         }
     }
+}
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const fwn_pack_job* __restrict__ jobs,
+                                                        const float* __restrict__ scales, int scale_ld) {
+    __shared__ float tile[64][65];
+    const fwn_pack_job j = jobs[blockIdx.x];
+    if (j.scale_slot >= 0) pack_job_body<true>(j, scales + (size_t)j.scale_slot * scale_ld, tile, blockIdx.y, gridDim.y);
+    else pack_job_body<false>(j, nullptr, tile, blockIdx.y, gridDim.y);
 }
 void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack_job* jobs, int njobs, float* scales,
                           int scale_ld, hipStream_t st) {
