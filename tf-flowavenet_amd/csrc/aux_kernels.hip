@@ -192,11 +192,25 @@ __global__ __launch_bounds__(1024) void wn_scale_jobs_kernel(const fwn_scale_job
     const int n = blockIdx.y * 32 + nl;
     if (blockIdx.y * 32 >= j.n_src) return;
     double s = 0.0;
-    if (n < j.n_src)
-        for (int k = kg; k < j.k_src; k += 32) {
-            const double x = j.v[(size_t)k * j.n_src + n];
+    if (n < j.n_src) {
+        // 16 loads in flight per thread (a conditioning conv of the last block has 320 rows per thread: one dependent
+        // load at a time was a 300 us latency chain); the squares are still added in ascending k
+        typedef const __attribute__((address_space(1))) float* gf32;
+        const gf32 v = (gf32)j.v + n;
+        const size_t ld = (size_t)j.n_src;
+        int k = kg;
+        for (; k + 15 * 32 < j.k_src; k += 16 * 32) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = v[(size_t)(k + 32 * u) * ld];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += (double)x[u] * (double)x[u];
+        }
+        for (; k < j.k_src; k += 32) {
+            const double x = v[(size_t)k * ld];
             s += x * x;
         }
+    }
     red[kg][nl] = s;
     __syncthreads();
     for (int st = 16; st > 0; st >>= 1) {

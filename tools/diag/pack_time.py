@@ -15,10 +15,10 @@ tr.ddi(x, c)
 tr.step(x, c)
 plan = tr.engine._tp.plan
 rd = wr = 0
-for (v, sk, sn, out, ld, n_src, kd, nd, slot, trn, mul, late) in plan.jobs:
+for (v, sk, sn, out, ld, n_src, kd, nd, slot, trn, mul) in plan.jobs:
     rd += kd * nd * 4
     wr += kd * nd * 2
-print("jobs", len(plan.jobs), "late", sum(1 for j in plan.jobs if j[-1]), "scale jobs", len(plan.sjobs), "read MB %.0f write MB %.0f" % (rd / 1e6, wr / 1e6))
+print("jobs", len(plan.jobs), "scale jobs", len(plan.sjobs), "read MB %.0f write MB %.0f" % (rd / 1e6, wr / 1e6))
 def timed(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
