@@ -122,7 +122,14 @@ int fwn_gemm_launch(const fwn_gemm_desc* g, hipStream_t st) {
     else {   // small M: 128-wide K chunks (256-byte LDS rows) - a third less time per unit of K on these latency chains
         int nq128 = 0;
         for (int s = 0; s < g->nseg; ++s) nq128 += (g->seg[s].k + 127) / 128;
-        hipLaunchKernelGGL((lin_kernel<64, 128, 2, 2, 3, 1, 128>), dim3(((M + 63) / 64) * n128, 1, ns), dim3(256), 0, st, p, n128, nq128);
+        // A workgroup streams (BM + BN) K 2 bytes through ONE CU at ~50 GB/s: a launch of a few dozen 64 x 128 tiles is
+        // bound by that, not by the chip.  Below FWN_LIN_TINY such workgroups, 32 x 64 tiles (4-way split-K inside the
+        // workgroup): four times the CUs, half the bytes each.
+        if (((M + 63) / 64) * n128 * ns < FWN_TUNE(FWN_LIN_TINY, 40)) {
+            const int n64 = (g->N + 63) / 64;
+            hipLaunchKernelGGL((lin_kernel<32, 64, 1, 1, 6, 4, 128>), dim3(((M + 31) / 32) * n64, 1, ns), dim3(256), 0, st, p, n64, nq128);
+        } else
+            hipLaunchKernelGGL((lin_kernel<64, 128, 2, 2, 3, 1, 128>), dim3(((M + 63) / 64) * n128, 1, ns), dim3(256), 0, st, p, n128, nq128);
     }
     return 0;
 }

@@ -41,5 +41,23 @@ int main() {
         snprintf(nm, sizeof nm, "A || B persistent %d WGs", nwg);
         timeit(nm, [&]() { runB_pers(nwg); runA(); });
     }
+    // the same two chains as parallel branches of ONE hipGraph (the recorded training step): does replay overlap them?
+    for (int order = 0; order < 3; ++order) {
+        hipGraph_t graph; hipGraphExec_t exec;
+        hipEvent_t e0, e1; hipEventCreateWithFlags(&e0, hipEventDisableTiming); hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+        hipStreamBeginCapture(a, hipStreamCaptureModeThreadLocal);
+        hipEventRecord(e0, a); hipStreamWaitEvent(b, e0, 0);
+        if (order == 0) { runB_big(); runA(); }
+        else if (order == 1) { runA(); runB_big(); }
+        else for (int i = 0; i < NB; ++i) {          // interleaved: 1 B launch per 10 A launches
+            hipLaunchKernelGGL(spin_kernel, dim3(4096), dim3(256), 0, b, p, 4000);
+            for (int k = 0; k < NA / NB; ++k) hipLaunchKernelGGL(spin_kernel, dim3(16), dim3(256), 0, a, p, 1500);
+        }
+        hipEventRecord(e1, b); hipStreamWaitEvent(a, e1, 0);
+        hipStreamEndCapture(a, &graph);
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        const char* names[3] = {"graph: B recorded first", "graph: A recorded first", "graph: interleaved recording"};
+        timeit(names[order], [&]() { hipGraphLaunch(exec, a); });
+    }
     return 0;
 }
