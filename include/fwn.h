@@ -222,7 +222,11 @@ int fwn_clip_adam_dev(float* w, const float* g, float* m, float* v, int64_t n, c
  * mask: keep where mask[row][col] > 0 (the ReLU derivative from a stored activation).
  * Output bf16 [M][ldy], or fp32 (out_f32; accumulate: +=).  nsplit > 1 (fp32 only, no bias / R / mask):
  * the K chunks are split over nsplit partial outputs Y + z*split_stride, to be summed by
- * fwn_reduce_splits (fixed order: deterministic). */
+ * fwn_reduce_splits (fixed order: deterministic).
+ * gate_aux != NULL (bf16 output only): the 256 output columns from gate_col0 (a multiple of 256) are a gradient d with
+ * respect to a gated layer's output o = tanh(f) sigmoid(g); they are not stored in Y but, rounded to bf16 like Y, go
+ * through the gate's derivative with gate_aux = [tanh f | sigmoid g] (bf16 [M][512], kept by fwn_gate_train):
+ * gate_out[M][512] (bf16) = [d sg (1 - tf^2) | d tf sg (1 - sg)] - what fwn_gate_bwd computes from a stored d. */
 #define FWN_GEMM_MAXSEG 8
 typedef struct fwn_gemm_seg { const void* x; int32_t rows, ld, k, shift, koff, pad_; } fwn_gemm_seg;
 typedef struct fwn_gemm_desc {
@@ -235,7 +239,8 @@ typedef struct fwn_gemm_desc {
     void* Y;            int32_t ldy;    int32_t out_f32;
     int32_t accumulate, nsplit;
     int64_t split_stride;
-    float oscale;       int32_t pad1_;
+    float oscale;       int32_t gate_col0;
+    const void* gate_aux; void* gate_out;
 } fwn_gemm_desc;
 int fwn_gemm(const fwn_gemm_desc* g, void* stream);
 /* For tap z < ntap (shift = shift0 + z*dshift): dst[z*C + c][m] = src[m + shift][c] (zero where the tap

@@ -124,7 +124,8 @@ class GemmDesc(C.Structure):
                 ("Y", C.c_void_p), ("ldy", C.c_int32), ("out_f32", C.c_int32),
                 ("accumulate", C.c_int32), ("nsplit", C.c_int32),
                 ("split_stride", C.c_int64),
-                ("oscale", C.c_float), ("pad1_", C.c_int32)]
+                ("oscale", C.c_float), ("gate_col0", C.c_int32),
+                ("gate_aux", C.c_void_p), ("gate_out", C.c_void_p)]
 
 
 SIGNATURES = {

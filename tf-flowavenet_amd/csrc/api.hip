@@ -375,6 +375,9 @@ int fwn_gemm(const fwn_gemm_desc* g, void* stream) {
     REQUIRE(g->nsplit == 1 || (g->out_f32 && !g->bias && !g->R && !g->mask && !g->relu && !g->accumulate),
             "fwn_gemm: split-K writes plain fp32 partials");
     REQUIRE(!g->accumulate || g->out_f32, "fwn_gemm: accumulate needs an fp32 output");
+    REQUIRE(!g->gate_aux || (g->gate_out && !g->out_f32 && g->gate_col0 >= 0 && g->gate_col0 % 256 == 0 && g->gate_col0 + 256 <= g->N &&
+                             (int64_t)g->M * 512 * 2 < ((int64_t)1 << 31)),
+            "fwn_gemm: gate_aux needs gate_out, a bf16 output and 256 columns from gate_col0 (a multiple of 256) inside N");
     fwn_gemm_launch(g, (hipStream_t)stream);
     return check_launch("fwn_gemm");
 }

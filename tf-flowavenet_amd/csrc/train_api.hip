@@ -550,6 +550,8 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 fwn_gemm_launch(&g, st);
                 Seg a2{w.ds, m, 256, 256, 0, 0};
                 g = gemm_desc(&a2, 1, td->WskipT_all, 256, L * 256, m, 0, pl.d_all, L * 256, false);      // do_l = dS Wskip_l for every layer at once
+                // the last layer's do is complete here: its gate derivative rides this epilogue (no store + fwn_gate_bwd)
+                g.gate_aux = s.aux[L - 1]; g.gate_out = w.dpre[L - 1]; g.gate_col0 = (L - 1) * 256;
                 fwn_gemm_launch(&g, st);
             }
             for (int l = 0; l < L; ++l) add_wn(tn.add(s.o[l], 256, w.ds, 256, 256, 256, 1, 0, 0), &td->skip[l], 256, 256, 0, 1.0f, nullptr, nullptr);
@@ -563,16 +565,14 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                     Seg a{dh_next, m, 256, 256, 0, 0};
                     fwn_gemm_desc g = gemm_desc(&a, 1, td->WresT[l], 256, 256, m, 0, pl.d_o[l], 256, false);
                     g.R = d_ol; g.ldr = ld_do; g.rscale = (float)(1.0 / 0.7071067811865476); g.oscale = SQH;
+                    g.gate_aux = s.aux[l]; g.gate_out = w.dpre[l]; g.gate_col0 = 0;      // do_l goes straight through the gate derivative
                     fwn_gemm_launch(&g, st);
-                    d_ol = pl.d_o[l];
-                    ld_do = 256;
                 } else if (t->zero_dead_res) {      // dead res_conv of the last layer (modules.py:126-128): zero gradients
                     const fwn_conv_grad& c = td->res[l];
                     if (c.dV && hipMemsetAsync(c.dV, 0, (size_t)256 * 256 * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
                     if (c.dg && hipMemsetAsync(c.dg, 0, 256 * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
                     if (c.db && hipMemsetAsync(c.db, 0, 256 * 4, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
                 }
-                fwn_ew_gate_bwd(d_ol, ld_do, s.aux[l], m * 256, w.dpre[l], st);
                 const int jd = tn.add(s.h[l], 256, w.dpre[l], 512, 256, 512, 3, -dil, dil);
                 add_wn(jd, &td->filt[l], 768, 256, 0, 1.0f, nullptr, nullptr);
                 add_wn(jd, &td->gate[l], 768, 256, 256, 1.0f, nullptr, nullptr);

@@ -58,6 +58,8 @@ struct LinProb {
         const uint32_t ybytes = (uint32_t)((size_t)g.M * g.ldy * (g.out_f32 ? 4 : 2));
         const srd_t sY = make_srd(g.out_f32 ? (const void*)y32 : (const void*)g.Y, ybytes);
         const srd_t sYa = make_srd(g.out_f32 ? (const void*)y32 : (const void*)g.Y, (g.out_f32 && g.accumulate) ? ybytes : 0u);
+        const uint32_t gbytes = g.gate_aux ? (uint32_t)((size_t)g.M * 512 * 2) : 0u;
+        const srd_t sGa = make_srd(g.gate_aux ? g.gate_aux : g.W, gbytes), sGo = make_srd(g.gate_aux ? (const void*)g.gate_out : g.W, gbytes);
         const float mdef = g.mask ? 0.0f : 1.0f;                    // no mask: every element passes
         const float floor_ = g.relu ? 0.0f : -__builtin_inff();
         const uint32_t ysz = g.out_f32 ? 4u : 2u;
@@ -69,6 +71,10 @@ struct LinProb {
             const uint32_t vR = cok ? (uint32_t)(rbase * g.ldr + col) * 2u : FWN_OOB;
             const uint32_t vM = cok ? (uint32_t)(rbase * g.ldmask + col) * 2u : FWN_OOB;
             const uint32_t vY = cok ? (uint32_t)(rbase * g.ldy + col) * ysz : FWN_OOB;
+            // the 32 columns of this group lie inside or outside the gated range together (gate_col0 is a multiple of 256)
+            const int c0 = ncol0 + ni * 32 - g.gate_col0;
+            const bool gated = g.gate_aux && c0 >= 0 && c0 < 256;
+            const uint32_t vG = cok ? (uint32_t)(rbase * 512 + c0 + lr) * 2u : FWN_OOB;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 float rv[16], mv[16], yv[16], out[16];
@@ -89,6 +95,23 @@ struct LinProb {
                 if (g.out_f32) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) buf_store_f32(sY, vY, (uint32_t)((mi * 32 + acc_row_c(r)) * g.ldy * 4), out[r]);
+                } else if (gated) {
+                    // the gate's derivative instead of a store + fwn_gate_bwd: d (rounded to bf16 as it would have been
+                    // stored) times the kept factors; same expressions as gate_bwd_kernel
+                    float tf[16], sg[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t ro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 2);
+                        tf[r] = buf_load_bf16(sGa, vG, ro);
+                        sg[r] = buf_load_bf16(sGa, vG, ro + 512u);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t ro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 2);
+                        const float d = (float)(bf16)out[r];
+                        buf_store_bf16(sGo, vG, ro, d * sg[r] * (1.0f - tf[r] * tf[r]));
+                        buf_store_bf16(sGo, vG, ro + 512u, d * tf[r] * sg[r] * (1.0f - sg[r]));
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) buf_store_bf16(sY, vY, (uint32_t)((mi * 32 + acc_row_c(r)) * g.ldy * 2), out[r]);

@@ -18,9 +18,15 @@ __global__ void spin_persistent(float* p, int iters, int total) {
     }
 }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int main() {
+int main(int argc, char**) {
     float* p; hipMalloc(&p, 4096); hipMemset(p, 0, 4096);
-    hipStream_t a, b; hipStreamCreateWithFlags(&a, hipStreamNonBlocking); hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+    hipStream_t a, b;
+    int least = 0, greatest = 0;
+    hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const bool prio = argc > 1;       // any argument: the chain's stream gets the highest priority, the big grids the lowest
+    printf("stream priority range: least %d greatest %d; %s\n", least, greatest, prio ? "A high / B low" : "default priorities");
+    if (prio) { hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest); hipStreamCreateWithPriority(&b, hipStreamNonBlocking, least); }
+    else { hipStreamCreateWithFlags(&a, hipStreamNonBlocking); hipStreamCreateWithFlags(&b, hipStreamNonBlocking); }
     const int NA = 600, NB = 60;
     auto runA = [&]() { for (int i = 0; i < NA; ++i) hipLaunchKernelGGL(spin_kernel, dim3(16), dim3(256), 0, a, p, 1500); };
     auto runB_big = [&]() { for (int i = 0; i < NB; ++i) hipLaunchKernelGGL(spin_kernel, dim3(4096), dim3(256), 0, b, p, 4000); };
