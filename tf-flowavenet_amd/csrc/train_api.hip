@@ -526,8 +526,8 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             const void* ca = (const bf16*)pl.cplanes + (size_t)pp * cplane_elems;
             float* dca = pl.dcplanes + (size_t)pp * cplane_elems;
             // coupling
-            if (ldz > 2 * ch && hipMemsetAsync(w.dz, 0, (size_t)m * ldz * 2, st) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "hipMemsetAsync failed");
-            fwn_ew_coupling_bwd(gb, xb, s.z, td->ez, m * ch, ch, (float)(1.0 / (2.0 * (double)m * ch)), w.dz, ldz, pl.dzz, st);
+            // (also: the bf16 copy of y_a for the front conv's weight gradient, and the zero padding of dZ's rows)
+            fwn_ew_coupling_bwd_ex(gb, xb, s.z, td->ez, m * ch, ch, (float)(1.0 / (2.0 * (double)m * ch)), w.dz, ldz, pl.dzz, xa, w.ya_bf, st);
             {
                 Seg a{w.dz, m, ldz, ldz, 0, 0};
                 fwn_gemm_desc g = gemm_desc(&a, 1, td->WzT, ldz, 256, m, 0, w.du, 256, false);
@@ -596,7 +596,6 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 dh_next = w.dh[l];
             }
             // front conv
-            hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_of(m * ch)), dim3(256), 0, st, (bf16*)w.ya_bf, xa, m * ch);
             D.dh0 = dh_next;
             D.small_front = ch % 8 != 0;
             if (!D.small_front)
