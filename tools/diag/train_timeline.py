@@ -46,3 +46,13 @@ if len(sys.argv) > 2:
     with open(sys.argv[2], "w") as f:
         for r in step:
             f.write("%s,%s,%.2f,%.2f,%s\n" % (r["Queue_Id"], r["Kernel_Name"].split("(")[0][:50].replace(",", ";"), (r["s"] - t0) / 1e3, (r["e"] - r["s"]) / 1e3, r["Grid_Size_X"]))
+# phases of the step (main markers)
+def first(name, after=0):
+    for r in step:
+        if r["Kernel_Name"].startswith(name) and (r["s"] - t0) / 1e6 >= after:
+            return (r["s"] - t0) / 1e6
+    return float("nan")
+tp, tf = first("pack_jobs_kernel"), first("upsample_kernel")
+tl, tb, to = first("prior_kernel"), first("(anonymous namespace)::planes_to_rows_kernel"), first("sqnorm_partial_kernel")
+print("phases (ms): refresh+pack 0-%.2f | forward %.2f-%.2f | backward %.2f-%.2f | up-sampling bwd + optimiser %.2f-%.2f" % (tf, tf, tl, tl, tb, tb, T))
+print("   optimiser starts at %.2f" % to)
