@@ -48,6 +48,28 @@ def test_gemm_conv_like_with_epilogue(m, ti):
     assert err.max() < 0.05 * max(1.0, np.abs(want).max()) and err.mean() < 4e-3 * max(1.0, np.abs(want).mean())
 
 
+@pytest.mark.parametrize("m", [300, 5000, 30000])      # the 32 x 64, 64 x 128 and 256 x 128 tiles
+def test_gemm_gate_derivative_epilogue_equals_store_then_gate_bwd(m):
+    """fwn_gemm_desc.gate_aux: the 256 output columns from gate_col0 leave through the gate's derivative instead of being
+    stored - bit for bit what storing them and running fwn_gate_bwd gives; the other columns are stored as always."""
+    rng = np.random.default_rng(m)
+    x = bf(rng.standard_normal((m, 256)) * 0.5)
+    w = bf(rng.standard_normal((512, 256)) * 0.05)
+    res = bf(rng.standard_normal((m, 512)))
+    aux = bf(np.concatenate([np.tanh(rng.standard_normal((m, 256))), 1 / (1 + np.exp(-rng.standard_normal((m, 256))))], 1))
+    plain = TR.gemm([(x, 256, 0, 0)], w, 512, m, res=res, rscale=0.5, oscale=0.7)
+    want = torch.empty(m, 512, dtype=torch.bfloat16, device="cuda")
+    TR._lib.check(TR._lib.load().fwn_gate_bwd(plain[:, 256:].data_ptr(), 512, aux.data_ptr(), m, want.data_ptr(), None), "fwn_gate_bwd")
+    out = torch.full((m, 512), 3.0, dtype=torch.bfloat16, device="cuda")
+    dpre = torch.empty(m, 512, dtype=torch.bfloat16, device="cuda")
+    TR.gemm([(x, 256, 0, 0)], w, 512, m, res=res, rscale=0.5, oscale=0.7, out=out, gate=(aux, dpre, 256))
+    torch.cuda.synchronize()
+    assert torch.equal(dpre, want)
+    assert torch.equal(out[:, :256], plain[:, :256]) and bool((out[:, 256:] == 3.0).all())
+    with pytest.raises(RuntimeError):
+        TR.gemm([(x, 256, 0, 0)], w, 512, m, gate=(aux, dpre, 384))
+
+
 def test_gemm_fp32_accumulate_and_padding_columns_untouched():
     rng = np.random.default_rng(1)
     m, n = 700, 40

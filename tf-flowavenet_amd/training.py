@@ -26,10 +26,12 @@ def _stream(t):
 
 
 def gemm(segs, w, n, m, *, ti=0, bias=None, res=None, rscale=1.0, mask=None, relu=False, oscale=1.0,
-         out=None, out_f32=False, accumulate=False, nsplit=1, split_stride=0):
+         out=None, out_f32=False, accumulate=False, nsplit=1, split_stride=0, gate=None):
     """``out[m, n] = oscale * relu?(mask?(sum_s shift(x_s)[:, :k_s] @ w[:, koff_s:koff_s+k_s].T + bias + rscale*res))``.
 
-    segs: list of ``(x, k, shift, koff)`` with ``x`` a bf16 2-D tensor (rows, ld); ``w`` bf16 (n, ldw)."""
+    segs: list of ``(x, k, shift, koff)`` with ``x`` a bf16 2-D tensor (rows, ld); ``w`` bf16 (n, ldw).
+    gate: ``(aux, dpre, col0)`` - the 256 output columns from ``col0`` go through the gate derivative into ``dpre``
+    (bf16 [m, 512]) instead of ``out`` (fwn.h ``fwn_gemm_desc.gate_aux``)."""
     import torch
     lib = _lib.load()
     d = _lib.GemmDesc()
@@ -54,6 +56,12 @@ def gemm(segs, w, n, m, *, ti=0, bias=None, res=None, rscale=1.0, mask=None, rel
     d.Y, d.ldy = out.data_ptr(), int(out.stride(-2))
     d.out_f32, d.accumulate, d.nsplit = int(out.dtype == torch.float32), int(bool(accumulate)), int(nsplit)
     d.split_stride = int(split_stride or (out.stride(0) if nsplit > 1 else 0))
+    if gate is not None:
+        aux, dpre, col0 = gate
+        if aux.dtype != torch.bfloat16 or dpre.dtype != torch.bfloat16 or tuple(aux.shape) != (m, 512) or tuple(dpre.shape) != (m, 512) \
+                or not (aux.is_contiguous() and dpre.is_contiguous()):
+            raise ValueError("gate: aux and dpre must be contiguous bf16 (m, 512)")
+        d.gate_aux, d.gate_out, d.gate_col0 = aux.data_ptr(), dpre.data_ptr(), int(col0)
     _lib.check(lib.fwn_gemm(C.byref(d), _stream(w)), "fwn_gemm")
     return out
 
