@@ -109,7 +109,8 @@ def loss_and_grads(self, tp, params, x, c):
             h = [b16(m, 256) for _ in range(L)]
             o = [b16(m, 256) for _ in range(L)]
             aux = [b16(m, 512) for _ in range(L)]
-            self._call("fwn_front", C.byref(d), xa.data_ptr(), h[0].data_ptr(), None, m, ti, 0, st)
+            scr = torch.empty(m * 2 * ch, dtype=torch.bfloat16, device=dev) if ch >= 32 else None      # (hi | lo) image: ring-GEMM front
+            self._call("fwn_front", C.byref(d), xa.data_ptr(), h[0].data_ptr(), scr.data_ptr() if scr is not None else None, m, ti, 0, st)
             for l in range(L):
                 self._call("fwn_gate_train", C.byref(d), l, h[l].data_ptr(), ca.data_ptr() if P is None else None,
                            P[j, l].data_ptr() if P is not None else None, o[l].data_ptr(), aux[l].data_ptr(), m, ti, st)

@@ -119,7 +119,7 @@ struct Plan {               // every buffer of one call
     float* partial_all; float* out2; float* an_dummy;
     FlowSaved* saved;       // host array, owned by the caller of plan()
     // backward temporaries, sized for the largest block and reused flow after flow
-    float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; double* wn_scratch; double* sg_scratch; double* up_wn;
+    void* xhl; float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; double* wn_scratch; double* sg_scratch; double* up_wn;
     void* dyt; void* xt; float* fr_part;
     // the ones the weight-gradient GEMMs read.  One set without a side stream; with one, a set per flow: its weight
     // gradients run on the side stream while the main stream goes on differentiating
@@ -230,6 +230,7 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
             fr_b = fr_b > fr ? fr_b : fr;
         }
     }
+    pl.xhl = b.take((size_t)B * T * 2);        // front conv of the blocks with Ch >= 32: bf16 (hi | lo) image of the plane
     pl.dzz = (float*)b.take(dzz_b);
     pl.d_all = b.take((size_t)mmax * L * 256 * 2);
     for (int l = 0; l < L; ++l) pl.d_o[l] = b.take((size_t)mmax * 256 * 2);
@@ -373,7 +374,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             float* xb = pl.planes + (size_t)(p ^ 1) * plane_elems;
             const void* ca = (const bf16*)pl.cplanes + (size_t)p * cplane_elems;
             fwn_ew_actnorm_fwd2(xa, xb, d->an, m * ch, ch, st);
-            fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, s.h[0], nullptr, (int)m, (int)ti, ch, d->kfpad, 0, nullptr, st);
+            fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, s.h[0], ch >= 32 ? pl.xhl : nullptr, (int)m, (int)ti, ch, d->kfpad, 0, nullptr, st);
             for (int l = 0; l < L; ++l) {
                 const float* Pl = hoist ? pl.P + ((size_t)j * L + l) * m * 512 : nullptr;
                 fwn_launch_gate(s.h[l], hoist ? nullptr : ca, Pl, d->Wd[l], d->Wc[l], d->bgate[l], s.o[l], (int)m, (int)ti, dilation_of(l), d->cin,
