@@ -690,17 +690,26 @@ __global__ __launch_bounds__(256) void up_dw_kernel(const float* __restrict__ dp
     const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
     double acc = 0.0;
     if (tap < ntap) {
+        // the chunk's (row, w) pairs flattened over the threads, four independent pairs in flight per thread; addresses
+        // clamped and validity applied as a factor (a branch per load would serialise the round trips)
         const int k = tap / 3, kw = tap % 3;
-        for (long r = r0; r < r1; ++r) {
-            const int i = (int)(r % H), b = (int)(r / H);
-            const int tau = i * s + k - s / 2;
-            if (tau < 0 || tau >= H * s) continue;
-            const float* drow = dpre + ((long)b * H * s + tau) * W;
-            const float* xrow = x + r * W;
-            for (int w = threadIdx.x; w < W; w += 256) {
-                const int ww = w + kw - 1;
-                if (ww >= 0 && ww < W) acc += (double)xrow[w] * (double)drow[ww];
+        const long n = (r1 - r0) * W;
+        for (long e0 = threadIdx.x; e0 < n; e0 += 4 * 256) {
+            float xv[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long e = min(e0 + 256L * u, n - 1);
+                const long r = r0 + e / W;
+                const int w = (int)(e % W), ww = w + kw - 1;
+                const int i = (int)(r % H), b = (int)(r / H);
+                const int tau = i * s + k - s / 2;
+                const bool ok = e0 + 256L * u < n && tau >= 0 && tau < H * s && ww >= 0 && ww < W;
+                const long dj = ((long)b * H * s + min(max(tau, 0), H * s - 1)) * W + min(max(ww, 0), W - 1);
+                xv[u] = x[r * W + w] * (ok ? 1.0f : 0.0f);
+                dv[u] = dpre[dj];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (double)xv[u] * (double)dv[u];
         }
     } else {
         const long e0 = r0 * s * W, e1 = r1 * s * W;

@@ -56,3 +56,11 @@ tp, tf = first("pack_jobs_kernel"), first("upsample_kernel")
 tl, tb, to = first("prior_kernel"), first("(anonymous namespace)::planes_to_rows_kernel"), first("sqnorm_partial_kernel")
 print("phases (ms): refresh+pack 0-%.2f | forward %.2f-%.2f | backward %.2f-%.2f | up-sampling bwd + optimiser %.2f-%.2f" % (tf, tf, tl, tl, tb, tb, T))
 print("   optimiser starts at %.2f" % to)
+# kernel time of THIS step by name (the whole-trace summaries include the one-off setup launches)
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in step:
+    k = r["Kernel_Name"].split("(")[0][:64]
+    agg[k][0] += 1; agg[k][1] += (r["e"] - r["s"]) / 1e3
+print("last step: %d launches, %.2f ms of kernel time" % (len(step), sum(v[1] for v in agg.values()) / 1e3))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+    print("%8.1f us %4d x %7.2f us  %s" % (v[1], v[0], v[1] / v[0], k))
