@@ -376,13 +376,12 @@ __global__ __launch_bounds__(256) void flow_small_grads_final_kernel(const doubl
                                                                      float* __restrict__ dlogs, float* __restrict__ dzscale) {
     for (int idx = threadIdx.x; idx < 6 * Ch; idx += 256) {
         double a = 0.0;
-        for (int b0 = 0; b0 < nb; b0 += 8) {          // 8 loads in flight, added in block order
-            double v[8];
+        for (int b0 = 0; b0 < nb; b0 += 16) {         // 16 loads in flight, added in block order
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(b0 + u, nb - 1) * 6 * Ch + idx];
+            for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)min(b0 + u, nb - 1) * 6 * Ch + idx];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (b0 + u < nb) a += v[u];
+            for (int u = 0; u < 16; ++u) a += b0 + u < nb ? v[u] : 0.0;
         }
         if (idx < 4 * Ch) {
             const int role = idx / (2 * Ch), which = (idx / Ch) & 1, c = idx % Ch;
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(256) void flow_small_grads_final_kernel(const doubl
     }
 }
 int fwn_small_grads_blocks(long M, int Ch) {
-    long nb = M * Ch / 1024;          // few passes of a workgroup over its rows (a latency chain, not bytes); the final
+    long nb = M * Ch / 512;           // two passes of a workgroup over its rows (a latency chain, not bytes); the final
     return (int)(nb < 1 ? 1 : nb > 96 ? 96 : nb);      // pass adds the blocks serially: keep them few
 }
 void fwn_small_grads_launch(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
