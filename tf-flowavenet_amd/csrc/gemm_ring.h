@@ -50,6 +50,15 @@ struct RingGeom {
 
 #define FWN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+#ifdef FWN_STAMP      // tools/probe/lin_stamps.hip: s_memtime per wave of workgroup 0: [chunk][before wait | after wait | after barrier | after MFMAs]
+__device__ unsigned long long fwn_ring_stamps[16 * 64 * 4 + 64];
+#define FWN_RING_STAMP(q, k) do { if (blockIdx.x == 0 && blockIdx.z == 0 && (q) < 64 && lane == 0) fwn_ring_stamps[((wave) * 64 + (q)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FWN_RING_STAMP_X(i) do { if (blockIdx.x == 0 && blockIdx.z == 0 && lane == 0) fwn_ring_stamps[16 * 64 * 4 + (wave) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FWN_RING_STAMP(q, k)
+#define FWN_RING_STAMP_X(i)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_le(int pending_chunks) {
     // pending_chunks (wave-uniform) in {0, 1, .., 7}: wait until at most pending*N DMAs remain (vmcnt is a 6-bit
@@ -103,6 +112,7 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         bc[j] = G::piece_c(lane, brow[j]);
     }
     const int nq = p.template nchunks<BK>();
+    FWN_RING_STAMP_X(0);
 
     // piece j (0..PW-1) of chunk q: A pieces first, then B pieces
     auto issue_piece = [&](const typename Prob::ChunkCtx& cc, int q, int j) {
@@ -157,9 +167,12 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
     for (int q = 0; q < nq; ++q) {
         // chunks issued so far: min(nq, q + D - 1); those after q may stay in flight
         const int pending = min(nq, q + D - 1) - (q + 1);
+        FWN_RING_STAMP(q, 0);
         if (FWN_ABL_DMA) wait_vmcnt_le<PW>(pending);
         else if (q == 0) FWN_WAIT_VMCNT(0);
+        FWN_RING_STAMP(q, 1);
         if (FWN_ABL != 5) __builtin_amdgcn_s_barrier();
+        FWN_RING_STAMP(q, 2);
         // The refill of the slot freed by this barrier (chunk q+D-1) is spread over the k-steps,
         // so every DMA issue (~100 cycles of this wave's issue time) hides under MFMAs in flight.
         const bool refill = FWN_ABL_DMA && q + D - 1 < nq;
@@ -197,7 +210,9 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
             __builtin_amdgcn_sched_barrier(0);
         }
         ccn = p.template chunk_ctx<BK>(q + D < nq ? q + D : 0);
+            FWN_RING_STAMP(q, 3);
     }
+    FWN_RING_STAMP_X(1);
     if constexpr (KSP > 1) {
         // sum the KSP partial accumulators: groups 1.. park theirs in LDS (the ring is drained)
         constexpr int TILE_F = MI * 2 * 16 * 64;           // floats per wave
@@ -237,5 +252,7 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         if (sacc == 12345.678f) p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
         return;
     }
+    FWN_RING_STAMP_X(2);
     p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+    FWN_RING_STAMP_X(3);
 }

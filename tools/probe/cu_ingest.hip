@@ -1,0 +1,77 @@
+// Probe: how fast can ONE workgroup pull bytes into its CU?  LDS-DMA (buffer_load ... lds, the ring kernels' path) against
+// plain 16-byte loads to registers, for buffers that sit in L2 and buffers that do not.
+//   hipcc --offload-arch=gfx950 -O3 tools/probe/cu_ingest.hip -o tools/probe/cu_ingest_bin
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+// every workgroup streams `bytes_per_wg` starting at its own offset, `inflight` KiB-pieces per wave outstanding
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void dma_kernel(const char* src, size_t bytes_per_wg, size_t stride, int depth, float* sink) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[64 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char* base = src + (size_t)blockIdx.x * stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes_per_wg, 0x00020000);
+    const int pieces = (int)(bytes_per_wg / 1024);          // 1 KiB per wave-instruction
+    int issued = 0;
+    for (int p = wave; p < pieces; p += NW) {
+        lds_void* dst = (lds_void*)(lds + ((issued % 16) * NW + wave) * 1024);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, lane * 16, p * 1024, 0, 0);
+        ++issued;
+        if (issued % depth == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && lds[5] == 123) sink[0] = 1.0f;
+}
+template <int NW, int U>
+__global__ __launch_bounds__(64 * NW) void reg_kernel(const char* src, size_t bytes_per_wg, size_t stride, float* sink) {
+    const uint4* base = (const uint4*)(src + (size_t)blockIdx.x * stride);
+    const size_t n16 = bytes_per_wg / 16;
+    uint4 acc = {0, 0, 0, 0};
+    for (size_t i = threadIdx.x; i < n16; i += (size_t)64 * NW * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const size_t j = i + (size_t)64 * NW * u; v[u] = base[j < n16 ? j : i]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 2.0f;
+}
+int main() {
+    const size_t total = 512u << 20;
+    char* buf; float* sink;
+    hipMalloc(&buf, total); hipMemset(buf, 1, total); hipMalloc(&sink, 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timeit = [&](const char* name, int nwg, size_t per_wg, auto launch) {
+        launch(); hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+        printf("%-46s %3d WGs x %5zu KB: %7.1f us  %6.1f GB/s per WG  %6.2f TB/s total\n", name, nwg, per_wg >> 10, ms * 1e3,
+               per_wg / (ms * 1e-3) / 1e9, nwg * per_wg / (ms * 1e-3) / 1e12);
+    };
+    for (int nwg : {32, 256}) {
+        for (int shared = 0; shared < 2; ++shared) {
+            // shared = 1: every workgroup reads the SAME 1 MB (L2 hits after the first touch); 0: its own 1 MB (HBM / MALL)
+            const size_t per = 1u << 20, stride = shared ? 0 : per;
+            const char* tag = shared ? "same 1 MB (L2)" : "own 1 MB (HBM)";
+            char nm[128];
+            for (int depth : {4, 16}) {
+                snprintf(nm, sizeof nm, "LDS-DMA 4 waves depth %2d, %s", depth, tag);
+                timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL(dma_kernel<4>, dim3(nwg), dim3(256), 0, 0, buf, per, stride, depth, sink); });
+            }
+            snprintf(nm, sizeof nm, "LDS-DMA 8 waves depth 16, %s", tag);
+            timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL(dma_kernel<8>, dim3(nwg), dim3(512), 0, 0, buf, per, stride, 16, sink); });
+            snprintf(nm, sizeof nm, "16-B loads to VGPR 4 waves x 8, %s", tag);
+            timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL((reg_kernel<4, 8>), dim3(nwg), dim3(256), 0, 0, buf, per, stride, sink); });
+            snprintf(nm, sizeof nm, "16-B loads to VGPR 8 waves x 8, %s", tag);
+            timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL((reg_kernel<8, 8>), dim3(nwg), dim3(512), 0, 0, buf, per, stride, sink); });
+            snprintf(nm, sizeof nm, "16-B loads to VGPR 16 waves x 8, %s", tag);
+            timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL((reg_kernel<16, 8>), dim3(nwg), dim3(1024), 0, 0, buf, per, stride, sink); });
+        }
+    }
+    return 0;
+}
