@@ -39,6 +39,40 @@ __global__ __launch_bounds__(64 * NW) void reg_kernel(const char* src, size_t by
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 2.0f;
 }
+// the ring kernels' pattern: a wave instruction fetches 4 rows x 256 B of a [rows][ld] bf16 matrix (row stride ld * 2),
+// into LDS - by DMA, or through registers + ds_write_b128; `depth` pieces outstanding per wave (sliding window)
+template <int NW, bool DMA>
+__global__ __launch_bounds__(64 * NW) void tile_kernel(const char* src, int rows, int ldb, int kbytes, size_t stride, float* sink) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[96 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const char* base = src + (size_t)blockIdx.x * stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rows * ldb, 0x00020000);
+    // pieces: (row group of 4, 256-byte column block); this wave takes every NW-th
+    const int ncb = kbytes / 256, npieces = (rows / 4) * ncb;
+    const int r4 = lane >> 4, c16 = lane & 15;
+    constexpr int DEPTH = 8;
+    uint4 v[DEPTH];
+    int n = 0;
+    for (int p0 = wave; p0 < npieces; p0 += NW * DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            const int p = p0 + u * NW;
+            const int rg = (p < npieces ? p : p0) / ncb, cb = (p < npieces ? p : p0) % ncb;
+            const uint32_t voff = (uint32_t)((rg * 4 + r4) * ldb + cb * 256 + (c16 ^ ((rg * 4 + r4) & 15)) * 16);
+            unsigned char* dst = lds + (((n + u) % 24) * NW + wave) * 1024;
+            if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, voff, 0, 0, 0);
+            else v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+        }
+        if (!DMA) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) *(uint4*)(lds + (((n + u) % 24) * NW + wave) * 1024 + lane * 16) = v[u];
+        }
+        n += DEPTH;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && lds[5] == 123) sink[0] = 1.0f;
+}
 int main() {
     const size_t total = 512u << 20;
     char* buf; float* sink;
@@ -72,6 +106,16 @@ int main() {
             snprintf(nm, sizeof nm, "16-B loads to VGPR 16 waves x 8, %s", tag);
             timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL((reg_kernel<16, 8>), dim3(nwg), dim3(1024), 0, 0, buf, per, stride, sink); });
         }
+    }
+    printf("\nring pattern: per workgroup a 192-row x 3072-byte operand set (= the 64 x 128 tile over K = 1536), own data (cold)\n");
+    for (int nwg : {50, 256}) {
+        const int rows = 192, ldb = 3072, kb = 3072;
+        const size_t per = (size_t)rows * ldb;
+        char nm[128];
+#define TK(NW, DMA, label) snprintf(nm, sizeof nm, label " %d waves", NW); \
+        timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL((tile_kernel<NW, DMA>), dim3(nwg), dim3(64 * NW), 0, 0, buf, rows, ldb, kb, per, sink); });
+        TK(4, true, "LDS-DMA, swizzled 4-row pieces,") TK(8, true, "LDS-DMA, swizzled 4-row pieces,") TK(16, true, "LDS-DMA, swizzled 4-row pieces,")
+        TK(4, false, "registers + ds_write, same pieces,") TK(8, false, "registers + ds_write, same pieces,") TK(16, false, "registers + ds_write, same pieces,")
     }
     return 0;
 }
