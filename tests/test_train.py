@@ -154,16 +154,17 @@ def test_loss_and_all_parameter_gradients_match_autograd_oracle(cfg, b, t):
     assert dot / np.sqrt(na * nb_) > 0.999            # direction of the whole gradient
 
 
-@pytest.mark.parametrize("n_block,b,t", [(6, 2, 1024), (8, 2, 1024)])
+@pytest.mark.parametrize("n_block,b,t", [(6, 2, 1024), (8, 2, 1024), ("hp8000", 2, 960)])
 def test_full_width_model_gradients_match_autograd_oracle(n_block, b, t):
     """The real architecture (hop 256, 80 mels, n_flow=6, n_layer=2; BASELINE configs[2]'s model at n_block=8, and
     n_block=6 as the cheap case that already reaches the Ch = 32 ring front conv and the hoisted conditioning
-    backward): all trainable tensors (2 262 at n_block=8, 181 M elements) against fp64 autograd of the oracle."""
+    backward): all trainable tensors (2 262 at n_block=8, 181 M elements) against fp64 autograd of the oracle.
+    "hp8000": the reference's second configuration (hparams8000.py: n_block=5, hop 96 = 8 x 12)."""
     from oracle import grad_torch as G
     from tf_flowavenet_amd import weights as W
-    from tf_flowavenet_amd.hparams import default_hparams
+    from tf_flowavenet_amd.hparams import default_hparams, hparams8000
     from tf_flowavenet_amd.training import GradEngine
-    hp = default_hparams().replace(n_block=n_block)
+    hp = hparams8000() if n_block == "hp8000" else default_hparams().replace(n_block=n_block)
     p = W.synthetic_params(hp, 1234, actnorm="random")
     inp = W.synthetic_inputs(hp, b, t)
     loss0, lp0, ld0, g0 = G.loss_and_grads(p, inp["x"], inp["c"], hp)
