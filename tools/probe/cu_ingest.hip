@@ -41,15 +41,16 @@ __global__ __launch_bounds__(64 * NW) void reg_kernel(const char* src, size_t by
 }
 // the ring kernels' pattern: a wave instruction fetches 4 rows x 256 B of a [rows][ld] bf16 matrix (row stride ld * 2),
 // into LDS - by DMA, or through registers + ds_write_b128; `depth` pieces outstanding per wave (sliding window)
-template <int NW, bool DMA>
+template <int NW, bool DMA, int RB = 256>
 __global__ __launch_bounds__(64 * NW) void tile_kernel(const char* src, int rows, int ldb, int kbytes, size_t stride, float* sink) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[96 * 1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const char* base = src + (size_t)blockIdx.x * stride;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, rows * ldb, 0x00020000);
     // pieces: (row group of 4, 256-byte column block); this wave takes every NW-th
-    const int ncb = kbytes / 256, npieces = (rows / 4) * ncb;
-    const int r4 = lane >> 4, c16 = lane & 15;
+    constexpr int RPP = 1024 / RB, LPR = RB / 16;          // rows per 1-KiB piece, lanes per row
+    const int ncb = kbytes / RB, npieces = (rows / RPP) * ncb;
+    const int r4 = lane / LPR, c16 = lane % LPR;
     constexpr int DEPTH = 8;
     uint4 v[DEPTH];
     int n = 0;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(const char* src, int rows
         for (int u = 0; u < DEPTH; ++u) {
             const int p = p0 + u * NW;
             const int rg = (p < npieces ? p : p0) / ncb, cb = (p < npieces ? p : p0) % ncb;
-            const uint32_t voff = (uint32_t)((rg * 4 + r4) * ldb + cb * 256 + (c16 ^ ((rg * 4 + r4) & 15)) * 16);
+            const uint32_t voff = (uint32_t)((rg * RPP + r4) * ldb + cb * RB + (c16 ^ ((rg * RPP + r4) & (LPR - 1) & 15)) * 16);
             unsigned char* dst = lds + (((n + u) % 24) * NW + wave) * 1024;
             if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, voff, 0, 0, 0);
             else v[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
@@ -116,6 +117,10 @@ int main() {
         timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL((tile_kernel<NW, DMA>), dim3(nwg), dim3(64 * NW), 0, 0, buf, rows, ldb, kb, per, sink); });
         TK(4, true, "LDS-DMA, swizzled 4-row pieces,") TK(8, true, "LDS-DMA, swizzled 4-row pieces,") TK(16, true, "LDS-DMA, swizzled 4-row pieces,")
         TK(4, false, "registers + ds_write, same pieces,") TK(8, false, "registers + ds_write, same pieces,") TK(16, false, "registers + ds_write, same pieces,")
+#define TKR(NW, RB, label) snprintf(nm, sizeof nm, label " %d waves", NW); \
+        timeit(nm, nwg, per, [&]() { hipLaunchKernelGGL((tile_kernel<NW, true, RB>), dim3(nwg), dim3(64 * NW), 0, 0, buf, rows, ldb, kb, per, sink); });
+        TKR(4, 512, "LDS-DMA, 2 rows x 512 B per piece,") TKR(8, 512, "LDS-DMA, 2 rows x 512 B per piece,")
+        TKR(4, 1024, "LDS-DMA, 1 row x 1024 B per piece,") TKR(8, 1024, "LDS-DMA, 1 row x 1024 B per piece,")
     }
     return 0;
 }
