@@ -373,7 +373,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             float* xa = pl.planes + (size_t)p * plane_elems;
             float* xb = pl.planes + (size_t)(p ^ 1) * plane_elems;
             const void* ca = (const bf16*)pl.cplanes + (size_t)p * cplane_elems;
-            fwn_ew_actnorm_fwd2(xa, xb, d->an, m * ch, ch, st);
+            if (i == 0 && j == 0) fwn_ew_actnorm_fwd2(xa, xb, d->an, m * ch, ch, st);      // later flows: in the previous coupling kernel
             fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, s.h[0], ch >= 32 ? pl.xhl : nullptr, (int)m, (int)ti, ch, d->kfpad, 0, nullptr, st);
             for (int l = 0; l < L; ++l) {
                 const float* Pl = hoist ? pl.P + ((size_t)j * L + l) * m * 512 : nullptr;
@@ -396,7 +396,11 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 g.bias = td->bz;
                 fwn_gemm_launch(&g, st);
             }
-            fwn_ew_coupling_fwd(xb, s.z, td->ez, m * ch, ch, s.part, s.nb, st);
+            {   // the coupling, and the next flow's ActNorm of both planes with it
+                const bool last = i == md->n_block - 1 && j == NF - 1;
+                const fwn_flow_desc* dn = last ? nullptr : &md->flows[i * NF + j + 1];
+                fwn_ew_coupling_fwd_ex(xb, s.z, td->ez, m * ch, ch, s.part, s.nb, dn ? dn->an : nullptr, j == NF - 1 ? 2 * ch : ch, xa, st);
+            }
             p ^= 1;
         }
     }
