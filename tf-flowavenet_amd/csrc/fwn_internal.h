@@ -87,6 +87,10 @@ void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float sca
                         hipStream_t st);
 void fwn_ew_actnorm_bwd(float* dy, float* y, const float* an, long n, int Ch, hipStream_t st);
 int fwn_small_grads_blocks(long M, int Ch);
+void fwn_small_grads_main(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
+                          double* partial, hipStream_t st);
+void fwn_small_grads_final(const float* an, long M, int Ch, const long long* br, const long long* zc, const double* partial, float* db,
+                           float* dlogs, float* dzscale, hipStream_t st);
 void fwn_small_grads_launch(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
                             const long long* br, const long long* zc, double* partial, float* db, float* dlogs,
                             float* dzscale, hipStream_t st);

@@ -113,13 +113,13 @@ struct FlowSaved {          // what the training forward keeps of one flow
     void* s_act; void* u_act; float* z; float* part; int nb, p;
 };
 
-struct BwdSet { void* dz; void* du; void* ds; void* dpre[FWN_MAX_LAYERS]; void* dh[FWN_MAX_LAYERS]; void* ya_bf; };
+struct BwdSet { void* dz; void* du; void* ds; void* dpre[FWN_MAX_LAYERS]; void* dh[FWN_MAX_LAYERS]; void* ya_bf; double* sg; };
 struct Plan {               // every buffer of one call
     void* cplanes; float* ups[FWN_MAX_UPSAMPLE]; float* planes; float* gplanes; float* dcplanes; float* P;
     float* partial_all; float* out2; float* an_dummy;
     FlowSaved* saved;       // host array, owned by the caller of plan()
     // backward temporaries, sized for the largest block and reused flow after flow
-    void* xhl; float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; double* wn_scratch; double* sg_scratch; double* up_wn;
+    void* xhl; float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; double* wn_scratch; double* up_wn;
     void* dyt; void* xt; float* fr_part;
     // the ones the weight-gradient GEMMs read.  One set without a side stream; with one, a set per flow: its weight
     // gradients run on the side stream while the main stream goes on differentiating
@@ -248,11 +248,11 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
             w.dh[l] = b.take((size_t)mset * 256 * 2);
         }
         w.ya_bf = b.take(ya_b);
+        w.sg = (double*)b.take(sg_b);          // row-range partials of the flow's small gradients (totalled on the side stream)
     }
     pl.tn_part = (float*)b.take(tn_b);
     pl.wn_scratch = (double*)b.take(wn_b);
     pl.up_wn = (double*)b.take(1024 * 8);
-    pl.sg_scratch = (double*)b.take(sg_b);
     pl.dyt = b.take(dyt_b);
     pl.xt = b.take(xt_b);
     pl.fr_part = (float*)b.take(fr_b);
@@ -426,6 +426,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     struct Deferred {
         TnList tn; WnItem wn[4 + 7 * FWN_MAX_LAYERS]; int nwn; long m, ti; int ch, i; bool small_front; const BwdSet* w; const void* dh0;
         const fwn_flow_train_desc* td;
+        const float* an;                                   // the flow's ActNorm table (totals of the small gradients)
         fwn_gemm_desc dca[FWN_MAX_LAYERS]; int ndca;      // conditioning-gradient GEMMs (accumulate into the mel image: order kept)
     };
     std::vector<Deferred> pending;        // the flows of the block whose weight gradients are still to be enqueued
@@ -434,6 +435,9 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         const long m = D.m, ti = D.ti;
         const int ch = D.ch;
         TnList& tn = D.tn;
+        if (side)       // (one stream: totalled right behind their first pass, on the chain)
+            fwn_small_grads_final(D.an, m, ch, (const long long*)t->br[D.i], (const long long*)t->zcol[D.i], D.w->sg, D.td->d_an_b, D.td->d_an_logs,
+                                  D.td->d_zscale, s_);
         for (int k = 0; k < D.ndca; ++k) fwn_gemm_launch(&D.dca[k], s_);
         if (D.small_front) {       // rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
             const long mp = roundup(m, 64);
@@ -541,7 +545,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             }
             pending.emplace_back();
             Deferred& D = pending.back();
-            D.nwn = 0; D.m = m; D.ti = ti; D.ch = ch; D.i = i; D.w = &w; D.td = td; D.ndca = 0;
+            D.nwn = 0; D.m = m; D.ti = ti; D.ch = ch; D.i = i; D.w = &w; D.td = td; D.ndca = 0; D.an = d->an;
             TnList& tn = D.tn;
             auto add_wn = [&](int tnj, const fwn_conv_grad* c, int k, int n, int col0, float scale, const int32_t* row_src, const int32_t* col_src) {
                 D.wn[D.nwn++] = WnItem{tnj, nullptr, 0, 0, 0, 0, c, k, n, col0, scale, row_src, col_src};
@@ -619,8 +623,9 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             }
             // ActNorm of both planes back to the flow's inputs, with its b / logs gradients and the ZeroConv scale gradient
             TREQUIRE(td->d_an_b && td->d_an_logs && td->d_zscale, "fwn_train_loss_and_grads: flow (%d,%d): missing small gradient pointers", i, j);
-            fwn_small_grads_launch(ga, xa, gb, xb, pl.dzz, d->an, m, ch, (const long long*)t->br[i], (const long long*)t->zcol[i], pl.sg_scratch,
-                                   td->d_an_b, td->d_an_logs, td->d_zscale, st);
+            fwn_small_grads_main(ga, xa, gb, xb, pl.dzz, d->an, m, ch, w.sg, st);
+            if (!side) fwn_small_grads_final(d->an, m, ch, (const long long*)t->br[i], (const long long*)t->zcol[i], w.sg, td->d_an_b, td->d_an_logs,
+                                             td->d_zscale, st);
             if (!side && j == 0 && on_block_done) on_block_done(user, i);
             if (side && j == 0) {      // this block's weight gradients: under the next block's chain
                 if (!join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");

@@ -410,9 +410,19 @@ int fwn_small_grads_blocks(long M, int Ch) {
 void fwn_small_grads_launch(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
                             const long long* br, const long long* zc, double* partial, float* db, float* dlogs,
                             float* dzscale, hipStream_t st) {
-    const int nb = fwn_small_grads_blocks(M, Ch);
-    hipLaunchKernelGGL(flow_small_grads_kernel, dim3(nb), dim3(256), 0, st, ga, ya, gb, yb, dzz, an, M, Ch, partial);
-    hipLaunchKernelGGL(flow_small_grads_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, Ch, an, br, zc, db, dlogs, dzscale);
+    fwn_small_grads_main(ga, ya, gb, yb, dzz, an, M, Ch, partial, st);
+    fwn_small_grads_final(an, M, Ch, br, zc, partial, db, dlogs, dzscale, st);
+}
+// the two halves separately: the first is on the flow's chain (it restores the planes), the second only totals the
+// parameter gradients and may run elsewhere
+void fwn_small_grads_main(float* ga, float* ya, float* gb, float* yb, const float* dzz, const float* an, long M, int Ch,
+                          double* partial, hipStream_t st) {
+    hipLaunchKernelGGL(flow_small_grads_kernel, dim3(fwn_small_grads_blocks(M, Ch)), dim3(256), 0, st, ga, ya, gb, yb, dzz, an, M, Ch, partial);
+}
+void fwn_small_grads_final(const float* an, long M, int Ch, const long long* br, const long long* zc, const double* partial, float* db,
+                           float* dlogs, float* dzscale, hipStream_t st) {
+    hipLaunchKernelGGL(flow_small_grads_final_kernel, dim3(1), dim3(256), 0, st, partial, fwn_small_grads_blocks(M, Ch), Ch, an, br, zc, db,
+                       dlogs, dzscale);
 }
 
 // Weight-norm backward (convolutional.py:73-80): W = V g / ||V||_col, straight from the split-K partials.
