@@ -259,6 +259,40 @@ def test_side_stream_weight_gradients_equal_the_one_stream_call_bit_for_bit(cfg,
         assert torch.equal(res["0"][3][k], res["1"][3][k]), k
 
 
+def test_train_entry_point_rejects_bad_arguments_with_a_message():
+    """fwn_train_loss_and_grads / fwn_train_workspace_bytes: argument errors come back as codes with fwn_last_error()
+    set (workspace too small: FWN_ERR_WORKSPACE), nothing is launched, and the same descriptors still work afterwards."""
+    import ctypes as C
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W, _lib
+    from tf_flowavenet_amd.training import GradEngine
+    hp = small_hparams(n_block=2, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=8)
+    p = W.synthetic_params(hp, 3, actnorm="random")
+    inp = W.synthetic_inputs(hp, 2, 128)
+    x, c = torch.from_numpy(inp["x"]).reshape(2, 128).cuda(), torch.from_numpy(inp["c"]).cuda()
+    eng = GradEngine(hp)
+    l0 = float(eng.loss_and_grads(p, x, c)[0])
+    lib, td = eng.lib, eng._desc
+    need = int(lib.fwn_train_workspace_bytes(C.byref(td), 2, 128))
+    assert need > 0 and int(lib.fwn_train_workspace_bytes(C.byref(td), 2, 120)) == 0          # T not a multiple of the hop size
+    assert int(lib.fwn_train_workspace_bytes(C.byref(td), 0, 128)) == 0
+    ws = torch.empty(need + 512, dtype=torch.uint8, device="cuda")
+    base = ws.data_ptr() + (-ws.data_ptr()) % 256
+    out3 = torch.zeros(3, device="cuda")
+    cb = _lib.BLOCK_DONE_FN(lambda user, blk: None)
+    call = lambda B, T, xp, wsp, wsn: lib.fwn_train_loss_and_grads(C.byref(td), B, T, xp, c.data_ptr(), wsp, wsn, out3.data_ptr(), cb, None, None)
+    assert call(2, 128, x.data_ptr(), base, need - 1) == -3 and b"workspace" in lib.fwn_last_error()
+    assert call(2, 128, None, base, need) == -1 and b"null" in lib.fwn_last_error()
+    assert call(2, 128, x.data_ptr(), base + 16, need) == -1 and b"aligned" in lib.fwn_last_error()
+    assert call(2, 120, x.data_ptr(), base, need) == -1 and b"multiple" in lib.fwn_last_error()
+    assert call(0, 128, x.data_ptr(), base, need) == -1
+    torch.cuda.synchronize()
+    assert float(out3.abs().sum()) == 0.0                       # nothing ran
+    assert call(2, 128, x.data_ptr(), base, need) == 0
+    torch.cuda.synchronize()
+    assert float(out3[0]) == l0
+
+
 def test_gradient_is_reproducible_bit_for_bit():
     cfg = dict(n_block=2, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=8)
     _, _, _, (l1, _, _, g1) = _grad_case(cfg, 2, 128, 7)
