@@ -159,6 +159,15 @@ int fwn_res(const fwn_flow_desc* d, int layer, const void* o, const void* h_in, 
  * the block-contiguous weights, P_base/p_stride the outputs ([M][512] fp32 each). */
 int fwn_cond(const void* ca, const void* Wc_base, float* P_base, int64_t w_stride, int64_t p_stride,
              int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, void* stream);
+/* The same with the K range dealt over nsplit workgroups per tile (few rows against a long K: M = 63 rows, cin = 10240
+ * at the last block of a single clip): split 0 writes P, split z > 0 the same matrices into part + (z - 1) part_stride
+ * (floats; laid out like P); fwn_cond_reduce then adds the partials to P[0..n) in ascending order (bit-reproducible).
+ * fwn_cond_splits: the split count the model-level calls use for nz = nflow * L matrices per launch (1: none). */
+int fwn_cond_splits(int M, int nz, int kcpad);
+int fwn_cond_split(const void* ca, const void* Wc_base, float* P_base, int64_t w_stride, int64_t p_stride,
+                   int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part, int64_t part_stride,
+                   int nsplit, void* stream);
+int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit, int64_t n, void* stream);
 /* K6'+K7+K8 tail: skip sum, final 1x1, ZeroConv1d, affine coupling, ActNorm, log-det partials
  * (modules.py:175-180,51-56; model.py:86-102,124-141,146-161).  o = [L][M][256].
  * partial (forward only, may be NULL) receives fwn_tail_partials(M) partial sums.

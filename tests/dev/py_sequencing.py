@@ -94,9 +94,12 @@ def loss_and_grads(self, tp, params, x, c):
         if m < 4096:
             d0 = pm.flow_descs[i * hp.n_flow]
             P = f32(hp.n_flow, L, m, 512)
+            ns = int(self.lib.fwn_cond_splits(m, ((hp.n_flow + 1) // 2) * L, d0.kcpad))     # few rows: K dealt over workgroups
+            part = f32(max(1, ns - 1), hp.n_flow, L, m, 512)
             for g_ in range(min(2, hp.n_flow)):
-                self._call("fwn_cond", cplanes[p ^ g_].data_ptr(), d0.Wc[0], P.data_ptr(), 512 * d0.kcpad, m * 512, g_, 2,
-                           (hp.n_flow - g_ + 1) // 2, L, m, cin, d0.kcpad, st)
+                self._call("fwn_cond_split", cplanes[p ^ g_].data_ptr(), d0.Wc[0], P.data_ptr(), 512 * d0.kcpad, m * 512, g_, 2,
+                           (hp.n_flow - g_ + 1) // 2, L, m, cin, d0.kcpad, part.data_ptr(), P.numel(), ns, st)
+            self._call("fwn_cond_reduce", P.data_ptr(), part.data_ptr(), P.numel(), ns, P.numel(), st)
         for j in range(hp.n_flow):
             d = pm.flow_descs[i * hp.n_flow + j]
             t = tp.flows[(i, j)]

@@ -271,7 +271,8 @@ def test_train_entry_point_rejects_bad_arguments_with_a_message():
     inp = W.synthetic_inputs(hp, 2, 128)
     x, c = torch.from_numpy(inp["x"]).reshape(2, 128).cuda(), torch.from_numpy(inp["c"]).cuda()
     eng = GradEngine(hp)
-    l0 = float(eng.loss_and_grads(p, x, c)[0])
+    first = eng.loss_and_grads(p, x, c)         # kept: the descriptors point at these gradient tensors
+    l0 = float(first[0])
     lib, td = eng.lib, eng._desc
     need = int(lib.fwn_train_workspace_bytes(C.byref(td), 2, 128))
     assert need > 0 and int(lib.fwn_train_workspace_bytes(C.byref(td), 2, 120)) == 0          # T not a multiple of the hop size

@@ -155,6 +155,10 @@ SIGNATURES = {
     "fwn_res": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, vp]),
     "fwn_cond": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                            C.c_int, vp]),
+    "fwn_cond_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "fwn_cond_split": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64,
+                                 C.c_int, vp]),
+    "fwn_cond_reduce": (C.c_int, [vp, vp, i64, C.c_int, i64, vp]),
     "fwn_tail_partials": (C.c_int, [C.c_int]),
     "fwn_tail": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_flow_run": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,

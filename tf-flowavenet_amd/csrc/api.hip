@@ -241,8 +241,28 @@ int fwn_cond(const void* ca, const void* Wc_base, float* P_base, int64_t w_strid
             "fwn_cond: bad shape");
     REQUIRE(flow0 >= 0 && flow_step > 0, "fwn_cond: bad flow group");
     fwn_launch_cond(ca, Wc_base, P_base, (long)w_stride, (long)p_stride, flow0, flow_step, nflow, L, M, cin,
-                    kcpad, (hipStream_t)stream);
+                    kcpad, nullptr, 0, 1, (hipStream_t)stream);
     return check_launch("fwn_cond");
+}
+
+int fwn_cond_splits(int M, int nz, int kcpad) { return (M > 0 && nz > 0 && kcpad > 0) ? fwn_cond_nsplit(M, nz, kcpad) : 1; }
+int fwn_cond_split(const void* ca, const void* Wc_base, float* P_base, int64_t w_stride, int64_t p_stride,
+                   int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part, int64_t part_stride,
+                   int nsplit, void* stream) {
+    REQUIRE(ca && Wc_base && P_base, "fwn_cond_split: null pointer");
+    REQUIRE(nflow > 0 && L > 0 && M > 0 && cin > 0 && cin % 8 == 0 && kcpad % 64 == 0 && kcpad >= cin,
+            "fwn_cond_split: bad shape");
+    REQUIRE(flow0 >= 0 && flow_step > 0, "fwn_cond_split: bad flow group");
+    REQUIRE(nsplit >= 1 && nsplit <= kcpad / 64 && (nsplit == 1 || (part && part_stride > 0 && part_stride % 4 == 0)),
+            "fwn_cond_split: nsplit=%d needs a partial buffer and at most one split per 64-wide chunk", nsplit);
+    fwn_launch_cond(ca, Wc_base, P_base, (long)w_stride, (long)p_stride, flow0, flow_step, nflow, L, M, cin,
+                    kcpad, part, (long)part_stride, nsplit, (hipStream_t)stream);
+    return check_launch("fwn_cond_split");
+}
+int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit, int64_t n, void* stream) {
+    REQUIRE(P && n > 0 && n % 4 == 0 && nsplit >= 1 && (nsplit == 1 || (part && part_stride >= n)), "fwn_cond_reduce: bad argument");
+    fwn_launch_cond_reduce(P, part, (long)part_stride, nsplit, (long)n, (hipStream_t)stream);
+    return check_launch("fwn_cond_reduce");
 }
 
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
@@ -546,7 +566,7 @@ int fwn_clip_adam_dev(float* w, const float* g, float* m, float* v, int64_t n, c
 // Whole-model sequencing
 // ---------------------------------------------------------------------------------------------
 struct Carve {
-    size_t cplanes, up0, up1, planes, h0, h1, o, P, partial, mom, h8a, h8b, total;
+    size_t cplanes, up0, up1, planes, h0, h1, o, P, Ppart, partial, mom, h8a, h8b, total;
     int n_partial;
 };
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -604,17 +624,20 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
     c.h0 = off; off = align_up(off + Mmax * 256 * 2);
     c.h1 = off; off = align_up(off + Mmax * 256 * 2);
     c.o = off; off = align_up(off + (size_t)m->n_layer * Mmax * 256 * 2);
-    size_t pbytes = 0;
+    size_t pbytes = 0, ppart = 0;
     int npart = 0;
     for (int i = 0; i < m->n_block; ++i) {
         const int64_t M = B * T / ((int64_t)2 << i);
         if (hoist_cond(m, M)) {
             const size_t need = (size_t)m->n_flow * m->n_layer * M * 512 * 4;
             if (need > pbytes) pbytes = need;
+            const size_t sp = (size_t)(fwn_cond_nsplit((int)M, ((m->n_flow + 1) / 2) * m->n_layer, m->flows[i * m->n_flow].kcpad) - 1) * need;
+            if (sp > ppart) ppart = sp;
         }
         npart += m->n_flow * fwn_tail_partials((int)M);
     }
     c.P = off; off = align_up(off + pbytes);
+    c.Ppart = off; off = align_up(off + ppart);        // split-K partials of the hoisted conditioning (few rows)
     c.partial = off; off = align_up(off + (size_t)npart * 4);
     c.n_partial = npart;
     // per-flow moment buffers of the data-parallel ActNorm init: 4 Ch + 1 doubles each, Ch <= 2^(n_block-1)
@@ -649,12 +672,15 @@ static void run_cond_groups(const fwn_model_desc* m, int blk, int64_t M, const i
     const fwn_flow_desc* f0 = &m->flows[blk * m->n_flow];
     const size_t half = m->num_mels / 2;
     const size_t plane_elems = (size_t)B * T * half;
+    const long pn = (long)m->n_flow * m->n_layer * M * 512;          // floats of the block's P matrices
+    const int ns = fwn_cond_nsplit((int)M, ((m->n_flow + 1) / 2) * m->n_layer, f0->kcpad);
     for (int g = 0; g < 2 && g < m->n_flow; ++g) {
         const int nfl = (m->n_flow - g + 1) / 2;
         const char* ca = ws + c.cplanes + (size_t)parity_of_flow[g] * plane_elems * 2;
         fwn_launch_cond(ca, f0->Wc[0], (float*)(ws + c.P), (long)512 * f0->kcpad, (long)M * 512, g, 2, nfl,
-                        m->n_layer, (int)M, f0->cin, f0->kcpad, st);
+                        m->n_layer, (int)M, f0->cin, f0->kcpad, (float*)(ws + c.Ppart), pn, ns, st);
     }
+    fwn_launch_cond_reduce((float*)(ws + c.P), (const float*)(ws + c.Ppart), pn, ns, pn, st);
 }
 
 static int check_block_contiguity(const fwn_model_desc* m, int blk) {

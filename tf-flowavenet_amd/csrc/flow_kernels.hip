@@ -413,13 +413,14 @@ struct CondProb {
     static constexpr bool ALLOW_256 = false;
     const bf16* ca;       // [M][cin]
     const bf16* Wc;       // [512][kcpad]
-    float* P;             // [M][512]
+    float* P;             // [M][512] (this split's output)
     int M, cin, kcpad;
+    int k_begin = 0, k_end = 0;   // K range of this workgroup's split (k_end == 0: all of kcpad); multiples of 64
     struct RowCtx { int row; };
     struct ChunkCtx { int k0; };
-    template <int BK> __device__ int nchunks() const { return kcpad / BK; }
+    template <int BK> __device__ int nchunks() const { return ((k_end ? k_end : kcpad) - k_begin) / BK; }
     __device__ RowCtx row_ctx(int row) const { return RowCtx{row}; }
-    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{q * BK}; }
+    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{k_begin + q * BK}; }
     __device__ srd_t a_srd(const ChunkCtx&) const { return make_srd(ca, (uint32_t)((size_t)M * cin * 2)); }
     __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
         const bool ok = rc.row < M && cc.k0 + c8 * 8 < cin;
@@ -468,13 +469,25 @@ struct CondBatch {
     long p_stride;        // elements between consecutive P matrices
     int flow0, flow_step, L;
     int M, cin, kcpad;
+    // split-K over blockIdx.z (few rows, long K: a workgroup would stream K (BM + BN) 2 bytes through one CU): split 0
+    // writes P, split z > 0 the same matrix in part_base + (z - 1) part_stride; fwn_launch_cond_reduce adds them in order
+    float* part_base;
+    long part_stride;
+    int nsplit;
 };
 template <int BM, int BN, int WM, int WN, int BK, int D>
 __global__ __launch_bounds__(64 * WM * WN) void cond_batch_kernel(CondBatch cb, int ntn) {
     const int z = blockIdx.y;
     const int zi = (cb.flow0 + (z / cb.L) * cb.flow_step) * cb.L + (z % cb.L);
-    CondProb p{cb.ca, cb.Wc_base + (size_t)zi * cb.w_stride, cb.P_base + (size_t)zi * cb.p_stride,
-               cb.M, cb.cin, cb.kcpad};
+    const int sp = blockIdx.z;
+    float* out = (sp == 0 ? cb.P_base : cb.part_base + (size_t)(sp - 1) * cb.part_stride) + (size_t)zi * cb.p_stride;
+    CondProb p{cb.ca, cb.Wc_base + (size_t)zi * cb.w_stride, out, cb.M, cb.cin, cb.kcpad};
+    if (cb.nsplit > 1) {       // 64-wide chunks dealt out evenly; every split gets at least one (fwn_cond_splits)
+        const int nch = cb.kcpad / 64, per = (nch + cb.nsplit - 1) / cb.nsplit;
+        p.k_begin = min(sp * per, nch) * 64;
+        p.k_end = min((sp + 1) * per, nch) * 64;
+        if (p.k_end == 0) p.k_end = 64, p.k_begin = 64;          // (cannot happen: split 0 always has chunks) keep nchunks() >= 0
+    }
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     gemm_ring_body<BM, BN, WM, WN, BK, D, CondProb>(p, wg / ntn, wg % ntn);
 }
@@ -1108,11 +1121,43 @@ void fwn_launch_res(const void* o, const void* hin, const void* W, const float* 
     launch_ring(p, M, 256, 16, st);
 }
 
+// ---- hoisted conditioning: how many K splits, and the fixed-order sum of their partial outputs ----
+// nz (flow, layer) matrices per launch.  With a workgroup or less per two CUs and at least 8 chunks per split, the K range
+// is dealt over up to 8 workgroups (B = 1: M = 63 rows against K = 10240 at the last block).
+int fwn_cond_nsplit(int M, int nz, int kcpad) {
+    const int base = ((M + 63) / 64) * 4 * nz;
+    if (base >= 128) return 1;
+    int ns = 1;
+    while (ns < 8 && base * ns * 2 <= 256 && kcpad / 64 / (ns * 2) >= 8) ns *= 2;
+    return ns;
+}
+__global__ __launch_bounds__(256) void cond_reduce_kernel(float* __restrict__ P, const float* __restrict__ part, long part_stride,
+                                                          int nsplit, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 a = ((const float4*)P)[i];
+        for (int s = 0; s < nsplit - 1; ++s) {          // ascending split order: bit-reproducible
+            const float4 b = ((const float4*)(part + (size_t)s * part_stride))[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        ((float4*)P)[i] = a;
+    }
+}
+void fwn_launch_cond_reduce(float* P, const float* part, long part_stride, int nsplit, long n, hipStream_t st) {
+    if (nsplit <= 1) return;
+    const long n4 = n / 4;
+    const long g = (n4 + 255) / 256;
+    hipLaunchKernelGGL(cond_reduce_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, st, P, part, part_stride, nsplit, n4);
+}
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
-                     int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, hipStream_t st) {
+                     int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
+                     int nsplit, hipStream_t st) {
     CondBatch cb{(const bf16*)ca, (const bf16*)Wc_base, P_base, w_stride, p_stride, flow0, flow_step, L,
-                 M, cin, kcpad};
+                 M, cin, kcpad, part_base, part_stride, nsplit > 1 ? nsplit : 1};
     const int nz = nflow * L;
+    if (cb.nsplit > 1) {        // only ever with few rows: the smallest tile
+        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nz, cb.nsplit), dim3(256), 0, st, cb, 4);
+        return;
+    }
     // weights dominate the bytes and arrive from HBM: take the largest balanced tile that still
     // gives about one workgroup per CU (block 4: 256 x 256, block 5: 256 x 128 at the bench batch)
     const int t256 = (M + 255) / 256;

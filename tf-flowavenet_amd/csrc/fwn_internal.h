@@ -26,7 +26,12 @@ void fwn_launch_gate_fp8(const void* h8, const void* ca, const void* Wd8, int we
 void fwn_launch_res(const void* o, const void* hin, const void* W, const float* bias, void* hout, int M, void* h8out,
                     hipStream_t st);
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
-                     int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, hipStream_t st);
+                     int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
+                     int nsplit, hipStream_t st);
+// split-K of the hoisted conditioning for few rows: the split count for nz matrices per launch, and the in-order sum of
+// the partial outputs (part: [nsplit - 1][..] laid out like P) into P[0..n)
+int fwn_cond_nsplit(int M, int nz, int kcpad);
+void fwn_launch_cond_reduce(float* P, const float* part, long part_stride, int nsplit, long n, hipStream_t st);
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
                      const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,
                      float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse, void* scratch_s,

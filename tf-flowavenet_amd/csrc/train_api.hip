@@ -115,7 +115,7 @@ struct FlowSaved {          // what the training forward keeps of one flow
 
 struct BwdSet { void* dz; void* du; void* ds; void* dpre[FWN_MAX_LAYERS]; void* dh[FWN_MAX_LAYERS]; void* ya_bf; double* sg; };
 struct Plan {               // every buffer of one call
-    void* cplanes; float* ups[FWN_MAX_UPSAMPLE]; float* planes; float* gplanes; float* dcplanes; float* P;
+    void* cplanes; float* ups[FWN_MAX_UPSAMPLE]; float* planes; float* gplanes; float* dcplanes; float* P; float* Ppart;
     float* partial_all; float* out2; float* an_dummy;
     FlowSaved* saved;       // host array, owned by the caller of plan()
     // backward temporaries, sized for the largest block and reused flow after flow
@@ -173,12 +173,17 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
     pl.planes = (float*)b.take((size_t)B * T * 4);
     pl.gplanes = (float*)b.take((size_t)B * T * 4);
     pl.dcplanes = (float*)b.take((size_t)2 * B * T * half * 4);
-    size_t pbytes = 0;
+    size_t pbytes = 0, ppart = 0;
     int npart = 0;
     long mmax = B * T / 2;
     for (int i = 0; i < md->n_block; ++i) {
         const long ch = 1L << i, m = B * T / (2 * ch);
-        if (m < 4096) { const size_t need = (size_t)md->n_flow * L * m * 512 * 4; if (need > pbytes) pbytes = need; }
+        if (m < 4096) {
+            const size_t need = (size_t)md->n_flow * L * m * 512 * 4;
+            if (need > pbytes) pbytes = need;
+            const size_t sp = (size_t)(fwn_cond_nsplit((int)m, ((md->n_flow + 1) / 2) * L, md->flows[i * md->n_flow].kcpad) - 1) * need;
+            if (sp > ppart) ppart = sp;
+        }
         for (int j = 0; j < md->n_flow; ++j) {
             FlowSaved& s = pl.saved[i * md->n_flow + j];
             for (int l = 0; l < L; ++l) {
@@ -195,6 +200,7 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
         }
     }
     pl.P = (float*)b.take(pbytes);
+    pl.Ppart = (float*)b.take(ppart);          // split-K partials of the hoisted conditioning (few rows)
     pl.partial_all = (float*)b.take((size_t)npart * 4);
     pl.npart = npart;
     {   // partial slices in flow order
@@ -361,10 +367,14 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         const int cin = half * (2 << i);
         const fwn_flow_desc* d0 = &md->flows[i * NF];
         const bool hoist = m < 4096;
-        if (hoist)
+        if (hoist) {
+            const long pn = (long)NF * L * m * 512;
+            const int ns = fwn_cond_nsplit((int)m, ((NF + 1) / 2) * L, d0->kcpad);
             for (int g_ = 0; g_ < 2 && g_ < NF; ++g_)
                 fwn_launch_cond((const bf16*)pl.cplanes + (size_t)(p ^ g_) * cplane_elems, d0->Wc[0], pl.P, (long)512 * d0->kcpad, m * 512, g_, 2,
-                                (NF - g_ + 1) / 2, L, (int)m, cin, d0->kcpad, st);
+                                (NF - g_ + 1) / 2, L, (int)m, cin, d0->kcpad, pl.Ppart, pn, ns, st);
+            fwn_launch_cond_reduce(pl.P, pl.Ppart, pn, ns, pn, st);
+        }
         for (int j = 0; j < NF; ++j) {
             const fwn_flow_desc* d = &md->flows[i * NF + j];
             const fwn_flow_train_desc* td = &t->flows[i * NF + j];
