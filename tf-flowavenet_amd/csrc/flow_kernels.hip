@@ -1126,9 +1126,9 @@ void fwn_launch_res(const void* o, const void* hin, const void* W, const float* 
 // is dealt over up to 8 workgroups (B = 1: M = 63 rows against K = 10240 at the last block).
 int fwn_cond_nsplit(int M, int nz, int kcpad) {
     const int base = ((M + 63) / 64) * 4 * nz;
-    if (base >= 128) return 1;
+    if (base >= FWN_TUNE(FWN_COND_BASE, 128)) return 1;
     int ns = 1;
-    while (ns < 8 && base * ns * 2 <= 256 && kcpad / 64 / (ns * 2) >= 8) ns *= 2;
+    while (ns < 8 && base * ns * 2 <= FWN_TUNE(FWN_COND_FILL, 256) && kcpad / 64 / (ns * 2) >= 8) ns *= 2;
     return ns;
 }
 __global__ __launch_bounds__(256) void cond_reduce_kernel(float* __restrict__ P, const float* __restrict__ part, long part_stride,
