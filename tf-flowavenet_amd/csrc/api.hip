@@ -674,11 +674,17 @@ static void run_cond_groups(const fwn_model_desc* m, int blk, int64_t M, const i
     const size_t plane_elems = (size_t)B * T * half;
     const long pn = (long)m->n_flow * m->n_layer * M * 512;          // floats of the block's P matrices
     const int ns = fwn_cond_nsplit((int)M, ((m->n_flow + 1) / 2) * m->n_layer, f0->kcpad);
-    for (int g = 0; g < 2 && g < m->n_flow; ++g) {
-        const int nfl = (m->n_flow - g + 1) / 2;
-        const char* ca = ws + c.cplanes + (size_t)parity_of_flow[g] * plane_elems * 2;
-        fwn_launch_cond(ca, f0->Wc[0], (float*)(ws + c.P), (long)512 * f0->kcpad, (long)M * 512, g, 2, nfl,
-                        m->n_layer, (int)M, f0->cin, f0->kcpad, (float*)(ws + c.Ppart), pn, ns, st);
+    // even flows of the block read plane parity_of_flow[0], odd flows the other: one launch or one per parity group
+    const char* ca0 = ws + c.cplanes + (size_t)parity_of_flow[0] * plane_elems * 2;
+    const char* ca1 = ws + c.cplanes + (size_t)parity_of_flow[1] * plane_elems * 2;
+    const int nzg = ((m->n_flow + 1) / 2) * m->n_layer;
+    if (m->n_flow > 1 && fwn_cond_merge((int)M, nzg, ns)) {
+        fwn_launch_cond2(ca0, ca1, f0->Wc[0], (float*)(ws + c.P), (long)512 * f0->kcpad, (long)M * 512, 0, 1, m->n_flow,
+                         m->n_layer, (int)M, f0->cin, f0->kcpad, (float*)(ws + c.Ppart), pn, ns, st);
+    } else {
+        for (int g = 0; g < 2 && g < m->n_flow; ++g)
+            fwn_launch_cond(g ? ca1 : ca0, f0->Wc[0], (float*)(ws + c.P), (long)512 * f0->kcpad, (long)M * 512, g, 2, (m->n_flow - g + 1) / 2,
+                            m->n_layer, (int)M, f0->cin, f0->kcpad, (float*)(ws + c.Ppart), pn, ns, st);
     }
     fwn_launch_cond_reduce((float*)(ws + c.P), (const float*)(ws + c.Ppart), pn, ns, pn, st);
 }

@@ -463,6 +463,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void gemm_ring_kernel(Prob p, i
 // Batched conditioning projections: blockIdx.y selects (flow, layer) of one parity group.
 struct CondBatch {
     const bf16* ca;
+    const bf16* ca_odd;   // != NULL: flows with an odd index read this plane (both parity groups of a block in one launch)
     const bf16* Wc_base;
     float* P_base;
     long w_stride;        // elements between consecutive (flow*L + layer) weight matrices
@@ -478,10 +479,11 @@ struct CondBatch {
 template <int BM, int BN, int WM, int WN, int BK, int D>
 __global__ __launch_bounds__(64 * WM * WN) void cond_batch_kernel(CondBatch cb, int ntn) {
     const int z = blockIdx.y;
-    const int zi = (cb.flow0 + (z / cb.L) * cb.flow_step) * cb.L + (z % cb.L);
+    const int flow = cb.flow0 + (z / cb.L) * cb.flow_step;
+    const int zi = flow * cb.L + (z % cb.L);
     const int sp = blockIdx.z;
     float* out = (sp == 0 ? cb.P_base : cb.part_base + (size_t)(sp - 1) * cb.part_stride) + (size_t)zi * cb.p_stride;
-    CondProb p{cb.ca, cb.Wc_base + (size_t)zi * cb.w_stride, out, cb.M, cb.cin, cb.kcpad};
+    CondProb p{(cb.ca_odd && (flow & 1)) ? cb.ca_odd : cb.ca, cb.Wc_base + (size_t)zi * cb.w_stride, out, cb.M, cb.cin, cb.kcpad};
     if (cb.nsplit > 1) {       // 64-wide chunks dealt out evenly; every split gets at least one (fwn_cond_splits)
         const int nch = cb.kcpad / 64, per = (nch + cb.nsplit - 1) / cb.nsplit;
         p.k_begin = min(sp * per, nch) * 64;
@@ -1148,34 +1150,53 @@ void fwn_launch_cond_reduce(float* P, const float* part, long part_stride, int n
     const long g = (n4 + 255) / 256;
     hipLaunchKernelGGL(cond_reduce_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, st, P, part, part_stride, nsplit, n4);
 }
-void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
-                     int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
-                     int nsplit, hipStream_t st) {
-    CondBatch cb{(const bf16*)ca, (const bf16*)Wc_base, P_base, w_stride, p_stride, flow0, flow_step, L,
+// workgroups of one parity group's launch (nz matrices) under the tile rule of fwn_launch_cond2
+int fwn_cond_group_wgs(int M, int nz, int nsplit) {
+    if (nsplit > 1) return ((M + 63) / 64) * 4 * nz * nsplit;
+    const int t256 = (M + 255) / 256;
+    if (t256 * 2 * nz >= 192) return t256 * 2 * nz;
+    if (t256 * 4 * nz >= 192) return t256 * 4 * nz;
+    if (((M + 127) / 128) * 4 * nz >= 192) return ((M + 127) / 128) * 4 * nz;
+    return ((M + 63) / 64) * 4 * nz;
+}
+// ca_odd != NULL: one launch for both parity groups of a block (flow0 = 0, flow_step = 1, nflow = all flows): the second
+// group's workgroups fill the half-empty last round of the first instead of starting a launch of their own; the tile is
+// still chosen for ONE group's count (what the tuning of the tile sizes was done with).
+void fwn_launch_cond2(const void* ca, const void* ca_odd, const void* Wc_base, float* P_base, long w_stride, long p_stride,
+                      int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
+                      int nsplit, hipStream_t st) {
+    CondBatch cb{(const bf16*)ca, (const bf16*)ca_odd, (const bf16*)Wc_base, P_base, w_stride, p_stride, flow0, flow_step, L,
                  M, cin, kcpad, part_base, part_stride, nsplit > 1 ? nsplit : 1};
-    const int nz = nflow * L;
+    const int nzl = nflow * L;                                   // matrices of this launch
+    const int nz = ca_odd ? ((nflow + 1) / 2) * L : nzl;         // matrices of one parity group: the tile rule's count
     if (cb.nsplit > 1) {        // only ever with few rows: the smallest tile
-        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nz, cb.nsplit), dim3(256), 0, st, cb, 4);
+        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nzl, cb.nsplit), dim3(256), 0, st, cb, 4);
         return;
     }
     // weights dominate the bytes and arrive from HBM: take the largest balanced tile that still
     // gives about one workgroup per CU (block 4: 256 x 256, block 5: 256 x 128 at the bench batch)
     const int t256 = (M + 255) / 256;
     if (t256 * 2 * nz >= 192) {
-        hipLaunchKernelGGL((cond_batch_kernel<256, 256, 4, 4, 64, 2>), dim3(t256 * 2, nz), dim3(1024), 0, st, cb, 2);
+        hipLaunchKernelGGL((cond_batch_kernel<256, 256, 4, 4, 64, 2>), dim3(t256 * 2, nzl), dim3(1024), 0, st, cb, 2);
         return;
     }
     if (t256 * 4 * nz >= 192) {
-        hipLaunchKernelGGL((cond_batch_kernel<256, 128, 8, 2, 64, 3>), dim3(t256 * 4, nz), dim3(1024), 0, st, cb, 4);
+        hipLaunchKernelGGL((cond_batch_kernel<256, 128, 8, 2, 64, 3>), dim3(t256 * 4, nzl), dim3(1024), 0, st, cb, 4);
         return;
     }
     if (((M + 127) / 128) * 4 * nz >= 192) {
-        hipLaunchKernelGGL((cond_batch_kernel<128, 128, 2, 2, 64, 3>), dim3(((M + 127) / 128) * 4, nz), dim3(256), 0,
+        hipLaunchKernelGGL((cond_batch_kernel<128, 128, 2, 2, 64, 3>), dim3(((M + 127) / 128) * 4, nzl), dim3(256), 0,
                            st, cb, 4);
     } else {
-        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nz), dim3(256), 0,
+        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nzl), dim3(256), 0,
                            st, cb, 4);
     }
+}
+void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
+                     int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
+                     int nsplit, hipStream_t st) {
+    fwn_launch_cond2(ca, nullptr, Wc_base, P_base, w_stride, p_stride, flow0, flow_step, nflow, L, M, cin, kcpad, part_base, part_stride,
+                     nsplit, st);
 }
 
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,

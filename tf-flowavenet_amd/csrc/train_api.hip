@@ -370,9 +370,15 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         if (hoist) {
             const long pn = (long)NF * L * m * 512;
             const int ns = fwn_cond_nsplit((int)m, ((NF + 1) / 2) * L, d0->kcpad);
-            for (int g_ = 0; g_ < 2 && g_ < NF; ++g_)
-                fwn_launch_cond((const bf16*)pl.cplanes + (size_t)(p ^ g_) * cplane_elems, d0->Wc[0], pl.P, (long)512 * d0->kcpad, m * 512, g_, 2,
-                                (NF - g_ + 1) / 2, L, (int)m, cin, d0->kcpad, pl.Ppart, pn, ns, st);
+            const bf16* ca0 = (const bf16*)pl.cplanes + (size_t)p * cplane_elems;
+            const bf16* ca1 = (const bf16*)pl.cplanes + (size_t)(p ^ 1) * cplane_elems;
+            if (NF > 1 && fwn_cond_merge((int)m, ((NF + 1) / 2) * L, ns)) {
+                fwn_launch_cond2(ca0, ca1, d0->Wc[0], pl.P, (long)512 * d0->kcpad, m * 512, 0, 1, NF, L, (int)m, cin, d0->kcpad, pl.Ppart, pn, ns, st);
+            } else {
+                for (int g_ = 0; g_ < 2 && g_ < NF; ++g_)
+                    fwn_launch_cond(g_ ? ca1 : ca0, d0->Wc[0], pl.P, (long)512 * d0->kcpad, m * 512, g_, 2, (NF - g_ + 1) / 2, L, (int)m, cin, d0->kcpad,
+                                    pl.Ppart, pn, ns, st);
+            }
             fwn_launch_cond_reduce(pl.P, pl.Ppart, pn, ns, pn, st);
         }
         for (int j = 0; j < NF; ++j) {
