@@ -1150,47 +1150,49 @@ void fwn_launch_cond_reduce(float* P, const float* part, long part_stride, int n
     const long g = (n4 + 255) / 256;
     hipLaunchKernelGGL(cond_reduce_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, st, P, part, part_stride, nsplit, n4);
 }
-// workgroups of one parity group's launch (nz matrices) under the tile rule of fwn_launch_cond2
-int fwn_cond_group_wgs(int M, int nz, int nsplit) {
-    if (nsplit > 1) return ((M + 63) / 64) * 4 * nz * nsplit;
-    const int t256 = (M + 255) / 256;
-    if (t256 * 2 * nz >= 192) return t256 * 2 * nz;
-    if (t256 * 4 * nz >= 192) return t256 * 4 * nz;
-    if (((M + 127) / 128) * 4 * nz >= 192) return ((M + 127) / 128) * 4 * nz;
-    return ((M + 63) / 64) * 4 * nz;
+// ---- tile choice for the hoisted conditioning ----
+// These launches are operand streams (K = cin up to 10240): a workgroup pulls (BM + BN) K 2 bytes through its CU, one
+// workgroup per CU, so a launch costs about rounds x (BM + BN) with rounds = ceil(workgroups / 256).  fwn_cond_tile picks
+// the tile with the least of that for nz matrices (ties: the larger tile); tiles: 0 = 256 x 256, 1 = 256 x 128,
+// 2 = 128 x 128, 3 = 64 x 128.
+static const int kCondBM[4] = {256, 256, 128, 64}, kCondBN[4] = {256, 128, 128, 128};
+static int cond_tile_wgs(int t, int M, int nz) { return ((M + kCondBM[t] - 1) / kCondBM[t]) * (512 / kCondBN[t]) * nz; }
+static int cond_tile_cost(int t, int M, int nz) { return ((cond_tile_wgs(t, M, nz) + 255) / 256) * (kCondBM[t] + kCondBN[t]); }
+static int fwn_cond_tile(int M, int nz, int* cost) {
+    int best = 0, bc = cond_tile_cost(0, M, nz);
+    for (int t = 1; t < 4; ++t) {
+        const int c = cond_tile_cost(t, M, nz);
+        if (c < bc) { bc = c; best = t; }
+    }
+    if (cost) *cost = bc;
+    return best;
 }
-// ca_odd != NULL: one launch for both parity groups of a block (flow0 = 0, flow_step = 1, nflow = all flows): the second
-// group's workgroups fill the half-empty last round of the first instead of starting a launch of their own; the tile is
-// still chosen for ONE group's count (what the tuning of the tile sizes was done with).
+// Both parity groups of a block in ONE launch (ca_odd) when that is cheaper than one launch per group by the same
+// measure, or when the K range is split (few rows: a launch latency less).
+bool fwn_cond_merge(int M, int nz_group, int nsplit) {
+    if (nsplit > 1) return true;
+    int c1 = 0, c2 = 0;
+    fwn_cond_tile(M, nz_group, &c1);
+    fwn_cond_tile(M, 2 * nz_group, &c2);
+    return c2 < 2 * c1;
+}
+// ca_odd != NULL: flows with an odd index read that plane (flow0 = 0, flow_step = 1, nflow = all flows of the block)
 void fwn_launch_cond2(const void* ca, const void* ca_odd, const void* Wc_base, float* P_base, long w_stride, long p_stride,
                       int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
                       int nsplit, hipStream_t st) {
     CondBatch cb{(const bf16*)ca, (const bf16*)ca_odd, (const bf16*)Wc_base, P_base, w_stride, p_stride, flow0, flow_step, L,
                  M, cin, kcpad, part_base, part_stride, nsplit > 1 ? nsplit : 1};
-    const int nzl = nflow * L;                                   // matrices of this launch
-    const int nz = ca_odd ? ((nflow + 1) / 2) * L : nzl;         // matrices of one parity group: the tile rule's count
+    const int nz = nflow * L;                                    // matrices of this launch
     if (cb.nsplit > 1) {        // only ever with few rows: the smallest tile
-        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nzl, cb.nsplit), dim3(256), 0, st, cb, 4);
+        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nz, cb.nsplit), dim3(256), 0, st, cb, 4);
         return;
     }
-    // weights dominate the bytes and arrive from HBM: take the largest balanced tile that still
-    // gives about one workgroup per CU (block 4: 256 x 256, block 5: 256 x 128 at the bench batch)
-    const int t256 = (M + 255) / 256;
-    if (t256 * 2 * nz >= 192) {
-        hipLaunchKernelGGL((cond_batch_kernel<256, 256, 4, 4, 64, 2>), dim3(t256 * 2, nzl), dim3(1024), 0, st, cb, 2);
-        return;
-    }
-    if (t256 * 4 * nz >= 192) {
-        hipLaunchKernelGGL((cond_batch_kernel<256, 128, 8, 2, 64, 3>), dim3(t256 * 4, nzl), dim3(1024), 0, st, cb, 4);
-        return;
-    }
-    if (((M + 127) / 128) * 4 * nz >= 192) {
-        hipLaunchKernelGGL((cond_batch_kernel<128, 128, 2, 2, 64, 3>), dim3(((M + 127) / 128) * 4, nzl), dim3(256), 0,
-                           st, cb, 4);
-    } else {
-        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nzl), dim3(256), 0,
-                           st, cb, 4);
-    }
+    const int t = FWN_TUNE(FWN_COND_TILE, -1) >= 0 ? FWN_TUNE(FWN_COND_TILE, -1) : fwn_cond_tile(M, nz, nullptr);
+    const int gx = ((M + kCondBM[t] - 1) / kCondBM[t]) * (512 / kCondBN[t]);
+    if (t == 0) hipLaunchKernelGGL((cond_batch_kernel<256, 256, 4, 4, 64, 2>), dim3(gx, nz), dim3(1024), 0, st, cb, 2);
+    else if (t == 1) hipLaunchKernelGGL((cond_batch_kernel<256, 128, 8, 2, 64, 3>), dim3(gx, nz), dim3(1024), 0, st, cb, 4);
+    else if (t == 2) hipLaunchKernelGGL((cond_batch_kernel<128, 128, 2, 2, 64, 3>), dim3(gx, nz), dim3(256), 0, st, cb, 4);
+    else hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(gx, nz), dim3(256), 0, st, cb, 4);
 }
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
                      int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,

@@ -28,11 +28,8 @@ void fwn_launch_res(const void* o, const void* hin, const void* W, const float* 
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
                      int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
                      int nsplit, hipStream_t st);
-// Both parity groups of a block in ONE launch pay when a group alone is either a handful of workgroups (one launch
-// latency less) or more than a round of the chip (the second group fills the first one's last round); a group of 128-255
-// workgroups - the bench batch - measured better as two launches.
-int fwn_cond_group_wgs(int M, int nz, int nsplit);
-static inline bool fwn_cond_merge(int M, int nz, int nsplit) { const int w = fwn_cond_group_wgs(M, nz, nsplit); return w < 128 || w >= 256; }
+// whether both parity groups of a block go into ONE launch (cheaper by the stream model of flow_kernels.hip, or split K)
+bool fwn_cond_merge(int M, int nz_group, int nsplit);
 void fwn_launch_cond2(const void* ca, const void* ca_odd, const void* Wc_base, float* P_base, long w_stride, long p_stride,
                       int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
                       int nsplit, hipStream_t st);
