@@ -523,6 +523,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     };
     auto hand_over = [&]() -> int {          // fork, then everything in `pending` to the side stream
         if (!fork_side()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: forking the side stream failed");
+        // (FWN_SKIP_WG: developer builds only - times the data-gradient chain alone; the gradients are then wrong)
         for (size_t k = 0; k < pending.size() && !FWN_TUNE(FWN_SKIP_WG, 0); ++k) {
             const int rc = weight_grads(pending[k], side);
             if (rc != FWN_OK) return rc;
