@@ -137,10 +137,15 @@ int fwn_gemm_launch(const fwn_gemm_desc* g, hipStream_t st) {
     for (int s = 0; s < g->nseg; ++s) nq_all += (g->seg[s].k + 63) / 64;
     const int M = g->M, ns = g->nsplit;
     const int n128 = (g->N + 127) / 128;
-    // the same fill rule as the inference GEMMs: the largest tile that still gives about a workgroup per CU
-    if (((M + 255) / 256) * n128 * ns >= 192)
+    // Tile by the operand-stream cost of the launch (one workgroup per CU pulls (BM + BN) K 2 bytes through it):
+    // ceil(workgroups / 256) x (BM + BN), the larger tile on ties.  For most shapes this is the old "largest tile that
+    // still gives ~a workgroup per CU"; it differs where 64 x 128 tiles would run a second, mostly empty round (the
+    // conditioning-gradient GEMMs of the late blocks: N = cin up to 10240 against a few hundred rows).
+    const int w256 = ((M + 255) / 256) * n128 * ns, w128 = ((M + 127) / 128) * n128 * ns, w64 = ((M + 63) / 64) * n128 * ns;
+    const int c256 = ((w256 + 255) / 256) * 384, c128 = ((w128 + 255) / 256) * 256, c64 = ((w64 + 255) / 256) * 192;
+    if (c256 <= c128 && c256 <= c64)
         hipLaunchKernelGGL((lin_kernel<256, 128, 8, 2, 3>), dim3(((M + 255) / 256) * n128, 1, ns), dim3(1024), 0, st, p, n128, nq_all);
-    else if (((M + 127) / 128) * n128 * ns >= 192)
+    else if (c128 <= c64)
         hipLaunchKernelGGL((lin_kernel<128, 128, 4, 2, 3>), dim3(((M + 127) / 128) * n128, 1, ns), dim3(512), 0, st, p, n128, nq_all);
     else {   // small M: 128-wide K chunks (256-byte LDS rows) - a third less time per unit of K on these latency chains
         int nq128 = 0;
