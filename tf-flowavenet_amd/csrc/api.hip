@@ -571,10 +571,12 @@ struct Carve {
 };
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static bool hoist_cond(const fwn_model_desc* m, int64_t M) {
+static bool hoist_cond(const fwn_model_desc* m, int64_t M, int cin) {
     if (m->cond_mode == 1) return false;
     if (m->cond_mode == 2) return true;
-    return M < 4096;  // small-M blocks: batch the weight-streaming cond GEMMs of all flows
+    // small-M blocks: batch the weight-streaming cond GEMMs of all flows - where the conditioning K is long enough to pay for
+    // the extra launch and the P round trip
+    return M < FWN_TUNE(FWN_HOIST_M, 4096) && cin >= FWN_TUNE(FWN_HOIST_CIN, 256);
 }
 
 static int hop_of(const fwn_model_desc* m) {
@@ -628,7 +630,7 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
     int npart = 0;
     for (int i = 0; i < m->n_block; ++i) {
         const int64_t M = B * T / ((int64_t)2 << i);
-        if (hoist_cond(m, M)) {
+        if (hoist_cond(m, M, m->flows[i * m->n_flow].cin)) {
             const size_t need = (size_t)m->n_flow * m->n_layer * M * 512 * 4;
             if (need > pbytes) pbytes = need;
             const size_t sp = (size_t)(fwn_cond_nsplit((int)M, ((m->n_flow + 1) / 2) * m->n_layer, m->flows[i * m->n_flow].kcpad) - 1) * need;
@@ -724,7 +726,7 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
     int poff = 0;
     for (int i = 0; i < m->n_block; ++i) {
         const int64_t M = B * T / ((int64_t)2 << i);
-        const bool hoist = hoist_cond(m, M);
+        const bool hoist = hoist_cond(m, M, m->flows[i * m->n_flow].cin);
         if (hoist) {
             rc = check_block_contiguity(m, i);
             if (rc) return rc;
@@ -787,7 +789,7 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
     int p = 0;
     for (int i = m->n_block - 1; i >= 0; --i) {
         const int64_t M = B * T / ((int64_t)2 << i);
-        const bool hoist = hoist_cond(m, M);
+        const bool hoist = hoist_cond(m, M, m->flows[i * m->n_flow].cin);
         if (hoist) {
             rc = check_block_contiguity(m, i);
             if (rc) return rc;
