@@ -709,48 +709,67 @@ __global__ __launch_bounds__(256) void up_dx_kernel(const float* __restrict__ dp
         dx[idx] = acc;
     }
 }
-// blockIdx.x = kernel tap (k, kw), the last one the bias; blockIdx.y = a contiguous chunk of the
-// (b, i) rows.  partial[chunk][tap] in a fixed order, summed by colsum_final_kernel.
+// blockIdx.x = kernel row k (its three kw taps together: one x load serves all three), the last one the bias;
+// blockIdx.y = a contiguous chunk of the (b, i) rows.  partial[chunk][tap = 3 k + kw | 6 s] in a fixed order, summed by
+// colsum_final_kernel.  The chunk's (row, w) pairs are flattened over the threads, four independent pairs in flight per
+// thread; addresses clamped and validity applied as a factor (a branch per load would serialise the round trips).
 __global__ __launch_bounds__(256) void up_dw_kernel(const float* __restrict__ dpre, const float* __restrict__ x, int B,
                                                     int H, int W, int s, float* __restrict__ partial) {
-    __shared__ double red[256];
-    const int tap = blockIdx.x, ntap = 6 * s;
+    __shared__ double red[3][256];
+    const int k = blockIdx.x, ntap = 6 * s;
     const long rows = (long)B * H, per = (rows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
-    double acc = 0.0;
-    if (tap < ntap) {
-        // the chunk's (row, w) pairs flattened over the threads, four independent pairs in flight per thread; addresses
-        // clamped and validity applied as a factor (a branch per load would serialise the round trips)
-        const int k = tap / 3, kw = tap % 3;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (k < 2 * s) {
         const long n = (r1 - r0) * W;
         for (long e0 = threadIdx.x; e0 < n; e0 += 4 * 256) {
-            float xv[4], dv[4];
+            float xv[4], dv[4][3];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const long e = min(e0 + 256L * u, n - 1);
                 const long r = r0 + e / W;
-                const int w = (int)(e % W), ww = w + kw - 1;
+                const int w = (int)(e % W);
                 const int i = (int)(r % H), b = (int)(r / H);
                 const int tau = i * s + k - s / 2;
-                const bool ok = e0 + 256L * u < n && tau >= 0 && tau < H * s && ww >= 0 && ww < W;
-                const long dj = ((long)b * H * s + min(max(tau, 0), H * s - 1)) * W + min(max(ww, 0), W - 1);
+                const bool ok = e0 + 256L * u < n && tau >= 0 && tau < H * s;
+                const long dr = ((long)b * H * s + min(max(tau, 0), H * s - 1)) * W;
                 xv[u] = x[r * W + w] * (ok ? 1.0f : 0.0f);
-                dv[u] = dpre[dj];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ww = w + kw - 1;
+                    dv[u][kw] = dpre[dr + min(max(ww, 0), W - 1)] * ((ww >= 0 && ww < W) ? 1.0f : 0.0f);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc += (double)xv[u] * (double)dv[u];
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[kw] += (double)xv[u] * (double)dv[u][kw];
         }
-    } else {
+    } else {        // bias: the sum of the chunk's dpre, eight loads in flight
         const long e0 = r0 * s * W, e1 = r1 * s * W;
-        for (long idx = e0 + threadIdx.x; idx < e1; idx += 256) acc += (double)dpre[idx];
+        for (long idx = e0 + threadIdx.x; idx < e1; idx += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = dpre[min(idx + 256L * u, e1 - 1)] * (idx + 256L * u < e1 ? 1.0f : 0.0f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[0] += (double)v[u];
+        }
     }
-    red[threadIdx.x] = acc;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) red[kw][threadIdx.x] = acc[kw];
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        if (threadIdx.x < st) {
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) red[kw][threadIdx.x] += red[kw][threadIdx.x + st];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * (ntap + 1) + tap] = (float)red[0];
+    if (threadIdx.x < 3) {
+        float* o = partial + (size_t)blockIdx.y * (ntap + 1);
+        if (k < 2 * s) o[3 * k + threadIdx.x] = (float)red[threadIdx.x][0];
+        else if (threadIdx.x == 0) o[ntap] = (float)red[0][0];
+    }
 }
 int fwn_up_bwd_chunks(int B, int H) { const long r = (long)B * H; return (int)(r < 64 ? 1 : (r / 16 > 64 ? 64 : r / 16)); }
 void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, int W, int s, const float* wk,
@@ -759,7 +778,7 @@ void fwn_up_bwd_launch(float* dy, const float* y, const float* x, int B, int H, 
     const int nc = fwn_up_bwd_chunks(B, H);
     hipLaunchKernelGGL(up_dpre_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, y, n);
     if (dx) hipLaunchKernelGGL(up_dx_kernel, dim3(ew_grid((long)B * H * W)), dim3(256), 0, st, dy, B, H, W, s, wk, dx);
-    hipLaunchKernelGGL(up_dw_kernel, dim3(6 * s + 1, nc), dim3(256), 0, st, dy, x, B, H, W, s, partial);
+    hipLaunchKernelGGL(up_dw_kernel, dim3(2 * s + 1, nc), dim3(256), 0, st, dy, x, B, H, W, s, partial);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((6 * s + 1 + 255) / 256), dim3(256), 0, st, partial, nc, 6 * s + 1, 1.0f, dwk_bias);
 }
 
