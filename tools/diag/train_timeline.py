@@ -1,7 +1,7 @@
 """Diagnostic: per-queue timeline of the LAST training step in a rocprofv3 kernel trace (tools/bench_train.py under
 rocprofv3 --kernel-trace): busy time per queue, overlap, and the gaps of the main queue.
 usage: train_timeline.py <kernel_trace.csv> [out.csv]"""
-import csv, sys, collections
+import csv, sys, collections, os
 rows = list(csv.DictReader(open(sys.argv[1])))
 print("columns:", list(rows[0].keys()))
 for r in rows:
@@ -62,5 +62,5 @@ for r in step:
     k = r["Kernel_Name"].split("(")[0][:64]
     agg[k][0] += 1; agg[k][1] += (r["e"] - r["s"]) / 1e3
 print("last step: %d launches, %.2f ms of kernel time" % (len(step), sum(v[1] for v in agg.values()) / 1e3))
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOPN', '32'))]:
     print("%8.1f us %4d x %7.2f us  %s" % (v[1], v[0], v[1] / v[0], k))
