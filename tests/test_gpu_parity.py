@@ -315,6 +315,37 @@ def _run_flow(model, d, hp, b, ti, xa, xb, ca_dev, inverse):
     return partial
 
 
+@pytest.mark.parametrize("blk,m", [(7, 63), (6, 126), (5, 300)])
+def test_conditioning_split_k_equals_the_one_pass_projection(full_model, blk, m):
+    """fwn_cond_split + fwn_cond_reduce (K dealt over workgroups: a single clip has 63 rows against cin = 10240 at the last
+    block) against fwn_cond: same matrices up to the order of the fp32 partial sums, bit-reproducible, and the split count
+    fwn_cond_splits picks for these shapes is > 1 (fwn_cond itself is held against the oracle by the single-flow tests)."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    d0 = model._packed.flow_descs[blk * hp.n_flow]
+    L, nf, cin, kc = hp.n_layer, hp.n_flow, d0.cin, d0.kcpad
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(blk)
+    ca = torch.from_numpy(rng.standard_normal((m, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    ns = int(lib.fwn_cond_splits(m, ((nf + 1) // 2) * L, kc))
+    assert ns > 1 and int(lib.fwn_cond_splits(4032, ((nf + 1) // 2) * L, kc)) == 1
+    P1 = torch.empty(nf, L, m, 512, device="cuda")
+    _lib.check(lib.fwn_cond(ca.data_ptr(), d0.Wc[0], P1.data_ptr(), 512 * kc, m * 512, 0, 1, nf, L, m, cin, kc, st), "fwn_cond")
+    outs = []
+    for rep in range(2):
+        P = torch.full((nf, L, m, 512), float("nan"), device="cuda")
+        part = torch.full((ns - 1, nf, L, m, 512), float("nan"), device="cuda")
+        _lib.check(lib.fwn_cond_split(ca.data_ptr(), d0.Wc[0], P.data_ptr(), 512 * kc, m * 512, 0, 1, nf, L, m, cin, kc,
+                                      part.data_ptr(), P.numel(), ns, st), "fwn_cond_split")
+        _lib.check(lib.fwn_cond_reduce(P.data_ptr(), part.data_ptr(), P.numel(), ns, P.numel(), st), "fwn_cond_reduce")
+        outs.append(P)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    scale = float(P1.abs().max())
+    assert float((outs[0] - P1).abs().max()) < 1e-5 * max(1.0, scale) * (cin ** 0.5)
+    assert lib.fwn_cond_split(ca.data_ptr(), d0.Wc[0], P1.data_ptr(), 512 * kc, m * 512, 0, 1, nf, L, m, cin, kc, None, 0, 4, st) == -1
+
+
 FLOW_CASES = [(0, 13, 1000), (0, 26, 1000), (1, 7, 1000), (3, 9, 700), (5, 4, 200), (7, 3, 70)]
 
 
