@@ -327,19 +327,27 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
         const int b = (int)(rt / ((long)H * s));
         const int i1 = (tau + s / 2) / s;
         const int k1 = tau + s / 2 - i1 * s;
-        float acc = bias;
+        // six taps, all loads unconditional (clamped addresses, validity as a factor): a branch per load costs a memory
+        // round trip each.  The products are added in the same order as before.
+        float xv[2][3], wv[2][3];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = i1 - j, k = k1 + j * s;
-            if (i >= 0 && i < H) {
-                const float* xr = in + ((size_t)b * H + i) * W;
+            const bool iok = i >= 0 && i < H;
+            const float* xr = in + ((size_t)b * H + min(max(i, 0), H - 1)) * W;
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ws = w - kw + 1;
-                    if (ws >= 0 && ws < W) acc += xr[ws] * wk[k * 3 + kw];
-                }
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ws = w - kw + 1;
+                const bool ok = iok && ws >= 0 && ws < W;
+                xv[j][kw] = xr[min(max(ws, 0), W - 1)] * (ok ? 1.0f : 0.0f);
+                wv[j][kw] = wk[min(k, 2 * s - 1) * 3 + kw];
             }
         }
+        float acc = bias;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc += xv[j][kw] * wv[j][kw];
         acc = fmaxf(acc, 0.4f * acc);
         if (out_f32) out_f32[idx] = acc;
         if (out_planes) {
@@ -455,11 +463,29 @@ __global__ __launch_bounds__(1024) void prior_kernel(const float* __restrict__ z
     __shared__ double r1[1024], r2[1024];
     const int tid = threadIdx.x;
     double s = 0.0, p = 0.0;
-    for (long i = tid; i < n; i += 1024) {
+    // eight loads in flight per thread, added in the same ascending order as one at a time (one dependent load per
+    // iteration was a chain of n / 1024 memory round trips: 40 us for the bench batch, on the critical path of the pass)
+    long i = tid;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = z[i + 1024L * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)v[u] * (double)v[u];
+    }
+    for (; i < n; i += 1024) {
         const double v = z[i];
         s += v * v;
     }
-    for (int i = tid; i < n_partial; i += 1024) p += partial[i];
+    int j = tid;
+    for (; j + 7 * 1024 < n_partial; j += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[j + 1024 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p += v[u];
+    }
+    for (; j < n_partial; j += 1024) p += partial[j];
     r1[tid] = s;
     r2[tid] = p;
     __syncthreads();
