@@ -217,11 +217,12 @@ def loss_and_grads(self, tp, params, x, c):
             dh_next = dh
         # front conv
         ya_bf = xa.to(torch.bfloat16)
-        if ch % 8 == 0:
-            wn(wp + "/Conv_front", wgrad(ya_bf, dh_next, ch, 256, (-1, 0, 1)), 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
-        else:       # rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
-            part = weight_grad_partials(ya_bf, m, ch, transpose_shift(dh_next, m, 256), 256, shifts=(-1, 0, 1), ti=ti)
-            wn(wp + "/Conv_front", part, 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
+        kxp = max(ch, 8)        # rows of fewer than 8 channels are padded to 8 (16 bytes): the same TN job for every block
+        if kxp != ch:
+            ya8 = torch.zeros(m, kxp, dtype=torch.bfloat16, device=dev)
+            ya8[:, :ch] = ya_bf
+            ya_bf = ya8
+        wn(wp + "/Conv_front", wgrad(ya_bf, dh_next, kxp, 256, (-1, 0, 1)), 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
         parts = tn_weight_grad_group(tnj, m, ti)
         _wn_group(self, grads, [(nm, parts[jb] if isinstance(jb, int) else jb, k_, c0_, shp_, sc_, rs_, cs_)
                                for nm, jb, k_, c0_, shp_, sc_, rs_, cs_ in wnj])

@@ -90,7 +90,7 @@ void fwn_ew_coupling_fwd_ex(float* yb, const float* Z, const float* ez, long n, 
 void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
                          int ldz, float* dzz, hipStream_t st);
 void fwn_ew_coupling_bwd_ex(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
-                            int ldz, float* dzz, const float* ya, void* ya_bf, hipStream_t st);
+                            int ldz, float* dzz, const float* ya, void* ya_bf, int ldya, hipStream_t st);
 void fwn_ew_gate_bwd(const void* do_, int ld_do, const void* aux, long n, void* dpre, hipStream_t st);
 int fwn_colsum_blocks(long M, int C);
 void fwn_ew_colsum_prod(const float* A, const float* B, long M, int C, float scale, float* partial, float* out,

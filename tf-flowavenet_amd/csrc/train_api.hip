@@ -120,7 +120,6 @@ struct Plan {               // every buffer of one call
     FlowSaved* saved;       // host array, owned by the caller of plan()
     // backward temporaries, sized for the largest block and reused flow after flow
     void* xhl; float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; double* wn_scratch; double* up_wn;
-    void* dyt; void* xt; float* fr_part;
     // the ones the weight-gradient GEMMs read.  One set without a side stream; with one, a set per flow: its weight
     // gradients run on the side stream while the main stream goes on differentiating
     std::vector<BwdSet> sets;
@@ -143,7 +142,7 @@ long tn_partial_floats(const fwn_model_desc* md, int i, long m) {
         sp[n++] = {256, 512, 3};
         sp[n++] = {cin, 512, 1};
     }
-    if (ch % 8 == 0) sp[n++] = {ch, 256, 3};
+    sp[n++] = {ch < 8 ? 8 : ch, 256, 3};
     long tot = 0;
     for (int g0 = 0; g0 < n; g0 += FWN_MAX_GROUP) {
         const int cnt = n - g0 < FWN_MAX_GROUP ? n - g0 : FWN_MAX_GROUP;
@@ -151,13 +150,6 @@ long tn_partial_floats(const fwn_model_desc* md, int i, long m) {
         for (int j = g0; j < g0 + cnt; ++j) tot += (long)ns * ((long)sp[j].ntap * sp[j].kx + 1) * sp[j].n;
     }
     return tot;
-}
-
-int front_small_nsplit(long mp, int rows1) {      // training.weight_grad_partials, the branch rows + 1 < 512
-    const long nchunks = mp / 64, n128 = 2;
-    const long b = (256 + (((rows1 + 63) / 64) * n128) - 1) / (((rows1 + 63) / 64) * n128);
-    const long r = nchunks < b ? nchunks : b;
-    return (int)(r < 1 ? 1 : r);
 }
 
 void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
@@ -209,13 +201,13 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
     }
     pl.out2 = (float*)b.take(16);
     // backward temporaries: maxima over the blocks
-    size_t dz_b = 0, dzz_b = 0, ya_b = 0, tn_b = 0, wn_b = 0, sg_b = 0, dyt_b = 0, xt_b = 0, fr_b = 0;
+    size_t dz_b = 0, dzz_b = 0, ya_b = 0, tn_b = 0, wn_b = 0, sg_b = 0;
     for (int i = 0; i < md->n_block; ++i) {
         const long ch = 1L << i, m = B * T / (2 * ch), cin = (long)half * (2 << i);
         const long ldz = 2 * ch > 8 ? 2 * ch : 8;
         dz_b = dz_b > (size_t)m * ldz * 2 ? dz_b : (size_t)m * ldz * 2;
         dzz_b = dzz_b > (size_t)m * 2 * ch * 4 ? dzz_b : (size_t)m * 2 * ch * 4;
-        ya_b = ya_b > (size_t)m * ch * 2 ? ya_b : (size_t)m * ch * 2;
+        ya_b = ya_b > (size_t)m * (ch < 8 ? 8 : ch) * 2 ? ya_b : (size_t)m * (ch < 8 ? 8 : ch) * 2;      // rows padded to 8 channels (16 bytes)
         const size_t tnb = (size_t)tn_partial_floats(md, i, m) * 4;
         tn_b = tn_b > tnb ? tn_b : tnb;
         // weight-norm scratch of a group of <= 16 jobs: bounded by the 16 largest jobs (K/32 + 1) N 2 doubles; the
@@ -228,13 +220,6 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
         wn_b = wn_b > wn * 8 ? wn_b : wn * 8;
         const size_t sg = (size_t)fwn_small_grads_blocks(m, (int)ch) * 6 * ch * 8;
         sg_b = sg_b > sg ? sg_b : sg;
-        if (ch % 8) {
-            const long mp = roundup(m, 64), rows1 = 3 * ch + 1;
-            dyt_b = dyt_b > (size_t)256 * mp * 2 ? dyt_b : (size_t)256 * mp * 2;
-            xt_b = xt_b > (size_t)rows1 * mp * 2 ? xt_b : (size_t)rows1 * mp * 2;
-            const size_t fr = (size_t)front_small_nsplit(mp, (int)rows1) * rows1 * 256 * 4;
-            fr_b = fr_b > fr ? fr_b : fr;
-        }
     }
     pl.xhl = b.take((size_t)B * T * 2);        // front conv of the blocks with Ch >= 32: bf16 (hi | lo) image of the plane
     pl.dzz = (float*)b.take(dzz_b);
@@ -259,9 +244,6 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
     pl.tn_part = (float*)b.take(tn_b);
     pl.wn_scratch = (double*)b.take(wn_b);
     pl.up_wn = (double*)b.take(1024 * 8);
-    pl.dyt = b.take(dyt_b);
-    pl.xt = b.take(xt_b);
-    pl.fr_part = (float*)b.take(fr_b);
     // up-sampling backward
     pl.up_dy = (float*)b.take((size_t)B * T * nmel * 4);
     pl.up_y = (float*)b.take((size_t)B * T * nmel * 4);
@@ -440,7 +422,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         evp->next = 0;
     }
     struct Deferred {
-        TnList tn; WnItem wn[4 + 7 * FWN_MAX_LAYERS]; int nwn; long m, ti; int ch, i; bool small_front; const BwdSet* w; const void* dh0;
+        TnList tn; WnItem wn[4 + 7 * FWN_MAX_LAYERS]; int nwn; long m, ti; int ch, i; const BwdSet* w;
         const fwn_flow_train_desc* td;
         const float* an;                                   // the flow's ActNorm table (totals of the small gradients)
         fwn_gemm_desc dca[FWN_MAX_LAYERS]; int ndca;      // conditioning-gradient GEMMs (accumulate into the mel image: order kept)
@@ -455,18 +437,6 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             fwn_small_grads_final(D.an, m, ch, (const long long*)t->br[D.i], (const long long*)t->zcol[D.i], D.w->sg, D.td->d_an_b, D.td->d_an_logs,
                                   D.td->d_zscale, s_);
         for (int k = 0; k < D.ndca; ++k) fwn_gemm_launch(&D.dca[k], s_);
-        if (D.small_front) {       // rows of fewer than 8 channels are not 16-byte aligned: transposed-copy path
-            const long mp = roundup(m, 64);
-            const int rows1 = 3 * ch + 1;
-            fwn_transpose_launch(D.dh0, (int)m, 256, 256, 0, 0, 1, 0, pl.dyt, (int)mp, 0, s_);
-            fwn_transpose_launch(D.w->ya_bf, (int)m, ch, ch, -1, 1, 3, (int)ti, pl.xt, (int)mp, 1, s_);
-            const int ns = front_small_nsplit(mp, rows1);
-            Seg a{pl.xt, rows1, (int)mp, (int)mp, 0, 0};
-            fwn_gemm_desc g = gemm_desc(&a, 1, pl.dyt, (int)mp, 256, rows1, 0, pl.fr_part, 256, true);
-            g.nsplit = ns; g.split_stride = (int64_t)rows1 * 256;
-            fwn_gemm_launch(&g, s_);
-            D.wn[D.nwn++] = WnItem{-1, pl.fr_part, ns, (long)rows1 * 256, rows1, 256, &D.td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[D.i], nullptr};
-        }
         // all weight gradients of the flow: grouped TN GEMM(s), then the grouped weight-norm backward(s)
         float* part = pl.tn_part;
         for (int g0 = 0; g0 < tn.n; g0 += FWN_MAX_GROUP) {
@@ -553,7 +523,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             float* dca = pl.dcplanes + (size_t)pp * cplane_elems;
             // coupling
             // (also: the bf16 copy of y_a for the front conv's weight gradient, and the zero padding of dZ's rows)
-            fwn_ew_coupling_bwd_ex(gb, xb, s.z, td->ez, m * ch, ch, (float)(1.0 / (2.0 * (double)m * ch)), w.dz, ldz, pl.dzz, xa, w.ya_bf, st);
+            fwn_ew_coupling_bwd_ex(gb, xb, s.z, td->ez, m * ch, ch, (float)(1.0 / (2.0 * (double)m * ch)), w.dz, ldz, pl.dzz, xa, w.ya_bf, ch < 8 ? 8 : ch, st);
             {
                 Seg a{w.dz, m, ldz, ldz, 0, 0};
                 fwn_gemm_desc g = gemm_desc(&a, 1, td->WzT, ldz, 256, m, 0, w.du, 256, false);
@@ -622,10 +592,10 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 dh_next = w.dh[l];
             }
             // front conv
-            D.dh0 = dh_next;
-            D.small_front = ch % 8 != 0;
-            if (!D.small_front)
-                add_wn(tn.add(w.ya_bf, ch, dh_next, 256, ch, 256, 3, -1, 1), &td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[i], nullptr);
+            // front conv: y_a rows are padded to 8 channels (16 bytes: the unit the TN GEMM moves), so every block's front weight
+            // gradient is one more job of the group; front_rows maps logical row tap Ch + c to GEMM row tap max(Ch, 8) + c'
+            const int kxp = ch < 8 ? 8 : ch;
+            add_wn(tn.add(w.ya_bf, kxp, dh_next, 256, kxp, 256, 3, -1, 1), &td->front, 3 * ch, 256, 0, 1.0f, t->front_rows[i], nullptr);
             if (!side) {
                 const int rc = weight_grads(D, st);
                 if (rc != FWN_OK) return rc;

@@ -279,16 +279,18 @@ __global__ __launch_bounds__(256) void coupling_bwd_kernel(float* __restrict__ g
                                                            const float* __restrict__ Z, const float* __restrict__ ez,
                                                            long n, int Ch, float cls, bf16* __restrict__ dZ, int ldz,
                                                            float* __restrict__ dzz, const float* __restrict__ ya,
-                                                           bf16* __restrict__ ya_bf) {
+                                                           bf16* __restrict__ ya_bf, int ldya) {
     // ya / ya_bf (optional): also the bf16 copy of the other plane that the front conv's weight gradient reads, and the
     // zero padding of dZ's rows (ldz > 2 Ch) - two launches less per flow
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const long m = i / Ch;
         const int c = (int)(i - m * Ch);
-        if (ya_bf) {
-            ya_bf[i] = (bf16)ya[i];
-            if (c == 0)
+        if (ya_bf) {        // rows of ldya >= Ch channels, zero padded (16-byte rows for the TN GEMM)
+            ya_bf[m * ldya + c] = (bf16)ya[i];
+            if (c == 0) {
+                for (int k = Ch; k < ldya; ++k) ya_bf[m * ldya + k] = (bf16)0.0f;
                 for (int k = 2 * Ch; k < ldz; ++k) dZ[m * ldz + k] = (bf16)0.0f;
+            }
         }
         const float ls = Z[m * 2 * Ch + c] * ez[c], t = Z[m * 2 * Ch + Ch + c] * ez[Ch + c];
         const float e = __expf(-ls), gb = g[i], o = ob[i];
@@ -656,12 +658,12 @@ void fwn_ew_coupling_fwd_ex(float* yb, const float* Z, const float* ez, long n, 
 void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
                          int ldz, float* dzz, hipStream_t st) {
     hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, ob, Z, ez, n, Ch, cls, (bf16*)dZ, ldz, dzz,
-                       (const float*)nullptr, (bf16*)nullptr);
+                       (const float*)nullptr, (bf16*)nullptr, 0);
 }
 void fwn_ew_coupling_bwd_ex(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
-                            int ldz, float* dzz, const float* ya, void* ya_bf, hipStream_t st) {
+                            int ldz, float* dzz, const float* ya, void* ya_bf, int ldya, hipStream_t st) {
     hipLaunchKernelGGL(coupling_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, ob, Z, ez, n, Ch, cls, (bf16*)dZ, ldz, dzz, ya,
-                       (bf16*)ya_bf);
+                       (bf16*)ya_bf, ldya);
 }
 void fwn_ew_gate_bwd(const void* do_, int ld_do, const void* aux, long n, void* dpre, hipStream_t st) {
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, st, (const bf16*)do_, ld_do, (const bf16*)aux, n, (bf16*)dpre);

@@ -242,7 +242,8 @@ class _TrainPack:
         # logical row of a weight gradient -> row of the GEMM that computed it in device channel order
         self.cond_rows = [self._i32(("cond_rows", i), np.argsort(packing.cond_src_k(i, half_)[:half_ * (2 << i)]))
                           for i in range(hp.n_block)]
-        self.front_rows = [self._i32(("front_rows", i), np.concatenate([tap * (1 << i) + packing.bitrev_table(i) for tap in range(3)]))
+        # logical row tap Ch + c of a front weight gradient -> row of the TN GEMM over y_a rows padded to max(Ch, 8) channels
+        self.front_rows = [self._i32(("front_rows8", i), np.concatenate([tap * max(1 << i, 8) + packing.bitrev_table(i) for tap in range(3)]))
                            for i in range(hp.n_block)]
         self.csrc64 = [self._i64(("csrc", i), packing.cond_src_k(i, hp.num_mels // 2)[:(hp.num_mels // 2) * (2 << i)])
                        for i in range(hp.n_block)]
