@@ -389,13 +389,16 @@ typedef struct fwn_conv_grad {          /* one trainable convolution */
 typedef struct fwn_flow_train_desc {
     const void* WfT;                            /* [Ch][768]   front conv, transposed: K = tap*256 + n          */
     const void* WdT[FWN_MAX_LAYERS];            /* [256][1536] dilated filter|gate, K = tap*512 + (f|g)*256 + n */
-    const void* WcT[FWN_MAX_LAYERS];            /* [cin][512]  conditioning filter|gate                         */
+    const void* WcT[FWN_MAX_LAYERS];            /* [cin][512]  conditioning filter|gate, row stride wct_ld      */
     const void* WresT[FWN_MAX_LAYERS];          /* [256][256]  layers 0..L-2                                    */
     const void* Wskip;  const void* WskipT_all; /* [256][L*256], [L*256][256]                                   */
     const void* Wfin;   const void* WfinT;      /* [256][256] natural K order, and transposed                   */
     const void* Wz;     const void* WzT;        /* [2Ch][256] rows in plane order, [256][ldz]                   */
     const float* bskip; const float* bfin; const float* bz; const float* ez;    /* tables in device channel order */
-    int32_t ldz, reserved;                      /* max(8, 2Ch)                                                  */
+    int32_t ldz;                                /* max(8, 2Ch)                                                  */
+    int32_t wct_ld;                             /* row stride of WcT in elements (0: 512).  L*512 with WcT[l] =
+                                                   WcT[0] + l*512: the layers side by side in one [cin][L*512] matrix -
+                                                   the conditioning gradient of a flow is then ONE GEMM over K = L*512 */
     fwn_conv_grad front, final_, zero;          /* Conv_front, Conv_final, ZeroConv1d (g = NULL)                */
     fwn_conv_grad filt[FWN_MAX_LAYERS], gate[FWN_MAX_LAYERS], res[FWN_MAX_LAYERS], skip[FWN_MAX_LAYERS],
         filt_c[FWN_MAX_LAYERS], gate_c[FWN_MAX_LAYERS];

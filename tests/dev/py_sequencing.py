@@ -185,6 +185,7 @@ def loss_and_grads(self, tp, params, x, c):
             rp = "%s/ResBlock_%d" % (wp, l)
             wn(rp + "/skip_conv", wgrad(o[l], ds, 256, 256), 256, 0, (1, 256, 256))
         dh_next = None
+        dpres = [None] * L
         for l in range(L - 1, -1, -1):
             rp = "%s/ResBlock_%d" % (wp, l)
             dil = 3 ** l
@@ -210,11 +211,12 @@ def loss_and_grads(self, tp, params, x, c):
             jc = wgrad(ca, dpre, cin, 512)
             wn(rp + "/filter_conv_c", jc, cin, 0, (1, cin, 256), row_src=tp.cond_rows[i])
             wn(rp + "/gate_conv_c", jc, cin, 256, (1, cin, 256), row_src=tp.cond_rows[i])
-            gemm([(dpre, 512, 0, 0)], t["WcT"][l], cin, m, out=dca, accumulate=True)
+            dpres[l] = dpre          # the conditioning gradient of the flow is one GEMM over all layers (K = L * 512), below
             segs = [(dpre, 512, -(tap - 1) * dil, tap * 512) for tap in range(3)]
             dh = gemm(segs, t["WdT"][l], 256, m, ti=ti, res=dh_next, rscale=SQH if dh_next is not None else 0.0,
                       mask=h[0] if l == 0 else None)
             dh_next = dh
+        gemm([(dpres[l], 512, 0, l * 512) for l in range(L)], t["WcT_all"], cin, m, out=dca, accumulate=True)
         # front conv
         ya_bf = xa.to(torch.bfloat16)
         kxp = max(ch, 8)        # rows of fewer than 8 channels are padded to 8 (16 bytes): the same TN job for every block

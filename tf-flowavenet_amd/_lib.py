@@ -61,7 +61,7 @@ class FlowTrainDesc(C.Structure):
     """fwn_flow_train_desc (include/fwn.h)."""
     _fields_ = [("WfT", vp), ("WdT", vp * FWN_MAX_LAYERS), ("WcT", vp * FWN_MAX_LAYERS), ("WresT", vp * FWN_MAX_LAYERS),
                 ("Wskip", vp), ("WskipT_all", vp), ("Wfin", vp), ("WfinT", vp), ("Wz", vp), ("WzT", vp),
-                ("bskip", vp), ("bfin", vp), ("bz", vp), ("ez", vp), ("ldz", i32), ("reserved", i32),
+                ("bskip", vp), ("bfin", vp), ("bz", vp), ("ez", vp), ("ldz", i32), ("wct_ld", i32),
                 ("front", ConvGrad), ("final_", ConvGrad), ("zero", ConvGrad),
                 ("filt", ConvGrad * FWN_MAX_LAYERS), ("gate", ConvGrad * FWN_MAX_LAYERS), ("res", ConvGrad * FWN_MAX_LAYERS),
                 ("skip", ConvGrad * FWN_MAX_LAYERS), ("filt_c", ConvGrad * FWN_MAX_LAYERS), ("gate_c", ConvGrad * FWN_MAX_LAYERS),

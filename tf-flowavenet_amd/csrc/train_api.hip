@@ -576,15 +576,18 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 add_wn(jc, &td->filt_c[l], cin, 256, 0, 1.0f, t->cond_rows[i], nullptr);
                 add_wn(jc, &td->gate_c[l], cin, 256, 256, 1.0f, t->cond_rows[i], nullptr);
                 {
-                    Seg a{w.dpre[l], m, 512, 512, 0, 0};
-                    fwn_gemm_desc g = gemm_desc(&a, 1, td->WcT[l], 512, cin, m, 0, dca, cin, true);
-                    g.accumulate = 1;
-                    // nothing in the flow chain reads the conditioning gradient: with a side stream it leaves the chain
-                    if (side) D.dca[D.ndca++] = g;
-                    else fwn_gemm_launch(&g, st);
+                    const bool merged = td->wct_ld == L * 512;          // the layers' WcT side by side: one GEMM below, after the loop
+                    if (!merged) {
+                        Seg a{w.dpre[l], m, 512, 512, 0, 0};
+                        fwn_gemm_desc g = gemm_desc(&a, 1, td->WcT[l], td->wct_ld ? td->wct_ld : 512, cin, m, 0, dca, cin, true);
+                        g.accumulate = 1;
+                        // nothing in the flow chain reads the conditioning gradient: with a side stream it leaves the chain
+                        if (side) D.dca[D.ndca++] = g;
+                        else fwn_gemm_launch(&g, st);
+                    }
                     Seg sg[3];
                     for (int tap = 0; tap < 3; ++tap) sg[tap] = {w.dpre[l], m, 512, 512, -(tap - 1) * dil, tap * 512};
-                    g = gemm_desc(sg, 3, td->WdT[l], 1536, 256, m, (int)ti, w.dh[l], 256, false);
+                    fwn_gemm_desc g = gemm_desc(sg, 3, td->WdT[l], 1536, 256, m, (int)ti, w.dh[l], 256, false);
                     if (dh_next) { g.R = dh_next; g.ldr = 256; g.rscale = SQH; }
                     if (l == 0) { g.mask = s.h[0]; g.ldmask = 256; }
                     fwn_gemm_launch(&g, st);
@@ -592,6 +595,17 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 dh_next = w.dh[l];
             }
             // front conv
+            if (td->wct_ld == L * 512) {      // conditioning gradient of the flow: dca += [dpre_0 | dpre_1 | ..] [Wc_0 ; Wc_1 ; ..]
+                Seg sg[FWN_MAX_LAYERS];
+                for (int l = 0; l < L; ++l) {
+                    TREQUIRE((const char*)td->WcT[l] == (const char*)td->WcT[0] + (size_t)l * 512 * 2, "fwn_train_loss_and_grads: wct_ld = L*512 needs WcT[l] = WcT[0] + l*512");
+                    sg[l] = {w.dpre[l], m, 512, 512, 0, l * 512};
+                }
+                fwn_gemm_desc g = gemm_desc(sg, L, td->WcT[0], L * 512, cin, m, 0, dca, cin, true);
+                g.accumulate = 1;
+                if (side) D.dca[D.ndca++] = g;
+                else fwn_gemm_launch(&g, st);
+            }
             // front conv: y_a rows are padded to 8 channels (16 bytes: the unit the TN GEMM moves), so every block's front weight
             // gradient is one more job of the group; front_rows maps logical row tap Ch + c to GEMM row tap max(Ch, 8) + c'
             const int kxp = ch < 8 ? 8 : ch;

@@ -367,7 +367,9 @@ class _TrainPack:
                 job(rp + "/Conv_filter", taps[tap], 256, id256, 256, wdt, tap * 512, True)
                 job(rp + "/Conv_gate", taps[tap], 256, id256, 256, wdt, tap * 512 + 256, True)
             t["WdT"].append(wdt)
-            wct = bz(cin, 512)
+            if l == 0:
+                t["WcT_all"] = bz(cin, L * 512)          # the layers side by side: one K = L * 512 GEMM for the conditioning gradient
+            wct = t["WcT_all"][:, l * 512:(l + 1) * 512]
             job(rp + "/filter_conv_c", csrc, cin, id256, 256, wct, 0, True)
             job(rp + "/gate_conv_c", csrc, cin, id256, 256, wct, 256, True)
             t["WcT"].append(wct)
@@ -465,7 +467,10 @@ class _TrainPack:
             wc = bz(512, kcpad)
             self._pack(rp + "/filter_conv_c", csrc, rows_f, kcpad, 512, wc)
             self._pack(rp + "/gate_conv_c", csrc, rows_g, kcpad, 512, wc)
-            t["WcT"].append(transpose_shift(wc, 512, cin, ld_dst=512))            # [cin][512]
+            if l == 0:
+                t["WcT_all"] = bz(cin, L * 512)
+            t["WcT_all"][:, l * 512:(l + 1) * 512] = transpose_shift(wc, 512, cin, ld_dst=512)            # [cin][512] of layer l
+            t["WcT"].append(t["WcT_all"][:, l * 512:(l + 1) * 512])
             if l + 1 < L:
                 wr = bz(256, 256)
                 self._pack(rp + "/res_conv", id256, id256, 256, 256, wr)
@@ -612,6 +617,7 @@ class GradEngine:
                     wp = fp + "/WaveNet"
                     f.WfT, f.Wskip, f.WskipT_all = ptr(t["WfT"]), ptr(t["Wskip"]), ptr(t["WskipT_all"])
                     f.Wfin, f.WfinT, f.Wz, f.WzT, f.ldz = ptr(t["Wfin"]), ptr(t["WfinT"]), ptr(t["Wz"]), ptr(t["WzT"]), int(t["ldz"])
+                    f.wct_ld = int(t["WcT_all"].stride(0))
                     for l in range(L):
                         rp = "%s/ResBlock_%d" % (wp, l)
                         f.WdT[l], f.WcT[l] = ptr(t["WdT"][l]), ptr(t["WcT"][l])
