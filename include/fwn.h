@@ -39,6 +39,7 @@ extern "C" {
 #define FWN_ERR_ARG (-1)           /* bad argument (null pointer, size, alignment, config) */
 #define FWN_ERR_HIP (-2)           /* a HIP launch or runtime call failed */
 #define FWN_ERR_WORKSPACE (-3)     /* workspace too small */
+#define FWN_ERR_CALLBACK (-4)      /* a host callback (fwn_block_done_fn) asked to stop */
 
 int fwn_version(void);
 const char* fwn_last_error(void);
@@ -381,7 +382,10 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
  * reference's layouts and (d) where each gradient goes (e.g. views of one flat buffer that an RCCL all-reduce sums).
  * Everything else lives in `workspace`.  on_block_done(user, i) is called on the host once every launch that writes
  * block i's gradients has been enqueued (blocks finish last to first; -1 = the up-sampling convs): the hook a
- * data-parallel step uses to start that block's all-reduce under the rest of the backward pass, or to cut a graph. */
+ * data-parallel step uses to start that block's all-reduce under the rest of the backward pass, or to cut a graph.
+ * The hook returns 0 to go on; any other value stops the sequencing at once (nothing further is enqueued) and
+ * fwn_train_loss_and_grads returns FWN_ERR_CALLBACK - a host that cannot let an exception cross the C frame reports
+ * it this way and re-raises after the call. */
 typedef struct fwn_conv_grad {          /* one trainable convolution */
     const float* V; const float* g;     /* kernel [K][N] fp32 (reference layout, K = kernel_size * C_in), weight-norm g [N] or NULL */
     float* dV; float* dg; float* db;    /* gradients of kernel, g (NULL iff g NULL) and bias */
@@ -420,7 +424,7 @@ typedef struct fwn_train_desc {
      * read.  Same results. */
     void* side_stream;
 } fwn_train_desc;
-typedef void (*fwn_block_done_fn)(void* user, int block);
+typedef int (*fwn_block_done_fn)(void* user, int block);
 size_t fwn_train_workspace_bytes(const fwn_train_desc* t, int64_t B, int64_t T);
 /* x [B][T] fp32, mel [B][T/hop][num_mels] fp32 -> out3 = (loss, log_p, logdet) fp32 on device + every gradient. */
 int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B, int64_t T, const float* x, const float* mel,

@@ -408,3 +408,72 @@ def test_synthesize_splits_batches_under_the_per_call_addressing_limit():
     assert S.max_clips_per_call(hp, 220672) == 19          # 10 s clips: 19 per call, 20 would exceed the limit
     assert hp.n_layer * (19 * 220672 // 2) * 512 < 1 << 31 <= hp.n_layer * (20 * 220672 // 2) * 512
     assert S.max_clips_per_call(hp, 16128) == 260 and S.max_clips_per_call(hp, 5_000_000) == 0
+
+
+def test_restore_raises_on_a_checkpoint_of_another_model_instead_of_starting_over(tmp_path):
+    """a checkpoint that READS but does not fit the model (other hparams: missing entry, other size) must
+    raise - skipping it as 'unreadable' would restart at step 0 and overwrite the run's files.  Only I/O / container
+    errors are skipped."""
+    import os
+    import torch
+    from tf_flowavenet_amd import train as T
+
+    class _Opt:
+        def __init__(self, n=2):
+            self.w, self.m, self.v, self.global_step, self.group = torch.zeros(n), torch.zeros(n), torch.zeros(n), 0, None
+
+        def master_views(self):
+            return {"p": self.w}
+
+    class _Tr:
+        def __init__(self, n=2):
+            self.opt = _Opt(n)
+
+    tr = _Tr()
+    tr.opt.w[:] = 7.0
+    tr.opt.global_step = 300
+    T.save_checkpoint(str(tmp_path / "flowavenet_model.ckpt-300.npz"), tr)
+    with pytest.raises(ValueError, match="shape"):
+        T.restore_checkpoint(str(tmp_path), _Tr(n=3))            # same names, another size
+    np.savez(str(tmp_path / "flowavenet_model.ckpt-400.npz"), q=np.zeros(2))
+    with pytest.raises(KeyError, match="does not belong"):
+        T.restore_checkpoint(str(tmp_path), _Tr())               # a readable .npz without this model's entries
+    os.remove(str(tmp_path / "flowavenet_model.ckpt-400.npz"))
+    with open(str(tmp_path / "flowavenet_model.ckpt-500.npz"), "wb") as f:
+        f.write(b"PK\x03\x04 torn by a crash")
+    fresh = _Tr()
+    assert T.restore_checkpoint(str(tmp_path), fresh) == 300 and float(fresh.opt.w[0]) == 7.0     # the torn file is skipped
+
+
+def test_dataset_keeps_a_bounded_number_of_file_descriptors_open(tmp_path):
+    """every numpy memmap pins a descriptor; the LRU of open utterances must stay far below the usual soft
+    RLIMIT_NOFILE of 1024 and release descriptors when it evicts."""
+    import os
+    from tf_flowavenet_amd import train as T
+    from tf_flowavenet_amd.hparams import default_hparams
+    hp = default_hparams().replace(max_time_steps=512, hop_size=256, batch_size=4, test_size=2)
+    os.makedirs(str(tmp_path / "audios"))
+    os.makedirs(str(tmp_path / "mels"))
+    n = 40
+    with open(str(tmp_path / "train.txt"), "w") as f:
+        for k in range(n):
+            np.save(str(tmp_path / "audios" / ("a%d.npy" % k)), np.zeros(4 * 256, np.float32))
+            np.save(str(tmp_path / "mels" / ("m%d.npy" % k)), np.zeros((4, hp.num_mels), np.float32))
+            f.write("a%d.npy|m%d.npy|%d|0|x\n" % (k, k, 4 * 256))
+    assert 2 * T.Dataset.MAX_OPEN <= 256
+    old = T.Dataset.MAX_OPEN
+    T.Dataset.MAX_OPEN = 4
+    try:
+        ds = T.Dataset(str(tmp_path / "train.txt"), hp, seed=1)
+        nfd = lambda: len(os.listdir("/proc/self/fd"))
+        for _ in range(3):
+            ds.next_train()
+        base = nfd()
+        for _ in range(40):
+            mels, audios = ds.next_train()
+            ds.eval_sample()
+        assert mels.shape == (4, 2, hp.num_mels) and audios.shape == (4, 512)
+        assert nfd() <= base + 2 * 4 + 4, (base, nfd())          # bounded by the LRU, not by the utterances touched
+        assert len(ds._cache) <= 4 + 1
+    finally:
+        T.Dataset.MAX_OPEN = old

@@ -1,5 +1,7 @@
 """Training-side primitives (work in progress towards the backward pass): the generic multi-segment
 GEMM, the shifted transpose and the deterministic split-K reduction against NumPy fp64."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -259,6 +261,40 @@ def test_side_stream_weight_gradients_equal_the_one_stream_call_bit_for_bit(cfg,
         assert torch.equal(res["0"][3][k], res["1"][3][k]), k
 
 
+def test_an_exception_in_the_block_callback_stops_the_call_and_reaches_the_caller():
+    """ctypes prints and drops an exception raised inside a callback.  A failed all-reduce / graph cut in
+    on_block_done must stop the C sequencer (FWN_ERR_CALLBACK) and be re-raised by GradEngine, with one stream and two."""
+    from conftest import small_hparams
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.training import GradEngine
+    hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=8)
+    p = W.synthetic_params(hp, 5, actnorm="random")
+    inp = W.synthetic_inputs(hp, 2, 128)
+    x, c = torch.from_numpy(inp["x"]).reshape(2, 128).cuda(), torch.from_numpy(inp["c"]).cuda()
+    for side in ("0", "1"):
+        os.environ["FWN_TRAIN_SIDE"] = side
+        try:
+            eng = GradEngine(hp)
+            seen = []
+
+            def hook(blk):
+                seen.append(blk)
+                if blk == 1:
+                    raise RuntimeError("all-reduce of block 1 failed")
+
+            with pytest.raises(RuntimeError, match="all-reduce of block 1 failed"):
+                eng.loss_and_grads(p, x, c, on_block_done=hook)
+            torch.cuda.synchronize()
+            assert seen == [2, 1]                      # nothing is reported (or enqueued) after the failure
+            # the raw C-ABI: a non-zero return from the callback -> FWN_ERR_CALLBACK with a message
+            good = eng.loss_and_grads(p, x, c)
+            torch.cuda.synchronize()
+            again = eng.loss_and_grads(p, x, c, on_block_done=lambda blk: None)
+            assert float(good[0]) == float(again[0])   # and the engine is usable afterwards
+        finally:
+            os.environ.pop("FWN_TRAIN_SIDE", None)
+
+
 def test_train_entry_point_rejects_bad_arguments_with_a_message():
     """fwn_train_loss_and_grads / fwn_train_workspace_bytes: argument errors come back as codes with fwn_last_error()
     set (workspace too small: FWN_ERR_WORKSPACE), nothing is launched, and the same descriptors still work afterwards."""
@@ -280,13 +316,18 @@ def test_train_entry_point_rejects_bad_arguments_with_a_message():
     ws = torch.empty(need + 512, dtype=torch.uint8, device="cuda")
     base = ws.data_ptr() + (-ws.data_ptr()) % 256
     out3 = torch.zeros(3, device="cuda")
-    cb = _lib.BLOCK_DONE_FN(lambda user, blk: None)
+    cb = _lib.BLOCK_DONE_FN(lambda user, blk: 0)
     call = lambda B, T, xp, wsp, wsn: lib.fwn_train_loss_and_grads(C.byref(td), B, T, xp, c.data_ptr(), wsp, wsn, out3.data_ptr(), cb, None, None)
     assert call(2, 128, x.data_ptr(), base, need - 1) == -3 and b"workspace" in lib.fwn_last_error()
     assert call(2, 128, None, base, need) == -1 and b"null" in lib.fwn_last_error()
     assert call(2, 128, x.data_ptr(), base + 16, need) == -1 and b"aligned" in lib.fwn_last_error()
     assert call(2, 120, x.data_ptr(), base, need) == -1 and b"multiple" in lib.fwn_last_error()
     assert call(0, 128, x.data_ptr(), base, need) == -1
+    stop = _lib.BLOCK_DONE_FN(lambda user, blk: 7)
+    assert lib.fwn_train_loss_and_grads(C.byref(td), 2, 128, x.data_ptr(), c.data_ptr(), base, need, out3.data_ptr(), stop, None, None) == -4
+    assert b"callback" in lib.fwn_last_error()
+    torch.cuda.synchronize()
+    out3.zero_()
     torch.cuda.synchronize()
     assert float(out3.abs().sum()) == 0.0                       # nothing ran
     assert call(2, 128, x.data_ptr(), base, need) == 0

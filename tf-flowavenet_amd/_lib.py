@@ -49,7 +49,7 @@ class ModelDesc(C.Structure):
 
 
 REDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)      # fwn_reduce_fn(user, buf, n, stream)
-BLOCK_DONE_FN = C.CFUNCTYPE(None, vp, C.c_int)             # fwn_block_done_fn(user, block)
+BLOCK_DONE_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int)         # fwn_block_done_fn(user, block) -> 0 to go on
 
 
 class ConvGrad(C.Structure):

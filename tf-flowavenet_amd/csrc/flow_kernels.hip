@@ -117,9 +117,20 @@ __global__ __launch_bounds__(256) void front_valu_kernel(FrontProb p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = 3 * p.Ch;
     const int m0 = blockIdx.x * ROWS;
-    for (int i = tid; i < K * 256; i += 256) {
-        const int n = i & 255, k = i >> 8;
-        wt[k * 256 + n] = (float)p.W[(size_t)n * p.kpad + k];
+    {
+        // Thread n stages row n of W ([256][kpad] bf16, kpad >= 64 > KMAX): its K values are one to six 16-byte pieces,
+        // all in flight at once.  (Element by element - wt[k][n] = W[n][k] in a loop over k - every iteration was a
+        // dependent 2-byte load: K serial L2 round trips per workgroup, ~10 us per launch whatever the row count.)
+        constexpr int NP = (KMAX + 7) / 8;
+        const uint4* wsrc = (const uint4*)(p.W + (size_t)tid * p.kpad);
+        Pack16 wv[NP];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) wv[c].u = wsrc[c];
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c * 8 + e < KMAX) wt[(c * 8 + e) * 256 + tid] = (float)wv[c].e[e];
     }
     for (int i = tid; i < K * ROWS; i += 256) {
         const int r = i % ROWS, k = i / ROWS;
@@ -372,6 +383,41 @@ struct ResProb {
         return (uint32_t)(n * FWN_HID + cc.k0 + c8 * 8) * 2u;
     }
     __device__ float acc_init(int) const { return 0.0f; }
+    // Row-major epilogue (gemm_ring.h, LDS_EPI): h in, h out (and the e4m3 copy) as 16- / 8-byte pieces of 8 columns.
+    // This layer is HBM-bound (o read, h read, h write); with one column per lane it issued 64 two-byte VMEM
+    // instructions per lane.  Same arithmetic, same order: (h + acc + b) * sqrt(1/2).
+    static constexpr bool LDS_EPI = true;
+    template <int MI>
+    __device__ void epilogue_rows(const float* wt, int mrow0, int ncol0, int lane) const {
+        const int col = ncol0 + (lane & 7) * 8;
+        const float4 b0 = *(const float4*)(bias + col), b1 = *(const float4*)(bias + col + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const uint32_t bytes = (uint32_t)((size_t)M * FWN_HID * 2);
+        const srd_t so = make_srd(hout, bytes), s8 = make_srd(h8out ? (void*)h8out : (void*)hout, h8out ? (uint32_t)((size_t)M * FWN_HID) : 0u);
+        Pack16 hv[4 * MI];
+#pragma unroll
+        for (int it = 0; it < 4 * MI; ++it) {        // plain (clamped) 16-byte loads: see DESIGN.md on raw_buffer_load_b128
+            const int row = mrow0 + it * 8 + (lane >> 3);
+            hv[it].u = *(const uint4*)(hin + (size_t)(row < M ? row : 0) * FWN_HID + col);
+        }
+#pragma unroll
+        for (int it = 0; it < 4 * MI; ++it) {
+            const int row = mrow0 + it * 8 + (lane >> 3);
+            float a[8];
+            lds_epi_take(wt, it, lane, a);
+            Pack16 out;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out.e[e] = (bf16)(((float)hv[it].e[e] + a[e] + bb[e]) * 0.70710678118654752f);
+            const uint32_t voff = row < M ? (uint32_t)(row * FWN_HID + col) * 2u : FWN_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(out.w, so, voff, 0, 0);
+            if (h8out) {
+                typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+                const u32x2 q = {pack_e4m3x2((float)out.e[0], (float)out.e[1]) | (pack_e4m3x2((float)out.e[2], (float)out.e[3]) << 16),
+                                 pack_e4m3x2((float)out.e[4], (float)out.e[5]) | (pack_e4m3x2((float)out.e[6], (float)out.e[7]) << 16)};
+                __builtin_amdgcn_raw_buffer_store_b64(q, s8, voff == FWN_OOB ? FWN_OOB : voff >> 1, 0, 0);
+            }
+        }
+    }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         const int lr = lane & 31;

@@ -70,6 +70,35 @@ __device__ __forceinline__ void wait_vmcnt_le(int pending_chunks) {
     FWN_WAIT_VMCNT(0);
 }
 
+// ---- row-major epilogue helpers (LDS_EPI problems) ----
+// A wave's (32 MI) x 64 fp32 tile in LDS: 256-byte rows, the 16-byte granule g of a row stored at g ^ ((row >> 1) & 1)
+// so that both the 4-byte column writes (32 consecutive floats of one row per half wave) and the 16-byte row reads
+// (ds_read_b128 is served in groups of 16 lanes that span four rows) are bank-conflict-free.
+template <class P, class = void> struct prob_lds_epi { static constexpr bool value = false; };
+template <class P> struct prob_lds_epi<P, decltype((void)P::LDS_EPI)> { static constexpr bool value = P::LDS_EPI; };
+
+template <int MI>
+__device__ __forceinline__ void lds_epi_park(const f32x16 (&acc)[MI][2], float* wt, int lane) {
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mi * 32 + acc_row_c(r) + 4 * lh;            // (row >> 1) & 1 == (r >> 1) & 1
+                wt[row * 64 + ((ni * 32 + lr) ^ (((r >> 1) & 1) << 2))] = acc[mi][ni][r];
+            }
+}
+// Row piece `it` (0 .. 4 MI - 1) of the parked tile: this lane's row (it * 8 + lane / 8) and 8 consecutive columns
+// (lane % 8) * 8 .. + 7, as two float4.  The wave's own writes are complete once lgkmcnt drains (same wave: no barrier).
+__device__ __forceinline__ void lds_epi_take(const float* wt, int it, int lane, float (&v)[8]) {
+    const int row = it * 8 + (lane >> 3), c = lane & 7, f = (lane >> 4) & 1;
+    const float4 a = *(const float4*)(wt + row * 64 + (((2 * c) ^ f) << 2));
+    const float4 b = *(const float4*)(wt + row * 64 + (((2 * c + 1) ^ f) << 2));
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
 // KSP > 1: intra-workgroup split-K for small tiles - KSP wave groups take alternate k-steps of
 // every chunk (more waves per CU to hide LDS latency on an otherwise 2-wave tile) and their
 // partial accumulators are summed through LDS before the epilogue.
@@ -253,6 +282,18 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         return;
     }
     FWN_RING_STAMP_X(2);
-    p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+    if constexpr (prob_lds_epi<Prob>::value && KSP == 1 && NWV * 32 * MI * 64 * 4 <= D * SLOT) {
+        // Row-major epilogue through LDS (problems that declare LDS_EPI): the accumulator layout gives a lane ONE column of
+        // 16 rows, so a direct epilogue moves 2 bytes per lane and instruction (32 loads + 32 stores per lane for a
+        // residual layer).  Each wave parks its (32 MI) x 64 fp32 tile in the drained ring and takes it back as rows of
+        // 8 consecutive columns per lane: 16-byte loads / stores, 8 rows x 128 bytes per wave instruction.
+        // (instantiations whose tiles would not fit the drained ring keep the direct epilogue)
+        __syncthreads();                 // every wave has read its last fragments (no DMA is in flight any more)
+        float* wt = (float*)lds + wave * (32 * MI * 64);
+        lds_epi_park<MI>(acc, wt, lane);
+        p.template epilogue_rows<MI>(wt, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+    } else {
+        p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+    }
     FWN_RING_STAMP_X(3);
 }

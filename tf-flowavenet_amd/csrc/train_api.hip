@@ -429,6 +429,9 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     };
     std::vector<Deferred> pending;        // the flows of the block whose weight gradients are still to be enqueued
     int pending_block = -1;               // block whose weight gradients run on the side stream, not yet joined
+    // a hook that returns non-zero stops the sequencing where it stands (the side stream is joined at that point)
+    bool hook_failed = false;
+    auto hook_stop = [&]() -> int { return fwn_set_error(FWN_ERR_CALLBACK, "fwn_train_loss_and_grads: the on_block_done callback asked to stop"); };
     auto weight_grads = [&](Deferred& D, hipStream_t s_) -> int {
         const long m = D.m, ti = D.ti;
         const int ch = D.ch;
@@ -487,7 +490,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     auto join_pending = [&]() -> bool {      // the block handed over last: join it into `st`, then report it
         if (pending_block < 0) return true;
         if (!join_side()) return false;
-        if (on_block_done) on_block_done(user, pending_block);
+        if (on_block_done && on_block_done(user, pending_block) != 0) hook_failed = true;
         pending_block = -1;
         return true;
     };
@@ -627,9 +630,11 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             fwn_small_grads_main(ga, xa, gb, xb, pl.dzz, d->an, m, ch, w.sg, st);
             if (!side) fwn_small_grads_final(d->an, m, ch, (const long long*)t->br[i], (const long long*)t->zcol[i], w.sg, td->d_an_b, td->d_an_logs,
                                              td->d_zscale, st);
-            if (!side && j == 0 && on_block_done) on_block_done(user, i);
+            if (!side && j == 0 && on_block_done && on_block_done(user, i) != 0) hook_failed = true;
+            if (hook_failed) return hook_stop();
             if (side && j == 0) {      // this block's weight gradients: under the next block's chain
                 if (!join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");
+                if (hook_failed) return hook_stop();
                 const int rc = hand_over();
                 if (rc != FWN_OK) return rc;
                 pending_block = i;
@@ -638,6 +643,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     }
     // the first block's: the conditioning gradient is complete only now
     if (side && !join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");
+    if (hook_failed) return hook_stop();
     // up-sampling transposed convolutions (model.py:301-311), last stage first
     hipLaunchKernelGGL(planes_to_rows_kernel, dim3(grid_of(B * T * nmel)), dim3(256), 0, st, pl.dcplanes, (const bf16*)pl.cplanes, B * T, half, pl.up_dy,
                        pl.up_y);
@@ -664,7 +670,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             y = xin;
         }
     }
-    if (on_block_done) on_block_done(user, -1);
+    if (on_block_done && on_block_done(user, -1) != 0) return hook_stop();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: %s", hipGetErrorString(e));
     return FWN_OK;

@@ -61,7 +61,7 @@ struct LinProb {
         const uint32_t gbytes = g.gate_aux ? (uint32_t)((size_t)g.M * 512 * 2) : 0u;
         const srd_t sGa = make_srd(g.gate_aux ? g.gate_aux : g.W, gbytes), sGo = make_srd(g.gate_aux ? (const void*)g.gate_out : g.W, gbytes);
         const float mdef = g.mask ? 0.0f : 1.0f;                    // no mask: every element passes
-        const float floor_ = g.relu ? 0.0f : -__builtin_inff();
+        const bool relu_on = g.relu != 0;                          // wave-uniform: a scalar select, no branch around loads
         const uint32_t ysz = g.out_f32 ? 4u : 2u;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -89,7 +89,7 @@ struct LinProb {
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[mi][ni][r] + b + g.rscale * rv[r];
                     v = (mv[r] + mdef) > 0.0f ? v : 0.0f;
-                    v = fmaxf(v, floor_);
+                    v = relu_on ? fmaxf(v, 0.0f) : v;       // off: v untouched, so a NaN stays a NaN (fmaxf(NaN, -inf) would be -inf)
                     out[r] = v * g.oscale + yv[r];
                 }
                 if (g.out_f32) {

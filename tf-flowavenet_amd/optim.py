@@ -121,6 +121,35 @@ class DataParallelAdam:
         out.append((cur, lo, self.layout.size))
         return out
 
+    def weights_checksum(self):
+        """64-bit position-weighted hash of the master weights' bit patterns (device tensor, int64).  Two ranks hold the
+        same masters iff (up to hash collisions) the sums agree; wrap-around arithmetic, order-free, chunked so the
+        int64 temporaries stay small."""
+        import torch
+        bits = self.w.view(torch.int32)
+        acc = torch.zeros((), dtype=torch.int64, device=bits.device)
+        chunk = 1 << 24
+        for lo in range(0, bits.numel(), chunk):
+            b = bits[lo:lo + chunk].to(torch.int64)
+            pos = torch.arange(lo, lo + b.numel(), dtype=torch.int64, device=bits.device)
+            acc = acc + (b * (2 * (pos % 1000003) + 1)).sum()
+        return acc
+
+    def weights_identical(self):
+        """True iff every rank of the group holds bit-identical master weights (all-reduce MIN / MAX of the checksum):
+        the lock-step invariant of the data-parallel step (utils.py:34-60: one averaged gradient, one update)."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return True
+        h = self.weights_checksum().reshape(1)
+        lo, hi = h.clone(), h.clone()
+        if lo.is_cuda and dist.get_backend(self.group) == "gloo":      # shared-GPU plumbing tests reduce on the host
+            lo, hi = lo.cpu(), hi.cpu()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        return int(lo.item()) == int(hi.item())
+
     def allreduce_range(self, lo, hi):
         """Start the all-reduce (sum) of ``g[lo:hi]`` now - called by the training step as soon as a
         block's gradients are complete, so the exchange overlaps the rest of the backward pass."""

@@ -30,7 +30,10 @@ import numpy as np
 
 class Dataset:
     """Random fixed-length crops of (mel, audio) pairs (dataset.py:47-85)."""
-    MAX_OPEN = 512          # memory-mapped utterances kept open per rank (_load)
+    # memory-mapped utterances kept open per rank (_load).  Every numpy memmap pins a dup'd file descriptor, two per
+    # utterance: 64 pairs = 128 descriptors, far below the usual soft RLIMIT_NOFILE of 1024 that the GPU runtime, RCCL
+    # and the log files also draw on.
+    MAX_OPEN = 64
 
     def __init__(self, metadata_path, hparams, seed=None, rank=0):
         self._hp = hparams
@@ -95,7 +98,14 @@ class Dataset:
         self._lru[m[0]] = None
         while len(self._lru) > self.MAX_OPEN:
             old, _ = self._lru.popitem(last=False)
-            del self._cache[old]
+            gone = self._cache.pop(old)
+            for arr in gone:            # release the descriptor now, not when the garbage collector gets to it
+                mm = getattr(arr, "_mmap", None)
+                if mm is not None:
+                    try:
+                        mm.close()
+                    except (BufferError, ValueError):
+                        pass            # a caller still holds a view: the map goes with its last reference
         return pair
 
     def _batch(self, metas):
@@ -107,6 +117,7 @@ class Dataset:
             start = self._rng.randint(0, mel.shape[0] - self._frames)        # dataset.py:73-76
             mels[k] = mel[start:start + self._frames]
             audios[k] = audio[start * hp.hop_size:start * hp.hop_size + self._steps]
+            del audio, mel              # the batch holds copies: no view outlives this iteration (see _load's close)
         return mels, audios
 
     def next_train(self):
@@ -125,7 +136,7 @@ class Dataset:
         frames = min(int(hp.eval_max_time_steps // hp.hop_size), mel.shape[0])
         while frames > 1 and (frames * hp.hop_size) % (1 << hp.n_block):      # model.py:226: T % 2^n_block == 0
             frames -= 1
-        return mel[:frames], audio[:frames * hp.hop_size]
+        return np.array(mel[:frames]), np.array(audio[:frames * hp.hop_size])   # copies, not views of the map
 
 
 def save_checkpoint(path, trainer):
@@ -153,19 +164,67 @@ def checkpoint_files(save_dir):
     return [p for _, p in sorted(found)]
 
 
+def _checkpoint_step(path):
+    import re
+    return int(re.search(r"ckpt-(\d+)\.npz$", path).group(1))
+
+
 def restore_checkpoint(save_dir, trainer):
-    """Highest-step readable ``flowavenet_model.ckpt-<step>.npz`` -> masters, Adam slots, global step (a file that
-    cannot be read - truncated by a crash - is skipped with a message).  Returns the step or None."""
+    """Highest-step readable ``flowavenet_model.ckpt-<step>.npz`` -> masters, Adam slots, global step.  Returns the
+    step or None.
+
+    Only a file that cannot be READ (truncated by a crash: zip / EOF / OS errors) is skipped, with a message.  A file
+    that reads but does not fit this model - a missing parameter, another shape: different hparams - raises: silently
+    starting from step 0 would go on to overwrite the run's checkpoints.  In a data-parallel job rank 0 picks the file
+    and every rank must load that very step; disagreement (a file one rank cannot read) aborts the job."""
+    import zipfile
     import torch
-    for path in reversed(checkpoint_files(save_dir)):
+    import torch.distributed as dist
+    group = getattr(trainer.opt, "group", None)
+    multi = dist.is_available() and dist.is_initialized() and group is not False and dist.get_world_size(group) > 1
+    files = list(reversed(checkpoint_files(save_dir)))
+    want = None
+    if multi:      # the step rank 0 is about to try first; ranks that see other files fail below instead of diverging
+        box = [(_checkpoint_step(files[0]) if files else -1) if dist.get_rank(group) == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        want = box[0]
+    got = None
+    for path in files:
+        if want is not None and got is None and _checkpoint_step(path) > want >= 0:
+            continue                    # newer than what rank 0 sees (it is still being written there)
         try:
             with np.load(path) as f:
-                views = trainer.opt.master_views()
-                loaded = {k: torch.from_numpy(f[k]).reshape(v.shape) for k, v in views.items()}
-                m, v_, gs = torch.from_numpy(f["__opt/m"]), torch.from_numpy(f["__opt/v"]), int(f["__opt/global_step"])
-        except Exception as e:        # zipfile.BadZipFile, KeyError, OSError, ValueError ...
+                names = set(f.files)
+                arrays = {k: f[k] for k in names}
+        except (zipfile.BadZipFile, EOFError, OSError, ValueError) as e:      # I/O and container-format errors only
             print("Skipping unreadable checkpoint {} ({}: {})".format(path, type(e).__name__, e))
-            continue
+            continue                    # (data parallel: if only this rank cannot read it, the agreement check below aborts)
+        views = trainer.opt.master_views()
+        missing = [k for k in list(views) + ["__opt/m", "__opt/v", "__opt/global_step"] if k not in names]
+        if missing:
+            raise KeyError("checkpoint {} does not belong to this model: {} entries missing, e.g. {!r} (other hparams?)"
+                           .format(path, len(missing), missing[0]))
+        for k, v in views.items():
+            if int(np.prod(arrays[k].shape)) != v.numel():
+                raise ValueError("checkpoint {}: {!r} has shape {}, the model expects {} (other hparams?)"
+                                 .format(path, k, tuple(arrays[k].shape), tuple(v.shape)))
+        loaded = {k: torch.from_numpy(arrays[k]).reshape(v.shape) for k, v in views.items()}
+        m, v_, gs = torch.from_numpy(arrays["__opt/m"]), torch.from_numpy(arrays["__opt/v"]), int(arrays["__opt/global_step"])
+        if m.numel() != trainer.opt.m.numel() or v_.numel() != trainer.opt.v.numel():
+            raise ValueError("checkpoint {}: Adam slots of {} elements, the model has {}".format(path, m.numel(), trainer.opt.m.numel()))
+        got = (path, loaded, m, v_, gs)
+        break
+    if multi:
+        mine = torch.tensor([got[4] if got else -1], dtype=torch.int64, device=trainer.opt.m.device)
+        lo, hi = mine.clone(), mine.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if int(lo) != int(hi):
+            raise RuntimeError("ranks disagree on the checkpoint to restore (steps {} .. {}; this rank: {}): every rank "
+                               "must read the same file of {}".format(int(lo), int(hi), int(mine), save_dir))
+    if got is not None:
+        path, loaded, m, v_, gs = got
+        views = trainer.opt.master_views()
         print("Loading checkpoint {}".format(path))
         for k, v in views.items():
             v.copy_(loaded[k])

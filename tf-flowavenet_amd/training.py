@@ -670,10 +670,25 @@ class GradEngine:
         ws = self._ws
         off = (-ws.data_ptr()) % 256
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
-        hook = self._on_block
-        cb = _lib.BLOCK_DONE_FN((lambda user, blk: hook(blk)) if hook is not None else (lambda user, blk: None))
+        hook, failure = self._on_block, []
+
+        def block_done(user, blk):
+            # ctypes prints and DROPS an exception raised inside a callback: a failed all-reduce or graph cut would go
+            # unnoticed and the optimiser would step on un-reduced gradients.  Catch it, make the C sequencer stop
+            # (non-zero return) and re-raise once the call is back.
+            try:
+                if hook is not None:
+                    hook(blk)
+                return 0
+            except BaseException as e:
+                failure.append(e)
+                return 1
+
+        cb = _lib.BLOCK_DONE_FN(block_done)
         rc = lib.fwn_train_loss_and_grads(C.byref(td), B, T, x.data_ptr(), c.data_ptr(), ws.data_ptr() + off, ws.numel() - off,
                                           out3.data_ptr(), cb, None, st)
+        if failure:
+            raise failure[0]
         _lib.check(rc, "fwn_train_loss_and_grads")
         td.zero_dead_res = 0
         self._alive = (masters, an_ld, x, c)           # until the stream has consumed them
@@ -716,6 +731,12 @@ class Trainer:
         m.forward(xx.reshape(xx.shape[0], -1, 1), torch.as_tensor(c).to(self.device))
         for k, v in m.export_actnorm().items():
             views[k].copy_(torch.as_tensor(v).to(self.device).reshape(views[k].shape))
+        # Only the ActNorm tables were made identical above (moment all-reduce).  Any other per-rank difference in the
+        # initial masters - caller-supplied params, another seed, a restore that went differently - would survive every
+        # all-reduced step: check once, here, that the ranks start in lock-step.
+        if not self.opt.weights_identical():
+            raise RuntimeError("Trainer.ddi: the ranks hold different master weights after the data-dependent init "
+                               "(different initial parameters or checkpoints per rank?)")
 
     def step(self, x, c):
         """-> (loss, log_p, logdet, grad_norm) device scalars; the masters are updated in place."""

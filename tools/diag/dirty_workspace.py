@@ -13,7 +13,7 @@ l0 = float(eng.loss_and_grads(p, x, c)[0])
 lib, td = eng.lib, eng._desc
 need = int(lib.fwn_train_workspace_bytes(C.byref(td), 2, 128))
 out3 = torch.zeros(3, device="cuda")
-cb = _lib.BLOCK_DONE_FN(lambda user, blk: None)
+cb = _lib.BLOCK_DONE_FN(lambda user, blk: 0)
 for fill in (0, 255, 0x7f, 0x3c):
     ws = torch.full((need + 512,), fill, dtype=torch.uint8, device="cuda")
     base = ws.data_ptr() + (-ws.data_ptr()) % 256
