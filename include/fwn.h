@@ -126,6 +126,11 @@ typedef struct fwn_flow_desc {
      * e4m3 bytes [512][768], stored as W * 2^wd8_exp[l] (one power-of-two scale per matrix, fwn_pack_e4m3). */
     const void* Wd8[FWN_MAX_LAYERS];
     int32_t wd8_exp[FWN_MAX_LAYERS];
+    /* Chained front conv (Ch <= 8, else NULL / 0): the front weights once more as [256][kf3], K = (tap*Ch + tau)*2 + (hi|lo),
+     * kf3 = 6*Ch rounded up to 16.  With it the whole-model calls let the tail of the PREVIOUS flow of the block compute
+     * this flow's h0 (csrc/tail_chain.h); the stage entry points ignore it. */
+    const void* Wfront3;
+    int32_t kf3, reserved;
 } fwn_flow_desc;
 
 /* ---- stage entry points (K4..K8), exposed so each kernel can be parity-tested alone ---- */
@@ -352,6 +357,9 @@ typedef struct fwn_model_desc {
     const fwn_flow_desc* flows;               /* HOST array [n_block*n_flow] */
     int32_t cond_mode;                        /* 0 auto, 1 always fused in gate, 2 always hoisted */
     int32_t gate_fp8;                         /* != 0: fp8 dilated taps where supported (needs flows[].Wd8) */
+    int32_t chain_mode;                       /* 0: chain the flows of a block (out_b to a third plane buffer, the next flow's
+                                               * front conv in the previous flow's tail: csrc/tail_chain.h); 1: every flow on its own */
+    int32_t reserved;
 } fwn_model_desc;
 
 size_t fwn_workspace_bytes(const fwn_model_desc* m, int64_t B, int64_t T);

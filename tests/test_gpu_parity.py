@@ -79,9 +79,14 @@ def test_forward_and_inverse_match_golden(name, cond_mode):
         last = "Block_%d/Flow_%d/ActNorm/" % (hp.n_block - 1, hp.n_flow - 1)
         np.testing.assert_allclose(an[last + "b"], g["an_b_last"], atol=2e-2)
         np.testing.assert_allclose(an[last + "logs"], g["an_logs_last"], atol=5e-3)
-        # a second forward (init consumed) reproduces the first bit for bit
+        # a second forward (init consumed) reproduces the first - to rounding: the init pass runs every flow on its own
+        # (a flow's ActNorm table does not exist while the previous flow's tail runs), later passes chain the flows of a
+        # block and compute the front conv on the MFMA (hi | lo bf16 halves of the fp32 state) - and the third the second
+        # bit for bit
         lp2, ld2 = model.forward(dev(inp["x"]), dev(inp["c"]))
-        assert float(lp2) == float(log_p) and float(ld2) == float(logdet)
+        assert abs(float(lp2) - float(log_p)) <= 2e-5 * abs(float(log_p)) and abs(float(ld2) - float(logdet)) <= 2e-5 * max(1.0, abs(float(logdet)))
+        lp3, ld3 = model.forward(dev(inp["x"]), dev(inp["c"]))
+        assert float(lp3) == float(lp2) and float(ld3) == float(ld2)
     if "x_rev" in g:
         wav = model.reverse(dev(inp["z"]), dev(inp["c"])).cpu().numpy()
         assert wav.shape == (b, t, 1)

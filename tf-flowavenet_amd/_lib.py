@@ -31,6 +31,7 @@ class FlowDesc(C.Structure):
         ("Wzero", vp), ("bzero", vp), ("ezero", vp),
         ("an", vp),
         ("Wd8", vp * FWN_MAX_LAYERS), ("wd8_exp", i32 * FWN_MAX_LAYERS),
+        ("Wfront3", vp), ("kf3", i32), ("reserved", i32),
     ]
 
 
@@ -45,6 +46,8 @@ class ModelDesc(C.Structure):
         ("flows", C.POINTER(FlowDesc)),
         ("cond_mode", i32),
         ("gate_fp8", i32),
+        ("chain_mode", i32),
+        ("reserved", i32),
     ]
 
 

@@ -274,16 +274,25 @@ int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float*
     REQUIRE(!scratch || ALIGNED16(scratch), "fwn_tail: scratch must be 16-byte aligned");
     fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
                     d->ezero, d->an, xa, xb, partial, M, d->Ch, d->npt, inverse, scratch,
-                    scratch ? (char*)scratch + (size_t)M * 512 : nullptr, (hipStream_t)stream);
+                    scratch ? (char*)scratch + (size_t)M * 512 : nullptr, nullptr, (hipStream_t)stream);
     return check_launch("fwn_tail");
 }
 
 int fwn_tail_partials(int M) { return M > 0 ? fwn_tail_npartials(M) : 0; }
 
 // ddi: 0 none, 1 local two-pass init, 2 moments -> reduce callback (may be NULL) -> tables
+// Chain context of one flow inside a whole-model call (NULL: a flow on its own, everything in place).
+struct FlowChain {
+    float* xb_out;               // third plane buffer that receives out_b, or NULL (in place)
+    const fwn_flow_desc* next;   // the flow whose front conv this flow's tail also computes (same block), or NULL
+    int have_h0;                 // the previous flow's tail has already written this flow's h0 into `h0`
+    void* h0_next;               // out: the buffer the next flow's h0 was written to (one of h0 / h1), NULL if none
+    int n_partial;               // out: log-det partial slots this flow's tail wrote
+};
+
 static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
                          void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
-                         double* mom, fwn_reduce_fn reduce, void* user, void* h8a, void* h8b, void* stream) {
+                         double* mom, fwn_reduce_fn reduce, void* user, void* h8a, void* h8b, FlowChain* chain, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(B > 0 && T > 0 && T % (2 * (int64_t)d->Ch) == 0, "fwn_flow_run: T=%lld not divisible by 2*Ch=%d",
@@ -313,8 +322,9 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
     };
     void* h8c = h8a;
     void* h8n = h8b;
-    fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h0, h1, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1,
-                     fp8_layer(0) ? h8c : nullptr, st);
+    if (!(chain && chain->have_h0))
+        fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h0, h1, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1,
+                         fp8_layer(0) ? h8c : nullptr, st);
     void* hc = h0;
     void* hn = h1;
     for (int l = 0; l < d->L; ++l) {
@@ -332,8 +342,21 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
         }
     }
     // both h buffers are free once the last gate has run: the N-split tail (small M) keeps S and U there
+    fwn_tail_chain tc;
+    memset(&tc, 0, sizeof(tc));
+    if (chain) {
+        tc.xb_out = chain->xb_out;
+        chain->h0_next = nullptr;
+        if (chain->next && chain->xb_out) {      // the next flow's front conv rides this tail: its h0 goes to the buffer S does not use
+            const fwn_flow_desc* nx = chain->next;
+            tc.h0_next = hc;
+            tc.Wfn = nx->Wfront3; tc.bfn = nx->bfront; tc.an_next = inverse ? nullptr : nx->an; tc.kfn = nx->kf3; tc.Ti = Ti;
+            chain->h0_next = hc;
+        }
+        chain->n_partial = fwn_tail_npartials_chain(M, d->Ch, tc.h0_next != nullptr);
+    }
     fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
-                    d->ezero, d->an, xa, xb, inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, hn, hc, st);
+                    d->ezero, d->an, xa, xb, inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, hn, hc, chain ? &tc : nullptr, st);
     return check_launch("fwn_flow_run");
 }
 
@@ -341,14 +364,14 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
                  void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
                  void* stream) {
     return flow_run_impl(d, B, T, xa, xb, ca, h0, h1, o, P, partial, inverse, ddi ? 1 : 0, nullptr, nullptr, nullptr, nullptr,
-                         nullptr, stream);
+                         nullptr, nullptr, stream);
 }
 int fwn_flow_run_fp8(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
                      void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
                      void* h8a, void* h8b, void* stream) {
     REQUIRE(h8a && h8b && ALIGNED16(h8a) && ALIGNED16(h8b), "fwn_flow_run_fp8: h8 scratch buffers (16-byte aligned) required");
     return flow_run_impl(d, B, T, xa, xb, ca, h0, h1, o, P, partial, inverse, ddi ? 1 : 0, nullptr, nullptr, nullptr, h8a, h8b,
-                         stream);
+                         nullptr, stream);
 }
 
 int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_partial, float* out2,
@@ -566,7 +589,7 @@ int fwn_clip_adam_dev(float* w, const float* g, float* m, float* v, int64_t n, c
 // Whole-model sequencing
 // ---------------------------------------------------------------------------------------------
 struct Carve {
-    size_t cplanes, up0, up1, planes, h0, h1, o, P, Ppart, partial, mom, h8a, h8b, total;
+    size_t cplanes, up0, up1, planes, plane3, h0, h1, o, P, Ppart, partial, mom, h8a, h8b, total;
     int n_partial;
 };
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -613,6 +636,40 @@ static int check_model(const fwn_model_desc* m, int64_t B, int64_t T) {
     return FWN_OK;
 }
 
+static int tail_partials_max(int M, int Ch) {       // a flow's tail runs plain or chained (overlapping tiles): room for either
+    const int a = fwn_tail_npartials(M), b = fwn_tail_npartials_chain(M, Ch, 1);
+    return a > b ? a : b;
+}
+
+// ---- plane bookkeeping of the chained flows ----
+// The flow state lives in two fp32 planes (even / odd samples).  A chained tail writes out_b to a third buffer (its
+// neighbours still read the old rows), so the three buffers rotate: `at[k]` = where logical plane k lives now.
+struct Planes {
+    float* at[2];
+    float* spare;
+    float* home[2];
+};
+static void planes_after_flow(Planes& pl, int p, bool rotated) {     // the flow read b = at[p ^ 1] and wrote out_b to spare
+    if (!rotated) return;
+    float* nb = pl.spare;
+    pl.spare = pl.at[p ^ 1];
+    pl.at[p ^ 1] = nb;
+}
+static int planes_go_home(Planes& pl, size_t plane_bytes, hipStream_t st) {   // back to the canonical buffers (no-op when the rotations cancel)
+    auto cp = [&](float* dst, float* src) { return hipMemcpyAsync(dst, src, plane_bytes, hipMemcpyDeviceToDevice, st) == hipSuccess; };
+    for (int k = 0; k < 2; ++k) {
+        if (pl.at[k] == pl.home[k]) continue;
+        if (pl.at[k ^ 1] == pl.home[k]) {            // the other plane sits in this one's home: move it to the spare buffer first
+            if (!cp(pl.spare, pl.at[k ^ 1])) return -1;
+            float* t = pl.spare; pl.spare = pl.at[k ^ 1]; pl.at[k ^ 1] = t;
+        }
+        if (!cp(pl.home[k], pl.at[k])) return -1;
+        if (pl.spare == pl.home[k]) pl.spare = pl.at[k];
+        pl.at[k] = pl.home[k];
+    }
+    return 0;
+}
+
 static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
     Carve c;
     size_t off = 0;
@@ -622,6 +679,7 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
     c.up0 = off; off = align_up(off + up_elems * 4);
     c.up1 = off; off = align_up(off + (m->n_up > 2 ? up_elems * 4 : 0));
     c.planes = off; off = align_up(off + (size_t)B * T * 4);
+    c.plane3 = off; off = align_up(off + (size_t)B * T * 2);      // third plane buffer: chained flows write out_b beside their inputs
     const size_t Mmax = (size_t)B * T / 2;
     c.h0 = off; off = align_up(off + Mmax * 256 * 2);
     c.h1 = off; off = align_up(off + Mmax * 256 * 2);
@@ -636,7 +694,7 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
             const size_t sp = (size_t)(fwn_cond_nsplit((int)M, ((m->n_flow + 1) / 2) * m->n_layer, m->flows[i * m->n_flow].kcpad) - 1) * need;
             if (sp > ppart) ppart = sp;
         }
-        npart += m->n_flow * fwn_tail_partials((int)M);
+        npart += m->n_flow * tail_partials_max((int)M, m->flows[i * m->n_flow].Ch);
     }
     c.P = off; off = align_up(off + pbytes);
     c.Ppart = off; off = align_up(off + ppart);        // split-K partials of the hoisted conditioning (few rows)
@@ -702,6 +760,21 @@ static int check_block_contiguity(const fwn_model_desc* m, int blk) {
     return FWN_OK;
 }
 
+// What flow `d` chains with inside a whole-model call: out_b to the spare plane wherever the tail at this shape can write
+// it elsewhere, and the front conv of `next` (the flow that runs after d in this block and direction) in d's tail where
+// that kernel exists (Ch <= 8) - not during the data-dependent init (next's ActNorm table does not exist yet) and not on
+// the fp8 path (its first gate reads an e4m3 copy of h0 that only the stand-alone front conv writes).
+static FlowChain flow_chain(const fwn_model_desc* m, const fwn_flow_desc* d, const fwn_flow_desc* next, int M, bool init, float* spare,
+                            int have_h0) {
+    FlowChain ch;
+    memset(&ch, 0, sizeof(ch));
+    const bool on = m->chain_mode != 1;
+    ch.xb_out = (on && fwn_tail_chain_xb_out(M, d->npt)) ? spare : nullptr;
+    ch.next = (ch.xb_out && next && !init && !m->gate_fp8 && next->Wfront3 && next->kf3 > 0 && fwn_tail_chain_front(M, d->Ch, d->npt)) ? next : nullptr;
+    ch.have_h0 = have_h0;
+    return ch;
+}
+
 static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
                               void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
                               fwn_reduce_fn reduce, void* user, void* stream) {
@@ -724,6 +797,7 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
     int p = 0;
     float* partial = (float*)(ws + c.partial);
     int poff = 0;
+    Planes pl{{planes, planes + plane_elems}, (float*)(ws + c.plane3), {planes, planes + plane_elems}};
     for (int i = 0; i < m->n_block; ++i) {
         const int64_t M = B * T / ((int64_t)2 << i);
         const bool hoist = hoist_cond(m, M, m->flows[i * m->n_flow].cin);
@@ -733,19 +807,26 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
             const int par[2] = {p, p ^ 1};
             run_cond_groups(m, i, M, par, ws, c, B, T, st);
         }
+        void* hA = ws + c.h0;
+        void* hB = ws + c.h1;
+        int have_h0 = 0;
         for (int j = 0; j < m->n_flow; ++j) {
             const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
             const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
             double* mom = (double*)(ws + c.mom) + (size_t)(i * m->n_flow + j) * (4 * ((size_t)1 << (m->n_block - 1)) + 1);
-            rc = flow_run_impl(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
-                               ws + c.h0, ws + c.h1, ws + c.o, P, partial + poff, 0, init, mom, reduce, user,
-                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, stream);
+            FlowChain ch = flow_chain(m, d, j + 1 < m->n_flow ? d + 1 : nullptr, (int)M, init != 0, pl.spare, have_h0);
+            rc = flow_run_impl(d, B, T, pl.at[p], pl.at[p ^ 1], ca, hA, hB, ws + c.o, P, partial + poff, 0, init, mom, reduce, user,
+                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, &ch, stream);
             if (rc) return rc;
-            poff += fwn_tail_partials((int)M);
+            poff += ch.n_partial;
+            planes_after_flow(pl, p, ch.xb_out != nullptr);
+            have_h0 = ch.h0_next != nullptr;
+            if (have_h0 && ch.h0_next != hA) { void* t = hA; hA = hB; hB = t; }
             p ^= 1;   // change_order (model.py:190)
         }
     }
+    if (planes_go_home(pl, plane_elems * 4, st)) return fail(FWN_ERR_HIP, "fwn_model_forward: plane copy failed");
     fwn_launch_prior(planes, (long)(B * T), partial, poff, 1.0 / (double)(B * T), out2, st);
     if (z_planes) {
         hipError_t e = hipMemcpyAsync(z_planes, planes, (size_t)B * T * 4, hipMemcpyDeviceToDevice, st);
@@ -787,6 +868,7 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
     run_upsample(m, B, T, mel, ws, c, st);
     fwn_launch_split(z, B, T, planes, st);   // the n_block pre-squeezes of model.py:374-392 are index math
     int p = 0;
+    Planes pl{{planes, planes + plane_elems}, (float*)(ws + c.plane3), {planes, planes + plane_elems}};
     for (int i = m->n_block - 1; i >= 0; --i) {
         const int64_t M = B * T / ((int64_t)2 << i);
         const bool hoist = hoist_cond(m, M, m->flows[i * m->n_flow].cin);
@@ -802,17 +884,24 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
             }
             run_cond_groups(m, i, M, par, ws, c, B, T, st);
         }
+        void* hA = ws + c.h0;
+        void* hB = ws + c.h1;
+        int have_h0 = 0;
         for (int j = m->n_flow - 1; j >= 0; --j) {
             p ^= 1;   // change_order first (model.py:199)
             const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
             const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
-            rc = flow_run_impl(d, B, T, planes + (size_t)p * plane_elems, planes + (size_t)(p ^ 1) * plane_elems, ca,
-                               ws + c.h0, ws + c.h1, ws + c.o, P, nullptr, 1, 0, nullptr, nullptr, nullptr,
-                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, stream);
+            FlowChain ch = flow_chain(m, d, j > 0 ? d - 1 : nullptr, (int)M, false, pl.spare, have_h0);
+            rc = flow_run_impl(d, B, T, pl.at[p], pl.at[p ^ 1], ca, hA, hB, ws + c.o, P, nullptr, 1, 0, nullptr, nullptr, nullptr,
+                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, &ch, stream);
             if (rc) return rc;
+            planes_after_flow(pl, p, ch.xb_out != nullptr);
+            have_h0 = ch.h0_next != nullptr;
+            if (have_h0 && ch.h0_next != hA) { void* t = hA; hA = hB; hB = t; }
         }
     }
+    if (planes_go_home(pl, plane_elems * 4, st)) return fail(FWN_ERR_HIP, "fwn_model_reverse: plane copy failed");
     fwn_launch_merge(planes, B, T, x_out, st);
     return check_launch("fwn_model_reverse");
 }

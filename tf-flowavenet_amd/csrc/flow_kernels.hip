@@ -681,365 +681,7 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
     }
 };
 
-// ---------------------------------------------------------------------------
-// Tail: skip-sum GEMM -> ReLU -> final 1x1 -> ReLU -> ZeroConv1d -> coupling + ActNorm.
-// modules.py:175-180,51-56; model.py:86-102,124-141,146-161.
-//
-// Weight-streaming, register-chained: each wave owns 32 time rows and ALL 256 hidden
-// channels.  The three GEMMs are computed transposed (channels on the accumulator
-// registers, time on the lanes), so the fp32 accumulator tile of one GEMM, after bias +
-// ReLU + bf16 packing, IS the B operand of the next MFMA chain: no LDS round trip.
-// Weights stream through a 2 x 32 KB LDS ring by LDS-DMA, shared by the NW waves of the
-// workgroup; the o_l rows are read once, straight into registers (no reuse across waves).
-// Wfinal / Wzero are packed with their K axis in accumulator-register order
-// (packing.acc_k_perm) so operand element j of lane half h meets the matching k.
-// ---------------------------------------------------------------------------
-#ifndef FWN_DEBUG_SCALAR_APLANE
-#define FWN_DEBUG_SCALAR_APLANE 0
-#endif
-struct TailArgs {
-    const bf16* o;        // [L][M][256]
-    const bf16* Ws;       // [256][L*256]
-    const float* bs;      // [256]  (sum of the L skip biases)
-    const bf16* Wf;       // [256][256]   K in acc order
-    const float* bfin;    // [256]
-    const bf16* Wz;       // [npt*64][256] K in acc order; pair tiles: 32 log_s rows then 32 t rows
-    const float* bz;      // [npt*64]
-    const float* ez;      // [npt*64]  exp(3*scale)
-    const float* an;      // [2][4][Ch]: (a|b) x (shift, scale, iscale, logs3)
-    float* xa;            // plane holding in_a / out_a  [M][Ch]
-    float* xb;            // plane holding in_b / out_b  [M][Ch]
-    float* partial;       // [gridDim.x] log-det partial sums (forward) or nullptr
-    long o_stride;        // elements between layers of o
-    int L, M, Ch, npt, inverse;
-};
-
-// NW waves x 32 rows per workgroup, D ring slots (D-1 chunks in flight), WDB = double-buffered
-// weight fragments (worth it at one wave per SIMD; at two per SIMD the partner wave covers the
-// LDS latency and the registers are needed to stay under 256).
-template <int NW, int D, bool WDB>
-__global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
-    constexpr int W_BYTES = 256 * 128;               // weight chunk: [256 rows][64 k] bf16
-    constexpr int O_BYTES = 32 * NW * 128;           // o tile of a phase-1 chunk: [32*NW rows][64 k]
-    constexpr int SLOT = W_BYTES + O_BYTES;
-    constexpr int PWW = 32 / NW, PWO = 4;            // DMA pieces per wave per chunk: weights, o rows
-    constexpr int CST = 2560 + 1024;                 // floats: bs | bfin | bz | ez | an[2][4][Ch<=128]
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT + CST * 4 + 64];
-    float* cst = (float*)(lds + D * SLOT);           // bs[256] bfin[256] bz[512] ez[512] an[1024]
-    float* red = cst + CST;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * (32 * NW);
-    const int row = m0 + wave * 32 + lr;             // this lane's time row
-    const int KS = a.L * FWN_HID;
-    const int nq1 = a.L * 4, NC = nq1 + 8;
-    const int Ch = a.Ch;
-
-    // constants -> LDS, also by LDS-DMA (8 pieces of 1 KB spread over the waves, ahead of chunk 0 in
-    // the same queue: the first step() wait covers them).  Ordinary loads here would have to retire
-    // before the first DMA is issued - a cold-miss stall at the head of every tail launch.
-    for (int pc = wave; pc < 8; pc += NW) {
-        const float* src = pc == 0 ? a.bs : pc == 1 ? a.bfin : pc == 2 ? a.bz : pc == 3 ? a.ez : a.an;
-        const uint32_t bytes = pc < 2 ? 1024u : pc < 4 ? (uint32_t)a.npt * 256u : (uint32_t)Ch * 32u;
-        const int dst = pc == 0 ? 0 : pc == 1 ? 256 : pc == 2 ? 512 : pc == 3 ? 1024 : 1536 + (pc - 4) * 256;
-        buf_load16_lds(make_srd(src, bytes), (uint32_t)((pc >= 4 ? (pc - 4) * 1024 : 0) + lane * 16),
-                       (unsigned char*)(cst + dst));
-    }
-
-    // ---- ring: chunk c (weights, and in phase 1 the o rows) goes to slot c % 3 ----
-    int wrow[PWW], wc8[PWW], orow[PWO], oc8[PWO];
-#pragma unroll
-    for (int j = 0; j < PWW; ++j) {
-        wrow[j] = 8 * (wave + NW * j) + (lane >> 3);
-        wc8[j] = (lane & 7) ^ ((wrow[j] >> 1) & 7);
-    }
-#pragma unroll
-    for (int j = 0; j < PWO; ++j) {
-        orow[j] = 8 * (wave + NW * j) + (lane >> 3);
-        oc8[j] = (lane & 7) ^ ((orow[j] >> 1) & 7);
-    }
-    const srd_t srd_s = make_srd(a.Ws, (uint32_t)(256u * KS * 2u));
-    const srd_t srd_f = make_srd(a.Wf, 256u * 256u * 2u);
-    const srd_t srd_z = make_srd(a.Wz, (uint32_t)(a.npt * 64u * 256u * 2u));
-    const srd_t srd_o = make_srd(a.o, (uint32_t)((size_t)a.L * a.o_stride * 2));
-    // Each chunk's DMA pieces are issued in 4 parts (one per k-step of the chunk being multiplied)
-    // so the issue cost hides under MFMAs; part < 0 issues the whole chunk (prologue).
-    auto issue_w = [&](const srd_t s, int ld, int col, int c, int part) {
-        unsigned char* dst = lds + (c % D) * SLOT;
-        constexpr int PP = PWW / 4;
-#pragma unroll
-        for (int j = 0; j < PWW; ++j)
-            if (part < 0 || j / PP == part)
-                buf_load16_lds(s, (uint32_t)(wrow[j] * ld + col + wc8[j] * 8) * 2u, dst + (wave + NW * j) * 1024);
-    };
-    auto issue1 = [&](int q, int part) {              // phase 1: Ws chunk q + o rows of (layer q/4, k (q%4)*64)
-        issue_w(srd_s, KS, q * FWN_BK, q, part);
-        unsigned char* dst = lds + (q % D) * SLOT + W_BYTES;
-        const uint32_t base = (uint32_t)((q >> 2) * a.o_stride + (q & 3) * FWN_BK);
-#pragma unroll
-        for (int j = 0; j < PWO; ++j)
-            if (part < 0 || j == part) {
-                const int r = m0 + orow[j];
-                const uint32_t off = (base + (uint32_t)(r * FWN_HID + oc8[j] * 8)) * 2u;
-                buf_load16_lds(srd_o, r < a.M ? off : FWN_OOB, dst + (wave + NW * j) * 1024);
-            }
-    };
-    auto issue2 = [&](int kc, int part) { issue_w(srd_f, FWN_HID, kc * FWN_BK, nq1 + kc, part); };
-    auto issue3 = [&](int kc, int part) { issue_w(srd_z, FWN_HID, kc * FWN_BK, nq1 + 4 + kc, part); };
-    // refill part `part` of chunk c2 (the slot freed by the barrier of chunk c2 - 2)
-    auto refill = [&](int c2, int part) {
-        if (FWN_ABL >= 2) return;
-        if (c2 < nq1) issue1(c2, part);
-        else if (c2 < nq1 + 4) issue2(c2 - nq1, part);
-        else if (c2 < NC) issue3(c2 - nq1 - 4, part);
-    };
-    // wait for chunk c (chunks c+1 .. c+D-2 may stay in flight) and cross the barrier
-    auto step = [&](int c) {
-        if (FWN_ABL >= 2) { if (c == 0) FWN_WAIT_VMCNT(0); __builtin_amdgcn_s_barrier(); return; }
-        if (D == 2 || c + 1 >= NC) FWN_WAIT_VMCNT(0);
-        else if (c + 1 < nq1) FWN_WAIT_VMCNT(PWW + PWO);
-        else FWN_WAIT_VMCNT(PWW);
-        __builtin_amdgcn_s_barrier();
-    };
-    static_assert(D == 2 || D == 3, "ring depth");
-    constexpr int LA = D - 1;                         // refill distance
-
-    // Fragment of 32-row tile `t`, k-step kk of a 64-wide chunk: the swizzle depends on the row only
-    // through lr, so tile t is an immediate offset t*4096.
-    int wfrag[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) wfrag[kk] = lr * 128 + (((kk * 2 + lh) ^ ((lr >> 1) & 7)) << 4);
-#define WFRAG(wb, t, kk) (*(const bf16x8*)((wb) + wfrag[kk] + (t) * 4096))
-
-    f32x16 acc[8];
-    auto init_acc = [&](const float* bias) {         // acc[ct][r] = bias[ct*32 + acc_row(r)]
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 v = *(const float4*)(bias + ct * 32 + 8 * g + 4 * lh);
-                acc[ct][4 * g + 0] = v.x; acc[ct][4 * g + 1] = v.y; acc[ct][4 * g + 2] = v.z; acc[ct][4 * g + 3] = v.w;
-            }
-    };
-    bf16x8 pk[8][2];                                  // packed activations: B operands of the next chain
-    auto pack_relu = [&]() {
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                Pack16 t;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t.e[j] = (bf16)fmaxf(acc[ct][8 * s + j], 0.0f);
-                pk[ct][s] = t.v;
-            }
-    };
-    // One k-step: acc[t] += W-tile(t) x B for t < NT, with the weight fragments read one step ahead.
-    bf16x8 wf[2][8];
-    auto ldw = [&](const unsigned char* wb, int kk, int s) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) wf[s][t] = WFRAG(wb, t, kk);
-    };
-
-    issue1(0, -1);
-    if (D == 3) issue1(1, -1);
-    step(0);
-    init_acc(cst);
-
-    // ---------------- phase 1: S^T = Ws @ [o_0 | o_1 | ..]^T + bs ----------------
-    for (int c = 0; c < nq1; ++c) {
-        if (c > 0) step(c);
-        if (FWN_ABL == 1) { refill(c + LA, -1); continue; }
-        const unsigned char* wb = lds + (c % D) * SLOT;
-        const unsigned char* ob = wb + W_BYTES + wave * 4096;
-        if (WDB) ldw(wb, 0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 b = *(const bf16x8*)(ob + wfrag[kk]);
-            if (WDB) {
-                if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of these MFMAs
-            }
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-                acc[ct] = mfma32(WDB ? wf[kk & 1][ct] : WFRAG(wb, ct, kk), b, acc[ct]);
-                if (ct == 0) refill(c + LA, kk);
-            }
-            if (WDB) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    pack_relu();
-    init_acc(cst + 256);
-
-    // ---------------- phase 2: U^T = Wf @ S^T + bfin ----------------
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-        step(nq1 + kc);
-        if (FWN_ABL == 1) { refill(nq1 + kc + LA, -1); continue; }
-        const unsigned char* wb = lds + ((nq1 + kc) % D) * SLOT;
-        if (WDB) ldw(wb, 0, 0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (WDB) {
-                if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int ot = 0; ot < 8; ++ot) {
-                acc[ot] = mfma32(WDB ? wf[kk & 1][ot] : WFRAG(wb, ot, kk), pk[2 * kc + (kk >> 1)][kk & 1], acc[ot]);
-                if (ot == 0) refill(nq1 + kc + LA, kk);
-            }
-            if (WDB) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    pack_relu();
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
-
-    // ---------------- phase 3: [log_s | t]^T = Wz @ U^T ----------------
-    const int ntz = 2 * a.npt;
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-        step(nq1 + 4 + kc);
-        refill(nq1 + 4 + kc + LA, -1);
-        if (FWN_ABL == 1) continue;
-        const unsigned char* wb = lds + ((nq1 + 4 + kc) % D) * SLOT;
-        if (WDB && ntz > 2) {           // wide ZeroConv (Ch > 32): fragments read one k-step ahead
-            ldw(wb, 0, 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk < 3) ldw(wb, kk + 1, (kk + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int tz = 0; tz < 8; ++tz)
-                    if (tz < ntz) acc[tz] = mfma32(wf[kk & 1][tz], pk[2 * kc + (kk >> 1)][kk & 1], acc[tz]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int tz = 0; tz < 8; ++tz)
-                    if (tz < ntz) acc[tz] = mfma32(WFRAG(wb, tz, kk), pk[2 * kc + (kk >> 1)][kk & 1], acc[tz]);
-        }
-    }
-
-    // ---------------- affine coupling + ActNorm on the b plane ----------------
-    // Buffer loads / stores: elements outside the plane (tau >= Ch, rows past M) get an
-    // out-of-range offset, read as 0 and are dropped on store - no branches.
-    const float* bzl = cst + 512;
-    const float* ezl = cst + 1024;
-    const float* an_a = cst + 1536;
-    const float* an_b = an_a + 4 * Ch;
-    const uint32_t plane_bytes = (uint32_t)((size_t)a.M * Ch * 4);
-    const srd_t sxb = make_srd(a.xb, plane_bytes), sxa = make_srd(a.xa, plane_bytes);
-    float lsum = 0.0f;
-    const bool vec4 = Ch >= 4;          // 4 consecutive channels per accumulator register group
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        if (pt < a.npt) {
-            float xv[16];
-            uint32_t voff[16];
-            if (vec4) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int tau0 = pt * 32 + 8 * g + 4 * lh;
-                    const bool ok = tau0 < Ch && row < a.M;
-                    const float4 q = *(const float4*)(a.xb + (ok ? (size_t)row * Ch + tau0 : 0));   // clamped
-                    xv[4 * g + 0] = q.x; xv[4 * g + 1] = q.y; xv[4 * g + 2] = q.z; xv[4 * g + 3] = q.w;
-                    voff[4 * g] = ok ? (uint32_t)(row * Ch + tau0) * 4u : FWN_OOB;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int tau = pt * 32 + acc_row(r, lane);
-                    const bool ok = tau < Ch && row < a.M;
-                    voff[r] = ok ? (uint32_t)(row * Ch + tau) * 4u : FWN_OOB;
-                    xv[r] = buf_load_f32(sxb, voff[r], 0);
-                }
-            }
-            float ov[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = acc_row(r, lane);
-                const int tau = pt * 32 + j;
-                const bool ok = tau < Ch && row < a.M;
-                const int tc = ok ? tau : 0;
-                const int nls = pt * 64 + j, nt = nls + 32;
-                const float ls = (acc[2 * pt][r] + bzl[nls]) * ezl[nls];
-                const float t = (acc[2 * pt + 1][r] + bzl[nt]) * ezl[nt];
-                if (!a.inverse) {
-                    const float yb = (xv[r] + an_b[tc]) * an_b[Ch + tc];              // ActNorm (model.py:86-94)
-                    ov[r] = (yb - t) * __expf(-ls);                                     // model.py:134
-                    lsum += ok ? (an_a[3 * Ch + tc] + an_b[3 * Ch + tc] - ls) : 0.0f;  // model.py:135 + :80
-                } else {
-                    const float yb = xv[r] * __expf(ls) + t;                            // model.py:156
-                    ov[r] = yb * an_b[2 * Ch + tc] - an_b[tc];                         // ActNorm^-1 (model.py:97-102)
-                }
-            }
-            if (vec4) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const u32x4 o4 = {__builtin_bit_cast(unsigned int, ov[4 * g]), __builtin_bit_cast(unsigned int, ov[4 * g + 1]),
-                                      __builtin_bit_cast(unsigned int, ov[4 * g + 2]), __builtin_bit_cast(unsigned int, ov[4 * g + 3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(o4, sxb, voff[4 * g], 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) buf_store_f32(sxb, voff[r], 0, ov[r]);
-            }
-        }
-    }
-    // a-plane: ActNorm only (the coupling passes in_a through unchanged); 4 elements per lane per
-    // step when the plane rows allow 16-byte pieces.
-    {
-        const int total = 32 * NW * Ch;                  // elements of this workgroup's rows
-        const uint32_t base = (uint32_t)(m0 * Ch) * 4u;
-        const int chmask = Ch - 1;
-        if (Ch >= 4 && !FWN_DEBUG_SCALAR_APLANE) {
-            // NOTE: the 16-byte load is a plain (clamped) float4 load, not raw_buffer_load_b128:
-            // hipcc (ROCm 7.2) lowers element extracts of that builtin's result to ONE
-            // buffer_load_dword reused for all four lanes (minimal repro in DESIGN.md).
-            const size_t plane_elems = (size_t)a.M * Ch;
-#pragma unroll 4
-            for (int idx = tid * 4; idx < total; idx += 64 * NW * 4) {
-                const size_t e0 = (size_t)m0 * Ch + idx;
-                const bool ok = e0 + 3 < plane_elems;
-                const float4 q = *(const float4*)(a.xa + (ok ? e0 : 0));
-                float f[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int tau = (idx + e) & chmask;
-                    f[e] = a.inverse ? (f[e] * an_a[2 * Ch + tau] - an_a[tau]) : ((f[e] + an_a[tau]) * an_a[Ch + tau]);
-                }
-                const u32x4 o4 = {__builtin_bit_cast(unsigned int, f[0]), __builtin_bit_cast(unsigned int, f[1]),
-                                  __builtin_bit_cast(unsigned int, f[2]), __builtin_bit_cast(unsigned int, f[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(o4, sxa, base + (uint32_t)idx * 4u, 0, 0);   // past the plane: dropped
-            }
-        } else {
-            for (int idx = tid; idx < total; idx += 64 * NW) {
-                const int tau = idx & chmask;
-                const uint32_t off = base + (uint32_t)idx * 4u;
-                const float v = buf_load_f32(sxa, off, 0);
-                buf_store_f32(sxa, off, 0, a.inverse ? (v * an_a[2 * Ch + tau] - an_a[tau]) : ((v + an_a[tau]) * an_a[Ch + tau]));
-            }
-        }
-    }
-    if (a.partial) {
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) lsum += __shfl_xor(lsum, s);
-        if (lane == 0) red[wave] = lsum;
-        __syncthreads();
-        if (tid == 0) {
-            float t = 0.0f;
-            for (int w = 0; w < NW; ++w) t += red[w];
-            a.partial[blockIdx.x] = t;
-        }
-    }
-}
+#include "tail_chain.h"
 
 // ---------------------------------------------------------------------------
 // Host-side launchers (called from the C-ABI in api.hip)
@@ -1052,9 +694,27 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 #endif
 int fwn_tail_rows(int M) { return M >= FWN_TAIL256_MIN ? 256 : 128; }   // rows per fused-tail workgroup
 int fwn_tail_is_split(int M) { return M <= FWN_TUNE(FWN_TAIL_SPLIT_MAX, FWN_TAIL_SPLIT_MAX); }
-int fwn_tail_npartials(int M) {       // log-det partial slots one tail launch writes
-    return fwn_tail_is_split(M) ? ((M + 63) / 64) * 8 : (M + fwn_tail_rows(M) - 1) / fwn_tail_rows(M);
+// M <= FWN_TAIL_SPLIT_MAX: the skip sum as a ring GEMM that splits its weights over workgroups, then either (FWN_TAIL_SPLIT_CHAIN,
+// default) tail_kernel<.., HAS_P1 = false> = final conv + ZeroConv + coupling in one launch of 64-row workgroups, or the round-2
+// form (two more ring GEMMs).
+#ifndef FWN_TAIL_SPLIT_CHAIN
+#define FWN_TAIL_SPLIT_CHAIN 1
+#endif
+#ifndef FWN_TAIL_SPLIT_CHAIN_MIN
+#define FWN_TAIL_SPLIT_CHAIN_MIN 6144    // fewer rows: too few 64-row workgroups to stream the final / ZeroConv weights through (in situ:
+#endif                                   // block 4, 4032 rows, +2 us per flow; block 7, 504 rows, +17 us against the two ring GEMMs)
+static bool tail_split_chain(int M) {
+    return FWN_TUNE(FWN_TAIL_SPLIT_CHAIN, FWN_TAIL_SPLIT_CHAIN) != 0 && M >= FWN_TUNE(FWN_TAIL_SPLIT_CHAIN_MIN, FWN_TAIL_SPLIT_CHAIN_MIN);
 }
+static int tail_chain_rows(int M) { return fwn_tail_is_split(M) ? 64 : fwn_tail_rows(M); }
+int fwn_tail_chain_xb_out(int M, int npt) { return !fwn_tail_is_split(M) || tail_split_chain(M); }
+int fwn_tail_chain_front(int M, int Ch, int npt) { return fwn_tail_chain_xb_out(M, npt) && Ch <= 8 && npt == 1; }
+int fwn_tail_npartials_chain(int M, int Ch, int front) {       // log-det partial slots one tail launch writes
+    if (fwn_tail_is_split(M) && !tail_split_chain(M)) return ((M + 63) / 64) * 8;
+    const int rw = tail_chain_rows(M) - (front ? 2 : 0);      // chained front conv: tiles overlap by one row on either side
+    return (M + rw - 1) / rw;
+}
+int fwn_tail_npartials(int M) { return fwn_tail_npartials_chain(M, 0, 0); }
 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -1247,15 +907,46 @@ void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_
                      nsplit, st);
 }
 
+// ---- tail dispatch ----
+// M > FWN_TAIL_SPLIT_MAX: the fused register-chained tail (tail_chain.h, HAS_P1), 256-row workgroups while those fill the
+// chip, else 128-row ones; below: see FWN_TAIL_SPLIT_CHAIN above.
+
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
                      const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,
                      float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse, void* scratch_s,
-                     void* scratch_u, hipStream_t st) {
+                     void* scratch_u, const fwn_tail_chain* chain, hipStream_t st) {
+    TailArgs a{(const bf16*)o, (const bf16*)Ws, bs, (const bf16*)Wf, bfin, (const bf16*)Wz, bz, ez, an,
+               xa, xb, partial, o_stride, L, M, Ch, npt, inverse};
+    const bool front = chain && chain->h0_next;
+    a.xb_out = chain ? chain->xb_out : nullptr;
+    a.S = nullptr;
+    a.h0_next = front ? (bf16*)chain->h0_next : nullptr;
+    a.Wfn = front ? (const bf16*)chain->Wfn : nullptr;
+    a.bfn = front ? chain->bfn : nullptr;
+    a.an_next = front ? chain->an_next : nullptr;
+    a.kfn = front ? chain->kfn : 0;
+    a.Ti = front ? chain->Ti : 0;
+    a.overlap = front ? 1 : 0;
+#define TAIL_LAUNCH(NW, D, BK1, WDB, NPT, P1, FRONT)                                                                  \
+    hipLaunchKernelGGL((tail_kernel<NW, D, BK1, WDB, NPT, P1, FRONT>),                                                 \
+                       dim3((M + 32 * NW - (FRONT ? 2 : 0) - 1) / (32 * NW - (FRONT ? 2 : 0))), dim3(64 * NW), 0, st, a)
+#define TAIL_BY_NPT(NW, D, BK1, WDB, P1)                                                                              \
+    do {                                                                                                              \
+        if (front) TAIL_LAUNCH(NW, D, BK1, WDB, 1, P1, true);                                                         \
+        else if (npt == 1) TAIL_LAUNCH(NW, D, BK1, WDB, 1, P1, false);                                                \
+        else if (npt == 2) TAIL_LAUNCH(NW, D, BK1, WDB, 2, P1, false);                                                \
+        else TAIL_LAUNCH(NW, D, BK1, WDB, 4, P1, false);                                                              \
+    } while (0)
     if (fwn_tail_is_split(M)) {          // scratch_s / scratch_u: [M][256] bf16 each (api.hip checks they are there)
         bf16* S = (bf16*)scratch_s;
         bf16* U = (bf16*)scratch_u;
         TailLinProb p1{(const bf16*)o, (const bf16*)Ws, bs, S, o_stride, L, M};
         launch_ring(p1, M, 256, L * 16, st);
+        if (tail_split_chain(M)) {
+            a.S = S;
+            TAIL_BY_NPT(2, 4, 64, true, false);
+            return;
+        }
         TailLinProb p2{S, (const bf16*)Wf, bfin, U, 0, 1, M};
         launch_ring(p2, M, 256, 16, st);
         TailZeroProb p3{U, (const bf16*)Wz, bz, ez, an, xa, xb, partial, M, Ch, npt, inverse};
@@ -1263,10 +954,8 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
                            st, p3, npt);
         return;
     }
-    TailArgs a{(const bf16*)o, (const bf16*)Ws, bs, (const bf16*)Wf, bfin, (const bf16*)Wz, bz, ez, an,
-               xa, xb, partial, o_stride, L, M, Ch, npt, inverse};
-    if (fwn_tail_rows(M) == 256)
-        hipLaunchKernelGGL((tail_kernel<8, 2, false>), dim3((M + 255) / 256), dim3(512), 0, st, a);
-    else
-        hipLaunchKernelGGL((tail_kernel<4, 3, true>), dim3((M + 127) / 128), dim3(256), 0, st, a);
+    if (fwn_tail_rows(M) == 256) TAIL_BY_NPT(8, 4, 32, false, true);
+    else TAIL_BY_NPT(4, 3, 64, true, true);
+#undef TAIL_BY_NPT
+#undef TAIL_LAUNCH
 }

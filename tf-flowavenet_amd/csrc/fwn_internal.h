@@ -37,14 +37,27 @@ void fwn_launch_cond2(const void* ca, const void* ca_odd, const void* Wc_base, f
 // the partial outputs (part: [nsplit - 1][..] laid out like P) into P[0..n)
 int fwn_cond_nsplit(int M, int nz, int kcpad);
 void fwn_launch_cond_reduce(float* P, const float* part, long part_stride, int nsplit, long n, hipStream_t st);
+// Chaining the flows of a block (whole-model calls): out_b to a third plane buffer, and the NEXT flow's front conv computed
+// by this tail (csrc/tail_chain.h).  NULL / all-zero = the plain in-place tail.
+struct fwn_tail_chain {
+    float* xb_out;          // out_b destination; NULL: in place (xb)
+    void* h0_next;          // != NULL: also the next flow's h0 [M][256] bf16 (needs xb_out: the tiles then overlap by one row)
+    const void* Wfn;        // next flow's chained front weights [256][kfn] (fwn_flow_desc.Wfront3)
+    const float* bfn;       // its bias [256]
+    const float* an_next;   // forward: the next flow's ActNorm table; inverse: NULL
+    int kfn, Ti;
+};
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
                      const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,
                      float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse, void* scratch_s,
-                     void* scratch_u, hipStream_t st);
+                     void* scratch_u, const fwn_tail_chain* chain, hipStream_t st);
 
 int fwn_tail_rows(int M);        // rows per fused-tail workgroup
-int fwn_tail_is_split(int M);    // the N-split tail (three ring GEMMs; needs [2][M][256] bf16 scratch) serves this M
-int fwn_tail_npartials(int M);   // log-det partial slots a tail launch writes
+int fwn_tail_is_split(int M);    // the N-split tail (ring GEMMs; needs [2][M][256] bf16 scratch) serves this M
+int fwn_tail_npartials(int M);   // log-det partial slots a plain (un-chained) tail launch writes
+int fwn_tail_npartials_chain(int M, int Ch, int front);   // ... a chained launch (fwn_tail_chain given; front: h0_next set)
+int fwn_tail_chain_xb_out(int M, int npt);                // whether the tail at this shape can write out_b elsewhere (xb_out)
+int fwn_tail_chain_front(int M, int Ch, int npt);         // ... and can compute the next flow's front conv
 
 void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st);
 void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,

@@ -27,6 +27,10 @@
 #pragma once
 #include "gemm_ring.h"
 
+#ifndef FWN_TABL
+#define FWN_TABL 0   // developer ablation (tools/diag/ab_tail.sh): 1 no MFMA / fragment reads, 2 no DMA after the prologue, 3 no epilogue
+#endif
+
 struct TailArgs {
     const bf16* o;        // [L][M][256]
     const bf16* Ws;       // [256][L*256]
@@ -68,8 +72,9 @@ __device__ __forceinline__ void fwn_wait_vm_le(int n) {
 
 // NW waves x 32 rows per workgroup, D ring slots, BK1 = phase-1 chunk width, WDB = double-buffered weight fragments
 // (worth it at one wave per SIMD), NPT = ZeroConv pair tiles (Ch <= 32 NPT), HAS_P1 = the skip GEMM runs here.
-template <int NW, int D, int BK1, bool WDB, int NPT, bool HAS_P1>
+template <int NW, int D, int BK1, bool WDB, int NPT, bool HAS_P1, bool FRONT = false>
 __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
+    static_assert(!FRONT || NPT == 1, "the chained front conv serves Ch <= 8 (one ZeroConv pair tile)");
     using G1 = RingGeom<BK1>;
     constexpr int RW = 32 * NW;
     constexpr int RB1 = BK1 * 2;
@@ -78,13 +83,13 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     constexpr int S_BYTES = RW * 512;                          // HAS_P1 == false: the S' rows of this tile, 4 sub-tiles [RW][64]
     constexpr int SLOT0 = HAS_P1 ? W1_BYTES + O1_BYTES : S_BYTES;
     constexpr int SLOT = SLOT0 > W2_BYTES ? SLOT0 : W2_BYTES;
-    constexpr int CHMAX = 32 * NPT;
+    constexpr bool FRONT_OK = FRONT;                           // the chained front conv (Ch <= 8 only)
     // constants, each table in 1-KB pieces of its own (an LDS-DMA piece always writes 1 KB):
-    // bs | bfin | bz | ez | an (NPT pieces) | bfn | an_next (NPT pieces)
+    // bs | bfin | bz | ez | an (NPT pieces) | [bfn | an_next]
     constexpr int C_BS = 0, C_BF = 256, C_BZ = 512, C_EZ = 768, C_AN = 1024, C_BFN = C_AN + 256 * NPT, C_ANN = C_BFN + 256,
-                  CST = C_ANN + 256 * NPT;
-    constexpr int NCP = 5 + 2 * NPT;                           // constant pieces
-    constexpr int T_FLOATS = RW * 8;                           // front-conv input image [RW][8] fp32 (Ch <= 8)
+                  CST = FRONT_OK ? C_ANN + 256 : C_BFN;
+    constexpr int NCP = 4 + NPT + (FRONT_OK ? 2 : 0);          // constant pieces
+    constexpr int T_FLOATS = FRONT_OK ? RW * 8 : 0;            // front-conv input image [RW][8] fp32
     static_assert(D * SLOT >= RW * 512, "the h0 transposition tiles must fit the ring");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[D * SLOT + CST * 4 + T_FLOATS * 4 + 64];
     float* cst = (float*)(lds + D * SLOT);
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     const bool owned = rvalid && (!a.overlap || (rl >= 1 && rl <= RW - 2));
     const int KS = a.L * FWN_HID;
     const int Ch = a.Ch;
-    const bool front = a.h0_next != nullptr;
+    constexpr bool front = FRONT;                    // (a.h0_next is set)
 
     // chunk sequence: [S rows] | phase 1 | phase 2 (4) | phase 3 (1 or 4) | [front weights]
     const int n0 = HAS_P1 ? 0 : 1;
@@ -124,8 +129,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         else if (pc == 3) { src = a.ez; bytes = (uint32_t)a.npt * 256u; dst = C_EZ; }
         else if (pc < 4 + NPT) { src = a.an; bytes = (uint32_t)Ch * 32u; off = (uint32_t)(pc - 4) * 1024u; dst = C_AN + (pc - 4) * 256; }
         else if (pc == 4 + NPT) { src = front ? a.bfn : a.bs; bytes = front ? 1024u : 0u; dst = C_BFN; }
-        else { src = (front && a.an_next) ? a.an_next : a.bs; bytes = (front && a.an_next) ? (uint32_t)Ch * 32u : 0u;
-               off = (uint32_t)(pc - 5 - NPT) * 1024u; dst = C_ANN + (pc - 5 - NPT) * 256; }
+        else { src = (front && a.an_next) ? a.an_next : a.bs; bytes = (front && a.an_next) ? (uint32_t)Ch * 32u : 0u; dst = C_ANN; }
         buf_load16_lds(make_srd(src, bytes), off + (uint32_t)lane * 16u, (unsigned char*)(cst + dst));
     }
     // (NZ bz / ez use only the first npt*64 floats of their piece; C_BZ / C_EZ regions are 256 floats apart)
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     };
     auto issue_chunk = [&](int c, int part, int nparts) {        // part < 0: the whole chunk
         if (c >= NC) return;
+        if (FWN_TABL == 2 && c >= D - 1) return;
         unsigned char* dst = lds + (c % D) * SLOT;
         if (!HAS_P1 && c == 0) {                                 // S' rows: sub-tile q = [RW][64] at q * RW * 128
 #pragma unroll
@@ -209,6 +214,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     auto pieces = [&](int c) -> int { return c >= NC ? 0 : (!HAS_P1 && c == 0) ? PS0 : c < c2 ? PW1 + PO1 : PW2; };
     // wait for chunk c (issued so far: chunks .. c + D - 2; those after c may stay in flight) and cross the barrier
     auto step = [&](int c) {
+        if (FWN_TABL == 2) { if (c == 0) FWN_WAIT_VMCNT(0); __builtin_amdgcn_s_barrier(); return; }
         int pend = 0;
 #pragma unroll
         for (int i = 1; i <= D - 2; ++i) pend += pieces(c + i);
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
             if (c > 0) step(c);
             const unsigned char* wb = lds + (c % D) * SLOT;
             const unsigned char* ob = wb + W1_BYTES + wave * (32 * RB1);
+            if (FWN_TABL == 1) { issue_chunk(c + LA, -1, 1); continue; }
             bf16x8 wf1[2][8];
             if (WDB) {
 #pragma unroll
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) pk[2 * q + (kk >> 1)][kk & 1] = *(const bf16x8*)(sb + q * (RW * 128) + wfrag[kk]);
-        issue_chunk(LA, -1, 1);                          // (the slot freed below is the S chunk's own: refill after the reads)
+        issue_chunk(LA, -1, 1);                          // slot D - 1 has not been used yet
     }
     init_acc(cst + C_BF);
 
@@ -310,6 +317,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
             step(c);
         }
         const unsigned char* wb = lds + (c % D) * SLOT;
+        if (FWN_TABL == 1) { issue_chunk(c + LA, -1, 1); continue; }
         if (WDB) ldw(wb, 0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -320,11 +328,10 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 #pragma unroll
             for (int ot = 0; ot < 8; ++ot) {
                 acc[ot] = mfma32(WDB ? wf[kk & 1][ot] : WFRAG(wb, ot, kk), pk[2 * kc + (kk >> 1)][kk & 1], acc[ot]);
-                if (ot == 0 && (HAS_P1 || kc > 0)) issue_chunk(c + LA, kk, 4);
+                if (ot == 0) issue_chunk(c + LA, kk, 4);
             }
             if (WDB) __builtin_amdgcn_sched_barrier(0);
         }
-        if (!HAS_P1 && kc == 0) issue_chunk(c + LA, -1, 1);
     }
     pack_relu();
 
@@ -339,12 +346,14 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         issue_chunk(c3 + LA, -1, 1);
         const unsigned char* wb = lds + (c3 % D) * SLOT;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int tz = 0; tz < 2; ++tz)
                     acc[tz] = mfma32(WFRAG(wb + q * 8192, tz, kk), pk[2 * q + (kk >> 1)][kk & 1], acc[tz]);
+            __builtin_amdgcn_sched_barrier(0);           // keep the 32 fragment reads of the chunk from being hoisted together
+        }
     } else {
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
@@ -359,6 +368,18 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         }
     }
 
+    // The chained front conv's weights were issued chunks ago: retire them NOW, while loads are the only vector-memory
+    // operations outstanding.  After the coupling a vmcnt wait would also wait for the epilogue's plane stores (vmcnt
+    // counts stores: ~2 us of store latency in front of the conv).
+    if constexpr (FRONT) FWN_WAIT_VMCNT(0);
+    if (FWN_TABL == 3) {
+        float sacc = 0.0f;
+#pragma unroll
+        for (int tz = 0; tz < 2 * NPT; ++tz)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += acc[tz][r];
+        if (sacc != 12345.678f) return;
+    }
     // ---------------- affine coupling + ActNorm on the b plane ----------------
     // Buffer loads / stores: elements outside the plane (tau >= Ch, rows not owned) get an out-of-range offset, read
     // as 0 and are dropped on store - no branches.
@@ -427,9 +448,9 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
             // the tile's out_b (every row, halo included) as the next flow's network input: ActNorm of that flow applied
             // in the forward direction (model.py:86-94 ahead of its coupling), raw in the inverse direction
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int tau = acc_row(r, lane);
-                if (tau < Ch && tau < 8) {
+            for (int r = 0; r < 4; ++r) {                // channels < 8 live in registers 0..3 (tau = r + 4 lh)
+                const int tau = r + 4 * lh;
+                if (tau < Ch) {
                     const float v = a.an_next ? (ov[r] + ann[tau]) * ann[Ch + tau] : ov[r];
                     Tt[rl * 8 + tau] = rvalid ? v : 0.0f;
                 }
@@ -472,19 +493,22 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) lsum += __shfl_xor(lsum, s);
         if (lane == 0) red[wave] = lsum;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // LDS only: __syncthreads() would also wait for the plane stores
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         if (tid == 0) {
             float t = 0.0f;
             for (int w = 0; w < NW; ++w) t += red[w];
             a.partial[blockIdx.x] = t;
         }
     }
-    if (!front) return;
-
+    if constexpr (!FRONT) return;
+    else {
     // ---------------- the next flow's front conv: h0^T = Wfn @ [taps of out_b as hi | lo]^T + bfn, ReLU ----------------
     init_acc(cst + C_BFN);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's T rows are written
-    step(c4);                                             // the weights have landed; every wave's T rows are visible
+    __builtin_amdgcn_s_barrier();                         // every wave's T rows are visible (the weights landed before the coupling)
+    asm volatile("" ::: "memory");
     {
         const unsigned char* wb = lds + (c4 % D) * SLOT;
         const int chlog = 31 - __builtin_clz(Ch);
@@ -508,7 +532,9 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
                 acc[ct] = mfma32(*(const bf16x8*)(wb + lr * 128 + ((((kk * 2 + lh) ^ ((lr >> 1) & 7))) << 4) + ct * 4096), b.v, acc[ct]);
         }
     }
-    __syncthreads();                                      // every wave is done with the weights and T: the ring is free
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // every wave is done with the weights and T: the ring is free
+    asm volatile("" ::: "memory");
     {
         // this wave's 32 rows x 256 channels as bf16 [32][256] in LDS (lds_off256 image), then 16-byte row pieces out
         unsigned char* tw = lds + wave * (32 * 512);
@@ -531,6 +557,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
             const bool own = (unsigned)grow < (unsigned)a.M && (!a.overlap || (trow >= 1 && trow <= RW - 2));
             __builtin_amdgcn_raw_buffer_store_b128(v, sh, own ? (uint32_t)(grow * FWN_HID + lr * 8) * 2u : FWN_OOB, 0, 0);
         }
+    }
     }
 #undef WFRAG
 #undef WFRAG1

@@ -15,6 +15,7 @@ Everything in this file except ``pack_model`` is pure NumPy and runs without a G
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -70,6 +71,21 @@ def front2_src_k(block: int) -> np.ndarray:
     for tap in range(3):
         for half in range(2):
             out[tap * 2 * ch + half * ch: tap * 2 * ch + (half + 1) * ch] = tap * ch + br
+    return out
+
+
+def front3_src_k(block: int) -> np.ndarray:
+    """[kf3] -> source row of the (3*Ch, 256) front kernel for the chained front conv of tail_chain.h (Ch <= 8):
+    K = (tap*Ch + tau)*2 + half - the same weight serves the hi and the lo bf16 half of the fp32 state, and the pair sits
+    in adjacent K positions so a lane builds its 8-element MFMA operand from 4 consecutive (tap, tau) inputs.
+    kf3 = 6*Ch rounded up to the MFMA k-step of 16 (16, 16, 32, 48 for Ch = 1, 2, 4, 8); -1 = K padding."""
+    ch = 1 << block
+    br = bitrev_table(block)
+    out = np.full(roundup(6 * ch, 16), -1, dtype=np.int32)
+    for tap in range(3):
+        for tau in range(ch):
+            for half in range(2):
+                out[(tap * ch + tau) * 2 + half] = tap * ch + br[tau]
     return out
 
 
@@ -503,6 +519,12 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                 wfront2 = bf16_zeros(FILTER, 6 * ch)
                 pack(wp + "/Conv_front", f2, ident256, 6 * ch, FILTER, wfront2, 6 * ch)
                 d.Wfront2 = wfront2.data_ptr()
+            if ch <= 8:      # chained front conv (the previous flow's tail computes this flow's h0, tail_chain.h)
+                f3 = dev_i32(("front3", i), lambda: front3_src_k(i))
+                kf3 = roundup(6 * ch, 16)
+                wfront3 = bf16_zeros(FILTER, kf3)
+                pack(wp + "/Conv_front", f3, ident256, kf3, FILTER, wfront3, kf3)
+                d.Wfront3, d.kf3 = wfront3.data_ptr(), kf3
             put(lambda v, d=d: setattr(d, "bfront", v.data_ptr()), lambda wp=wp: hostp[wp + "/Conv_front/bias"],
                 dict(terms=[(wp + "/Conv_front/bias", np.arange(FILTER))]))
 
@@ -596,6 +618,8 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
         pm.plan = plan
     md.flows = C.cast(pm.flow_descs, C.POINTER(_lib.FlowDesc))
     md.cond_mode = int(cond_mode)
+    # developer switch (same-box A/B, tests): FWN_CHAIN_MODE=1 runs every flow on its own like round 2 (fwn.h chain_mode)
+    md.chain_mode = int(os.environ.get("FWN_CHAIN_MODE", "0"))
     md.gate_fp8 = 1 if gate_fp8 else 0
     torch.cuda.current_stream(dev).synchronize()
     if gate_fp8:                                   # the exponents the pack kernels chose, in one copy

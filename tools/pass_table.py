@@ -3,9 +3,10 @@
     python tools/pass_table.py <kernel_trace.csv> [--batch 8] [--samples 16128] [--json out.json]
 
 A pass is found by its launch order on the one stream (the trace sorted by start time): `upsample_kernel` x n_up opens a
-pass, `prior_kernel` (forward) or `merge_kernel` (inverse) closes it.  Inside a pass every flow opens with its front conv
-(`front_valu_kernel`, or `xprep_kernel` for Ch >= 32), 6 flows make a block; `cond_batch_kernel` / `cond_reduce_kernel`
-launches belong to the block that follows them.  Per block the table gives the average kernel time per pass and stage
+pass, `prior_kernel` (forward) or `merge_kernel` (inverse) closes it.  Inside a pass every flow CLOSES with the launch that
+holds its coupling (`tail_kernel`, or the `TailZeroProb` ring GEMM), 6 flows make a block; `cond_batch_kernel` /
+`cond_reduce_kernel` launches belong to the block that follows them.  (A chained flow has no front launch of its own: the
+previous flow's tail computed its h0.)  Per block the table gives the average kernel time per pass and stage
 (front / gate / res / tail / cond), the algorithmic FLOP of the block (SURVEY 8d formula) and the fraction of the dense
 bf16 MFMA peak the block ran at, and the same per pass.  Kernel time only: launch gaps are not in it.
 """
@@ -72,11 +73,11 @@ def main():
     out = {}
     for direction in ("fwd", "inv"):
         sel = [p for d, p in passes if d == direction]
-        # only whole-model passes: 48 front launches
+        # only whole-model passes without the data-dependent init: 48 coupling launches, no ddi kernel
+        closes = lambda n: n.startswith("tail_kernel") or "TailZeroProb" in n
         good = []
         for p in sel:
-            nfront = sum(1 for _, _, n in p if n.startswith("front_valu") or n.startswith("xprep"))
-            if nfront == N_BLOCK * N_FLOW:
+            if sum(1 for _, _, n in p if closes(n)) == N_BLOCK * N_FLOW and not any(n.startswith("ddi_") for _, _, n in p):
                 good.append(p)
         if not good:
             continue
@@ -85,16 +86,14 @@ def main():
         span = 0.0
         for p in good:
             span += p[-1][1] - p[0][0]
-            flow = -1
+            flow = 0
             pending = []                          # cond launches ahead of a block's first flow
             for s, e, n in p:
                 st = stage_of(n)
-                if st == "front" and (n.startswith("front_valu") or n.startswith("xprep")):
-                    flow += 1
                 if st == "cond":
                     pending.append(e - s)
                     continue
-                if flow < 0 or (st == "other"):
+                if st == "other" or flow >= N_BLOCK * N_FLOW:
                     acc[("pre/post", "other")] += e - s
                     nl[("pre/post", "other")] += 1
                     continue
@@ -105,6 +104,8 @@ def main():
                     pending = []
                 acc[(blk, st)] += e - s
                 nl[(blk, st)] += 1
+                if closes(n):
+                    flow += 1
         npass = len(good)
         samples = a.batch * a.samples
         table = []
