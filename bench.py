@@ -121,6 +121,89 @@ def gate_roofline(model, hp, b, t, iters=30):
 
 
 GATE_SOURCES = ("gate_halo.h", "gemm_ring.h", "common.h", "flow_kernels.hip")
+# per-block lower bound sum_i max(FLOP_i / 2.5 PF, bytes_i / 8 TB/s) of one pass at datasheet peaks
+BOUND_US = {"B8_T16128": 853.0, "B1_T16128": 130.8, "B1_T220672": 1459.0}
+
+
+def kernel_source_hash():
+    """sha256 over every kernel source of the library (what a per-block / whole-pass profile must have been taken on)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "tf-flowavenet_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h"))):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(pattern):
+    """Newest profiles/<pattern> taken on the current kernel sources (its "source_sha" field), else (None, reason)."""
+    import glob
+    sha = kernel_source_hash()
+    for pj in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        with open(pj) as f:
+            rec = json.load(f)
+        if rec.get("source_sha") == sha:
+            return rec, os.path.relpath(pj, ROOT)
+    return None, "no profile of the current kernel sources (hash %s) under profiles/%s" % (sha, pattern)
+
+
+def path_roofline(hp, b, t, fwd_s, inv_s):
+    """The PATH against its rooflines (SURVEY section 8d asks for both): whole-pass MFMA fraction from the live timings,
+    the per-block table and the whole-pass HBM bytes from the committed rocprofv3 profiles of these kernel sources."""
+    flop = flop_per_sample(hp) * b * t
+    bound = BOUND_US.get("B%d_T%d" % (b, t))
+    out = {"flop_per_pass": flop, "mfma_peak_tflops": MFMA_PEAK_TFLOPS, "hbm_peak_gbs": HBM_PEAK_GBS,
+           "survey_bound_us": bound, "serial_pair_ms": (fwd_s + inv_s) * 1e3}
+    for name, sec in (("fwd", fwd_s), ("inv", inv_s)):
+        out[name] = {"ms": sec * 1e3, "mfma_frac": flop / sec / 1e12 / MFMA_PEAK_TFLOPS,
+                     "frac_of_survey_bound": (bound * 1e-6 / sec) if bound else None}
+    tab, src = committed_profile("r*_pass_table.json")
+    out["blocks_source"] = src
+    out["blocks"] = None
+    if tab:
+        out["blocks"] = {d: [{"block": r["block"], "rows": r["rows"], "us": round(r["us"], 1), "gflop": round(r["gflop"], 1),
+                              "mfma_frac": round(r["frac"], 4), "launches": r["launches"]} for r in tab[d]["blocks"]]
+                         for d in ("fwd", "inv") if d in tab}
+    tr, src = committed_profile("r*_pass_traffic.json")
+    out["hbm_source"] = src
+    out["hbm"] = None
+    if tr:
+        out["hbm"] = {d: {"traffic_bytes": tr[d]["traffic_bytes"], "ratio_to_algorithmic": tr[d]["ratio_to_algorithmic"],
+                          "gbs_at_this_pass": tr[d]["traffic_bytes"] / (fwd_s if d == "fwd" else inv_s) / 1e9,
+                          "hbm_frac": tr[d]["traffic_bytes"] / (fwd_s if d == "fwd" else inv_s) / 1e9 / HBM_PEAK_GBS}
+                      for d in ("fwd", "inv") if d in tr}
+        out["hbm"]["algorithmic_bytes"] = tr["algorithmic_bytes"]
+    return out
+
+
+def latency_b1(model, hp, t, dev, iters=10):
+    """configs[1] at the latency shape: ONE 16128-sample clip, forward and inverse, HIP events on the launch stream."""
+    import torch
+    from tf_flowavenet_amd import weights as W
+    inp = W.synthetic_inputs(hp, 1, t)
+    x, c, z = (torch.from_numpy(inp[k]).to(dev) for k in ("x", "c", "z"))
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+
+    fwd, inv = timed(lambda: model.forward(x, c)), timed(lambda: model.reverse(z, c))
+    flop = flop_per_sample(hp) * t
+    bound = BOUND_US.get("B1_T%d" % t)
+    return {"workload": "configs[1] latency shape: B=1, T=%d" % t, "fwd_ms": fwd * 1e3, "inv_ms": inv * 1e3,
+            "fwd_mfma_frac": flop / fwd / 1e12 / MFMA_PEAK_TFLOPS, "inv_mfma_frac": flop / inv / 1e12 / MFMA_PEAK_TFLOPS,
+            "survey_bound_us": bound, "fwd_frac_of_survey_bound": bound * 1e-6 / fwd if bound else None,
+            "inv_frac_of_survey_bound": bound * 1e-6 / inv if bound else None,
+            "realtime_factor_inverse": t / inv / hp.sample_rate}
 
 
 def gate_source_hash():
@@ -167,9 +250,12 @@ def rtf_10s(model, hp, dev, world, iters=5):
     sec = e0.elapsed_time(e1) * 1e-3 / iters
     assert bool(torch.isfinite(wav).all())
     audio_s = t / hp.sample_rate
+    bound = BOUND_US.get("B1_T%d" % t)
     return {"workload": "configs[3]: inverse synthesis, one %.3f s clip (T=%d) per GPU, B=1" % (audio_s, t),
             "inverse_ms": sec * 1e3, "rtf_per_gpu": audio_s / sec, "rtf_whole_job": world * audio_s / sec,
-            "samples_per_s_whole_job": world * t / sec, "n_gpus": world}
+            "samples_per_s_whole_job": world * t / sec, "n_gpus": world,
+            "mfma_frac": flop_per_sample(hp) * t / sec / 1e12 / MFMA_PEAK_TFLOPS,
+            "survey_bound_us": bound, "frac_of_survey_bound": bound * 1e-6 / sec if bound else None}
 
 
 def fp8_leg(hp, params, model_bf16, x, c, z, b, t):
@@ -255,7 +341,11 @@ def train_leg(hp, params, rank, world, dev, steps=10, batch=8, samples=6400, for
            "ms_per_step": step_s * 1e3, "samples_per_s": batch * samples * world / step_s, "n_gpus": world,
            "global_batch": batch * world, "loss": float(loss), "grad_norm": float(gnorm),
            "recorded_step": bool(tr.graph), "allreduce_ms": None, "compute_ms": None, "overlap": None,
-           "gradient_bytes": int(tr.opt.g.numel()) * 4}
+           "gradient_bytes": int(tr.opt.g.numel()) * 4,
+           # forward + backward = 3 x the forward FLOP of the samples (the recompute by inversion is not counted)
+           "mfma_frac": 3.0 * flop_per_sample(hp) * batch * samples / step_s / 1e12 / MFMA_PEAK_TFLOPS,
+           # lock-step: every rank holds bit-identical master weights after the timed steps (all-reduce of a 64-bit hash)
+           "weights_identical": bool(tr.opt.weights_identical())}
     if exchanging:
         tr.exchange = False              # same step without the gradient exchange (weights drift apart: timing only)
         compute_s, _ = timed(max(3, steps // 2))
@@ -513,6 +603,8 @@ def main():
             "realtime_factor_inverse": b * t / inv_s / hp.sample_rate,
         }
         out["roofline"] = gate_roofline(model, hp, b, t)
+        out["path"] = path_roofline(hp, b, t, fwd_s, inv_s)
+        out["latency_b1"] = latency_b1(model, hp, t, dev)
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None
         else:

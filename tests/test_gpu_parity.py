@@ -5,8 +5,10 @@ BASELINE.json's full sizes.  Nothing here reads /root/reference.
 Tolerances (stated, fp): hidden activations and weights are bf16 with fp32 accumulation, the
 flow state / ActNorm / coupling / reductions are fp32:
   * log_p within 1e-3 relative (north_star), logdet within 1e-3 * max(1, |logdet|);
-  * final z within 2e-2 max-abs (|z| up to ~5; measured maxima over 129 k .. 1.7 M latent samples: 1.2e-2 .. 1.75e-2) and
-    2.5e-3 mean-abs (measured 1.6e-3) on <= 48 flows;
+  * final z (|z| up to ~5, <= 48 flows): at the real sizes (129 k .. 1.7 M latent samples) the per-sample error is
+    asserted on robust statistics - mean-abs 2.5e-3 (measured 1.6e-3), 99.99th percentile 1.5e-2 (measured 1.15e-2 .. 1.19e-2) -
+    plus a loose bound on the single worst sample, 4e-2 (measured maxima 1.2e-2 .. 1.8e-2: one tail sample on another
+    box's reduction order must not turn the suite red); the small fixtures keep the plain 2e-2 max-abs;
   * inverse waveform within 1e-2 max-abs (relative to max(1, |x|max)) for DDI-initialised (normalised) models;
   * fixtures stored as float16 (the B=8 and 10 s cases) add half a float16 ulp of the reference value.
 """
@@ -32,6 +34,15 @@ REL_LOGP = 1e-3
 ABS_LOGDET = 1e-3
 ABS_Z = 2e-2
 ABS_WAV = 1e-2
+Z_MEAN, Z_P9999, Z_MAX = 2.5e-3, 1.5e-2, 4e-2       # full-size latent statistics (header)
+
+
+def check_z_stats(z, z0, half_ulp=0.0):
+    """Per-sample latent error at the real sizes: mean, 99.99th percentile and a loose max (see the header)."""
+    err = np.maximum(np.abs(z - z0) - half_ulp * np.abs(z0), 0.0).reshape(-1)
+    mean, p9999, worst = float(err.mean()), float(np.quantile(err, 0.9999)), float(err.max())
+    print("z error over %d samples: mean %.3e  p99.99 %.3e  max %.3e" % (err.size, mean, p9999, worst))
+    assert mean < Z_MEAN and p9999 <= Z_P9999 and worst <= Z_MAX, (mean, p9999, worst)
 
 
 def dev(a):
@@ -111,8 +122,7 @@ def test_baseline_configs_at_their_real_sizes_match_golden(name):
     z = z_planes_to_squeezed(zp, hp.n_block, hp.n_flow).cpu().numpy()
     z0 = g["z"].astype(np.float32)
     assert z.shape == z0.shape
-    assert (np.abs(z - z0) <= ABS_Z + half_ulp * np.abs(z0)).all(), np.abs(z - z0).max()
-    assert np.abs(z - z0).mean() < 2.5e-3              # measured 1.6e-3 (bf16 hidden activations through 48 flows)
+    check_z_stats(z, z0, half_ulp)                     # bf16 hidden activations through 48 flows
     an = model.export_actnorm()
     last = "Block_%d/Flow_%d/ActNorm/" % (hp.n_block - 1, hp.n_flow - 1)
     np.testing.assert_allclose(an[last + "b"], g["an_b_last"], atol=2e-2)
@@ -508,10 +518,26 @@ def test_synthesize_cli_file_contract(tmp_path):
                               output_dir=str(tmp_path / "out"), seed=75, batch=8))()
     names = S.synthesize(args, hp)
     assert names == ["a.npy", "b.npy", "c.npy"]
+    # what the file must hold: the oracle's reverse of the SAME seeded z (synthesize.py:14: z = N(0,1) * temp, drawn per
+    # launch in order of clip length from one generator), as 16-bit PCM
+    gen = torch.Generator(device="cpu").manual_seed(75)
+    p64 = onp.to_f64(params)
+    want = {}
+    for frames, group in ((3, ["a", "b"]), (5, ["c"])):
+        z = (torch.randn(len(group), frames * 256, 1, generator=gen) * hp.temp).numpy().astype(np.float64)
+        c = np.stack([np.load(tmp_path / "mels" / (n + ".npy")) for n in group]).astype(np.float64)
+        x0 = onp.reverse(p64, z, c, hp)
+        for n, w in zip(group, x0[:, :, 0]):
+            want[n] = w
     for name, frames in (("a", 3), ("b", 3), ("c", 5)):
         with wave.open(str(tmp_path / "out" / (name + ".wav"))) as w:
             assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 22050)
             assert w.getnframes() == frames * 256
+            pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float64)
+        ref = np.clip(want[name], -1.0, 1.0) * 32767.0
+        tol = 1.0 + ABS_WAV * max(1.0, float(np.abs(want[name]).max())) * 32767.0      # one LSB of rounding + the waveform tolerance
+        assert np.abs(pcm - ref).max() <= tol, (name, np.abs(pcm - ref).max(), tol)
+        print("wav %s: max |pcm - oracle| = %.1f LSB (tolerance %.1f)" % (name, np.abs(pcm - ref).max(), tol))
     # same seed -> same audio (z is seedable; TF's Philox stream is not reproducible)
     args.output_dir = str(tmp_path / "out2")
     S.synthesize(args, hp)

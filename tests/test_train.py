@@ -261,6 +261,37 @@ def test_side_stream_weight_gradients_equal_the_one_stream_call_bit_for_bit(cfg,
         assert torch.equal(res["0"][3][k], res["1"][3][k]), k
 
 
+def test_directional_derivatives_at_the_training_shape_match_the_oracle_forward():
+    """the gradient at the BENCH's training shape (n_block = 8, B = 8 crops of 6400 samples,
+    hparams.py:28,36 - 25 600 rows at block 0: the 256 x 256 halo gate, the 256 x 256 TN tiles, the fused tails), which fp64
+    autograd cannot reach.  tests/golden/make_grad_dir.py took central differences of the fp64 oracle's FORWARD loss along
+    one direction per parameter family (the normalised toy-batch autograd gradient of that family, recomputed here on the
+    CPU); <g_HIP, d> must match them.  Tolerance: 2 % of the derivative (bf16 hidden activations; measured below)."""
+    import importlib.util
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.hparams import default_hparams
+    from tf_flowavenet_amd.training import GradEngine
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_grad_dir", os.path.join(here, "make_grad_dir.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    fx = np.load(os.path.join(here, mg.NAME + ".npz"))
+    hp = default_hparams()
+    b, t = int(fx["b"]), int(fx["t"])
+    assert (b, t) == (hp.batch_size, hp.max_time_steps)
+    p = W.synthetic_params(hp, int(fx["seed"]), actnorm="random")
+    dirs = mg.directions(p, hp)                       # fp64 autograd on the toy batch (CPU, ~15 s)
+    inp = W.synthetic_inputs(hp, b, t)
+    loss, lp, ld, g = GradEngine(hp).loss_and_grads(p, torch.from_numpy(inp["x"]).reshape(b, t), torch.from_numpy(inp["c"]))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-3 * abs(float(fx["loss"]))
+    for fam in mg.FAMILIES:
+        got = sum(float((g[k].detach().cpu().numpy().astype(np.float64).reshape(-1) * d.reshape(-1)).sum()) for k, d in dirs[fam].items())
+        want = float(fx["fd_" + fam])
+        print("%-9s <g, d> = %.6e   oracle central difference %.6e   rel %.2e" % (fam, got, want, abs(got - want) / abs(want)))
+        assert abs(got - want) <= 2e-2 * abs(want), (fam, got, want)
+
+
 def test_an_exception_in_the_block_callback_stops_the_call_and_reaches_the_caller():
     """ctypes prints and drops an exception raised inside a callback.  A failed all-reduce / graph cut in
     on_block_done must stop the C sequencer (FWN_ERR_CALLBACK) and be re-raised by GradEngine, with one stream and two."""

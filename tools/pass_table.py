@@ -134,6 +134,11 @@ def main():
                 t.get("res_us", 0), t.get("tail_us", 0), t.get("cond_us", 0)))
         print("  upsample / split / merge / prior / copies: %.1f us" % other_us)
     if a.json:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        out["source_sha"] = bench.kernel_source_hash()          # bench.py quotes the table only for these kernel sources
+        out["workload"] = "B=%d, T=%d, one-stream pass (bench.py --serial), rocprofv3 --kernel-trace" % (a.batch, a.samples)
         with open(a.json, "w") as f:
             json.dump(out, f, indent=1)
     if not out:
