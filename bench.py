@@ -433,6 +433,7 @@ def main():
     ap.add_argument("--no-train", action="store_true", help="skip the configs[2] training-step leg")
     ap.add_argument("--no-rtf", action="store_true", help="skip the configs[3] 10 s clip leg")
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] fp8 gate leg")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B=1 latency leg (profile runs: only passes of the bench workload)")
     ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--leg-timeout", type=int, default=240, help="seconds an optional leg may take")
     ap.add_argument("--force-collectives", action="store_true",
@@ -604,7 +605,7 @@ def main():
         }
         out["roofline"] = gate_roofline(model, hp, b, t)
         out["path"] = path_roofline(hp, b, t, fwd_s, inv_s)
-        out["latency_b1"] = latency_b1(model, hp, t, dev)
+        out["latency_b1"] = None if args.no_latency else latency_b1(model, hp, t, dev)
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None
         else:

@@ -47,7 +47,7 @@ def main():
         d = "/tmp/pass_pmc_%s" % ctr
         subprocess.run(["rm", "-rf", d])
         subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-                        os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--serial", "--no-train", "--no-rtf", "--no-fp8", "--steps", "3",
+                        os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--serial", "--no-train", "--no-rtf", "--no-fp8", "--no-latency", "--steps", "3",
                         "--warmup", "1"], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
         if not files:

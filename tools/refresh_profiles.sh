@@ -13,7 +13,7 @@ cp $O/${TAG}_gate_traffic.json $R/profiles/ 2>/dev/null
 # whole-pass HBM bytes (FETCH_SIZE / WRITE_SIZE over every dispatch of a forward / inverse pass)
 python3 tools/pass_pmc.py $O $TAG > $O/pass_pmc.log 2>&1
 cp $O/${TAG}_pass_traffic.json $R/profiles/ 2>/dev/null
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -o $TAG -- python3 $R/bench.py --no-cpu-baseline --serial --no-train --no-rtf --no-fp8 --steps 20 --warmup 3 > $O/rocprof.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/rocprof -o $TAG -- python3 $R/bench.py --no-cpu-baseline --serial --no-train --no-rtf --no-fp8 --no-latency --steps 20 --warmup 3 > $O/rocprof.log 2>&1)
 T=$(ls $O/rocprof/*/*kernel_trace.csv $O/rocprof/*kernel_trace.csv 2>/dev/null | head -1)
 python3 tools/prof_summary.py $T 57 > $O/${TAG}_kernel_summary_B8.txt
 # per-(block, stage) table of the one-stream pass (bench.py quotes it while the kernel sources are unchanged)
