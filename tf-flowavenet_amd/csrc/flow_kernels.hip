@@ -387,6 +387,8 @@ struct ResProb {
     // This layer is HBM-bound (o read, h read, h write); with one column per lane it issued 64 two-byte VMEM
     // instructions per lane.  Same arithmetic, same order: (h + acc + b) * sqrt(1/2).
     static constexpr bool LDS_EPI = true;
+    __device__ bool rows_launch() const { return true; }
+    __device__ bool rows_tile(int) const { return true; }
     template <int MI>
     __device__ void epilogue_rows(const float* wt, int mrow0, int ncol0, int lane) const {
         const int col = ncol0 + (lane & 7) * 8;

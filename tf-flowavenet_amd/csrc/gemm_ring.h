@@ -288,10 +288,20 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         // residual layer).  Each wave parks its (32 MI) x 64 fp32 tile in the drained ring and takes it back as rows of
         // 8 consecutive columns per lane: 16-byte loads / stores, 8 rows x 128 bytes per wave instruction.
         // (instantiations whose tiles would not fit the drained ring keep the direct epilogue)
-        __syncthreads();                 // every wave has read its last fragments (no DMA is in flight any more)
-        float* wt = (float*)lds + wave * (32 * MI * 64);
-        lds_epi_park<MI>(acc, wt, lane);
-        p.template epilogue_rows<MI>(wt, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+        // rows_launch(): the same answer in every wave of the workgroup (the barrier below); rows_tile(): per wave tile -
+        // a tile whose epilogue needs the accumulator layout (the gate derivative of fwn_gemm) keeps the direct form
+        if (p.rows_launch()) {
+            __syncthreads();             // every wave has read its last fragments (no DMA is in flight any more)
+            if (p.rows_tile(n0 + wn * 64)) {
+                float* wt = (float*)lds + wave * (32 * MI * 64);
+                lds_epi_park<MI>(acc, wt, lane);
+                p.template epilogue_rows<MI>(wt, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+            } else {
+                p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+            }
+        } else {
+            p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+        }
     } else {
         p.template epilogue<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane);
     }

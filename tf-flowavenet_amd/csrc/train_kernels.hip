@@ -44,6 +44,105 @@ struct LinProb {
         return (n < g.N && kk < cc.k) ? (uint32_t)(n * g.ldw + cc.koff + kk) * 2u : FWN_OOB;
     }
     __device__ float acc_init(int) const { return 0.0f; }
+    // ---- row-major epilogue (gemm_ring.h LDS_EPI): 8 consecutive columns of one row per lane, 16-byte loads / stores ----
+    // With one column per lane the direct epilogue below issues up to 64 two- / four-byte VMEM instructions per lane and
+    // operand (absent operands included: their zero-sized descriptors still cost the issue); the training GEMMs with 256-row
+    // tiles spent more time there than in the K loop.  Same arithmetic in the same order: results are bit-identical.
+    // Needs 8-column groups that are whole and 16-byte aligned; the gate-derivative tiles keep the accumulator layout.
+    static constexpr bool LDS_EPI = true;
+    __device__ bool rows_launch() const {
+        const bool al = ((uintptr_t)g.Y & 15) == 0 && (!g.R || ((uintptr_t)g.R & 15) == 0) && (!g.mask || ((uintptr_t)g.mask & 15) == 0) &&
+                        (!g.bias || ((uintptr_t)g.bias & 15) == 0);
+        return al && g.N % 8 == 0 && g.ldy % 8 == 0 && (!g.R || g.ldr % 8 == 0) && (!g.mask || g.ldmask % 8 == 0) &&
+               (!g.out_f32 || (size_t)g.split_stride % 4 == 0);
+    }
+    __device__ bool rows_tile(int ncol0) const {
+        const int c0 = ncol0 - g.gate_col0;
+        return !(g.gate_aux && c0 >= 0 && c0 < 256);
+    }
+    template <int MI>
+    __device__ void epilogue_rows(const float* wt, int mrow0, int ncol0, int lane) const {
+        const int col = ncol0 + (lane & 7) * 8;
+        const bool cok = col < g.N;                              // the whole group of 8 (N % 8 == 0)
+        const int cc = cok ? col : 0;                            // clamped: loads stay inside, stores of such lanes are dropped
+        float bb[8];
+        if (g.bias) {
+            const float4 b0 = *(const float4*)(g.bias + cc), b1 = *(const float4*)(g.bias + cc + 4);
+            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bb[e] = 0.0f;
+        }
+        const bool relu_on = g.relu != 0, acc_on = g.out_f32 && g.accumulate;
+        const float mdef = g.mask ? 0.0f : 1.0f;
+        const uint32_t ybytes = (uint32_t)((size_t)g.M * g.ldy * (g.out_f32 ? 4 : 2));
+        const srd_t sY = make_srd(g.out_f32 ? (const void*)y32 : (const void*)g.Y, ybytes);
+        constexpr int NIT = 4 * MI;
+        Pack16 rv[NIT], mv[NIT];
+        float4 ya[NIT][2];
+        int rowc[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = mrow0 + it * 8 + (lane >> 3);
+            ok[it] = cok && row < g.M;
+            rowc[it] = row < g.M ? row : 0;
+        }
+        // one uniform branch per operand, not one per load: the loads inside issue back to back
+        if (g.R) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) rv[it].u = *(const uint4*)((const bf16*)g.R + (size_t)rowc[it] * g.ldr + cc);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) rv[it].u = zero16();
+        }
+        if (g.mask) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) mv[it].u = *(const uint4*)((const bf16*)g.mask + (size_t)rowc[it] * g.ldmask + cc);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) mv[it].u = zero16();
+        }
+        if (acc_on) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const float* yp = y32 + (size_t)rowc[it] * g.ldy + cc;
+                ya[it][0] = *(const float4*)yp;
+                ya[it][1] = *(const float4*)(yp + 4);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) ya[it][0] = ya[it][1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            float a[8], out[8];
+            lds_epi_take(wt, it, lane, a);
+            const float yv[8] = {ya[it][0].x, ya[it][0].y, ya[it][0].z, ya[it][0].w, ya[it][1].x, ya[it][1].y, ya[it][1].z, ya[it][1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = a[e] + bb[e] + g.rscale * (float)rv[it].e[e];
+                v = ((float)mv[it].e[e] + mdef) > 0.0f ? v : 0.0f;
+                v = relu_on ? fmaxf(v, 0.0f) : v;
+                out[e] = v * g.oscale + yv[e];
+            }
+            const int row = mrow0 + it * 8 + (lane >> 3);
+            if (g.out_f32) {
+                const uint32_t voff = ok[it] ? (uint32_t)(row * g.ldy + col) * 4u : FWN_OOB;
+                const u32x4 o0 = {__builtin_bit_cast(unsigned int, out[0]), __builtin_bit_cast(unsigned int, out[1]),
+                                  __builtin_bit_cast(unsigned int, out[2]), __builtin_bit_cast(unsigned int, out[3])};
+                const u32x4 o1 = {__builtin_bit_cast(unsigned int, out[4]), __builtin_bit_cast(unsigned int, out[5]),
+                                  __builtin_bit_cast(unsigned int, out[6]), __builtin_bit_cast(unsigned int, out[7])};
+                __builtin_amdgcn_raw_buffer_store_b128(o0, sY, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1, sY, voff == FWN_OOB ? FWN_OOB : voff + 16u, 0, 0);
+            } else {
+                Pack16 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o.e[e] = (bf16)out[e];
+                __builtin_amdgcn_raw_buffer_store_b128(o.w, sY, ok[it] ? (uint32_t)(row * g.ldy + col) * 2u : FWN_OOB, 0, 0);
+            }
+        }
+    }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
         // Branch-free: an absent operand (no residual / mask / accumulate / bias) gets a zero-sized buffer descriptor, rows
