@@ -272,14 +272,18 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
             const unsigned char* wb = lds + (c % D) * SLOT;
             const unsigned char* ob = wb + W1_BYTES + wave * (32 * RB1);
             if (FWN_TABL == 1) { issue_chunk(c + LA, -1, 1); continue; }
-            bf16x8 wf1[2][8];
+            bf16x8 wf1[2][8], bq[G1::KS];
             if (WDB) {
+                // the chunk's o fragments up front (one exposed LDS latency per chunk instead of one per k-step: at one wave per
+                // SIMD nothing else covers it), then the first weight fragments
+#pragma unroll
+                for (int kk = 0; kk < G1::KS; ++kk) bq[kk] = *(const bf16x8*)(ob + wfrag1[kk]);
 #pragma unroll
                 for (int t = 0; t < 8; ++t) wf1[0][t] = WFRAG1(wb, t, 0);
             }
 #pragma unroll
             for (int kk = 0; kk < G1::KS; ++kk) {
-                const bf16x8 b = *(const bf16x8*)(ob + wfrag1[kk]);
+                const bf16x8 b = WDB ? bq[kk] : *(const bf16x8*)(ob + wfrag1[kk]);
                 if (WDB) {
                     if (kk + 1 < G1::KS) {
 #pragma unroll
@@ -345,14 +349,27 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         step(c3);
         issue_chunk(c3 + LA, -1, 1);
         const unsigned char* wb = lds + (c3 % D) * SLOT;
+        // the 8 fragments of sub-tile q + 1 are read while the 8 MFMAs of sub-tile q issue
+        bf16x8 zf[2][4][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int tz = 0; tz < 2; ++tz) zf[0][kk][tz] = WFRAG(wb, tz, kk);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (q + 1 < 4) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int tz = 0; tz < 2; ++tz) zf[(q + 1) & 1][kk][tz] = WFRAG(wb + (q + 1) * 8192, tz, kk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int tz = 0; tz < 2; ++tz)
-                    acc[tz] = mfma32(WFRAG(wb + q * 8192, tz, kk), pk[2 * q + (kk >> 1)][kk & 1], acc[tz]);
-            __builtin_amdgcn_sched_barrier(0);           // keep the 32 fragment reads of the chunk from being hoisted together
+                    acc[tz] = mfma32(zf[q & 1][kk][tz], pk[2 * q + (kk >> 1)][kk & 1], acc[tz]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     } else {
 #pragma unroll
