@@ -46,19 +46,21 @@ def test_struct_layout_matches_header(tmp_path):
         pytest.skip("gcc not available")
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "fwn.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fwn_flow_desc), '
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(fwn_flow_desc), '
                    'offsetof(fwn_flow_desc, an), offsetof(fwn_flow_desc, Wd8), offsetof(fwn_flow_desc, wd8_exp), sizeof(fwn_model_desc), '
                    'offsetof(fwn_model_desc, up_w), offsetof(fwn_model_desc, flows), offsetof(fwn_model_desc, gate_fp8), '
                    'sizeof(fwn_conv_grad), sizeof(fwn_flow_train_desc), offsetof(fwn_flow_train_desc, d_zscale), sizeof(fwn_train_desc), '
                    'offsetof(fwn_train_desc, an_logdet), offsetof(fwn_train_desc, side_stream), sizeof(fwn_gemm_desc), '
-                   'offsetof(fwn_gemm_desc, gate_out)); return 0; }\n')
+                   'offsetof(fwn_gemm_desc, gate_out), offsetof(fwn_flow_desc, Wfront3), offsetof(fwn_flow_desc, kf3), '
+                   'offsetof(fwn_model_desc, chain_mode)); return 0; }\n')
     exe = str(tmp_path / "layout")
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     F, M, FT, T = _lib.FlowDesc, _lib.ModelDesc, _lib.FlowTrainDesc, _lib.TrainDesc
     assert got == [C.sizeof(F), F.an.offset, F.Wd8.offset, F.wd8_exp.offset, C.sizeof(M), M.up_w.offset, M.flows.offset,
                    M.gate_fp8.offset, C.sizeof(_lib.ConvGrad), C.sizeof(FT), FT.d_zscale.offset, C.sizeof(T), T.an_logdet.offset,
-                   T.side_stream.offset, C.sizeof(_lib.GemmDesc), _lib.GemmDesc.gate_out.offset]
+                   T.side_stream.offset, C.sizeof(_lib.GemmDesc), _lib.GemmDesc.gate_out.offset, F.Wfront3.offset, F.kf3.offset,
+                   M.chain_mode.offset]
 
 
 def test_argument_validation_reports_errors(lib):
