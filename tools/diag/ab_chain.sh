@@ -1,5 +1,4 @@
-# GPU box: parity subset, then single-pass times with the flows chained (default) and every flow on its own (FWN_CHAIN_MODE=1),
-# and with the round-2 N-split tail (libfwn_base.so)
+# GPU box: parity subset, then single-pass times with the flows chained (default) and every flow on its own (FWN_CHAIN_MODE=1)
 cd "$(dirname "$0")/../.."
 O=gpurun_out/ab_chain
 mkdir -p $O
@@ -18,7 +17,6 @@ print("%-34s %s" % (sys.argv[1], r.stdout.strip() or r.stderr[-800:]), flush=Tru
 PY
 }
 for i in 1 2; do
-run "base(r2 kernels)" FWN_LIB=tf-flowavenet_amd/csrc/libfwn_base.so
 run "new, unchained" FWN_CHAIN_MODE=1
 run "new, chained"
 done 2>&1 | tee $O/times.txt
