@@ -427,6 +427,38 @@ def test_full_size_round_trip_and_determinism(full_model):
     assert float(dz.max()) < 3e-2 and float(dz.mean()) < 2e-3
 
 
+def test_chained_flows_agree_with_every_flow_on_its_own(full_model, monkeypatch):
+    """Round 3: inside the whole-model calls the flows of a block are chained (fwn_model_desc.chain_mode = 0: out_b to a third
+    plane buffer, tiles that overlap by one row, the next flow's front conv on the MFMA in the previous tail -
+    csrc/tail_chain.h).  chain_mode = 1 runs every flow on its own as the stage entry points do.  Same arithmetic except for
+    the front conv of the chained flows (hi | lo bf16 halves of the fp32 state on the MFMA instead of fp32 FMAs).  The scalars
+    agree to 2e-5; per sample the two are two realisations of the same bf16 rounding noise (a flipped last bit of one hidden
+    activation decorrelates the rest of 48 flows), so they sit as far from each other as each sits from the fp64 oracle
+    (measured: z mean 1.4e-3, max 1.7e-2; waveform mean 2.8e-4, max 2.7e-3) and are held to the oracle's bounds.  Shapes: the
+    bench workload (fused tails in the 256- and 128-row forms, the N-split chain at block 3) and one clip (the N-split
+    forms at every block)."""
+    hp, model, x, c, z = full_model
+    params = dict(W.synthetic_params(hp, 1234))
+    for k, v in model.export_actnorm().items():          # the tables the data-dependent init of `full_model` produced
+        params[k] = np.asarray(v, dtype=np.float32).reshape(params[k].shape)
+    monkeypatch.setenv("FWN_CHAIN_MODE", "1")
+    plain = FloWaveNet(hp).load_params(params)
+    monkeypatch.delenv("FWN_CHAIN_MODE")
+    assert plain._packed.model_desc.chain_mode == 1 and model._packed.model_desc.chain_mode == 0
+    for xx, cc, zz in ((x, c, z), (x[2:3], c[2:3], z[2:3])):
+        lp0, ld0, zp0 = model.forward(xx, cc, return_z=True)
+        w0 = model.reverse(zz, cc)
+        lp1, ld1, zp1 = plain.forward(xx, cc, return_z=True)
+        w1 = plain.reverse(zz, cc)
+        assert abs(float(lp0) - float(lp1)) <= 2e-5 * abs(float(lp1)) and abs(float(ld0) - float(ld1)) <= 2e-5 * max(1.0, abs(float(ld1)))
+        dzz = (zp0 - zp1).abs()
+        dw = (w0 - w1).abs()
+        print("chained vs plain, B=%d: z mean %.2e max %.2e   wav mean %.2e max %.2e" % (xx.shape[0], float(dzz.mean()), float(dzz.max()),
+                                                                                      float(dw.mean()), float(dw.max())))
+        assert float(dzz.mean()) < Z_MEAN and float(dzz.max()) < Z_MAX
+        assert float(dw.mean()) < 1e-3 and float(dw.max()) < ABS_WAV
+
+
 def test_full_size_inverse_is_deterministic_and_bounded(full_model):
     hp, model, x, c, z = full_model
     w1 = model.reverse(z, c)
