@@ -105,7 +105,18 @@ def test_weight_and_bias_gradient_via_transposes_and_split_k(m, ti, shifts):
 GRAD_REL, GRAD_FLOOR, GRAD_REL_MAX = 0.1, 2e-3, 0.3
 
 
-def grad_rel_allowed(norm_ref, norm_total):
+GRAD_BIG, GRAD_REL_BIG = 0.01, 0.1       # tensors carrying >= 1 % of the whole gradient's norm: no absolute floor
+_SEEN_BIG = []
+
+
+def grad_rel_allowed(norm_ref, norm_total, rel=None):
+    """Allowed relative error of one gradient tensor.  Small tensors (cancelling sums of bf16 products) get an absolute floor
+    of 2e-3 of the whole gradient's norm; a tensor that carries 1 % of the whole gradient or more must be within GRAD_REL_BIG
+    on its own (the floor let such a tensor be 30 % off)."""
+    if norm_ref >= GRAD_BIG * norm_total:
+        if rel is not None:
+            _SEEN_BIG.append(rel)
+        return GRAD_REL_BIG
     return min(GRAD_REL_MAX, GRAD_REL + GRAD_FLOOR * norm_total / norm_ref)
 
 
@@ -150,7 +161,7 @@ def test_loss_and_all_parameter_gradients_match_autograd_oracle(cfg, b, t):
             continue
         rel = np.linalg.norm(a - r) / np.linalg.norm(r)
         rels.append(rel)
-        assert rel < grad_rel_allowed(np.linalg.norm(r), total), (k, rel, np.linalg.norm(r), total)
+        assert rel < grad_rel_allowed(np.linalg.norm(r), total, rel), (k, rel, np.linalg.norm(r), total)
         dot += float((a * r).sum()); na += float((a * a).sum()); nb_ += float((r * r).sum())
     assert np.median(rels) < 3e-2, np.median(rels)
     assert dot / np.sqrt(na * nb_) > 0.999            # direction of the whole gradient
@@ -184,9 +195,11 @@ def test_full_width_model_gradients_match_autograd_oracle(n_block, b, t):
             continue
         rel = np.linalg.norm(a - r) / nr
         rels.append(rel)
-        assert rel < grad_rel_allowed(nr, total), (k, rel, nr, total)
+        assert rel < grad_rel_allowed(nr, total, rel), (k, rel, nr, total)
         dot += float(a @ r); na += float(a @ a); nb_ += float(r @ r)
     assert len(rels) == len(g0) - 3 * hp.n_block * hp.n_flow
+    print("tensors with >= 1 %% of the gradient norm: %d, worst relative error %.3f" % (len(_SEEN_BIG), max(_SEEN_BIG) if _SEEN_BIG else 0.0))
+    _SEEN_BIG.clear()
     assert np.median(rels) < 4e-2, np.median(rels)
     assert dot / np.sqrt(na * nb_) > 0.9999
 
