@@ -222,6 +222,12 @@ def load():
         raise FwnError(
             "HIP extension %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C tf-flowavenet_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # libfwn.so depends on libamdhip64; in a process that also uses torch on the GPU that name must resolve to torch's own
+    # copy, i.e. torch has to be loaded first (the other order left torch with the system runtime: "no ROCm-capable device")
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
