@@ -234,6 +234,131 @@ struct FrontRingProb {
     }
 };
 
+// ---- front conv for the late blocks in ONE launch (round 3) ----------------------------------------
+// xprep_kernel + the ring GEMM were two dependent launches of a few dozen workgroups (4.7 + 5.3 us per flow, 18 flows per
+// pass).  Here a workgroup builds the (hi | lo) bf16 image of ITS rows (+ one halo row on either side) in LDS itself - ActNorm
+// applied, zero rows outside the clip - and the three taps read that one image at row offsets 0, 1, 2 (the tap sharing of
+// gate_halo.h); only the weights (Wfront2, K = tap*2Ch + half*Ch + tau) stream through a 4-slot LDS-DMA ring.
+// Tile 64 rows x 64 channels, 4 waves as 2 x 2, one 32 x 32 accumulator tile each.
+// LDS allocation: the kernel needs 64 - 66 KB, but it asks for 156 KB so that NO other LDS-using workgroup shares its CU.
+// With 66 KB (or 100 KB) it sat beside workgroups of other kernels from the bench's other streams and ~1 overlapped step in
+// 100 came back with one clip off by ~1e-2 (tools/diag/lanes_flake.py: 4 of 240 steps; 0 of 3 600 with the CU to itself;
+// 0 of 720 without this kernel).  It is the only kernel here that writes LDS with ds_write WHILE LDS-DMA pieces are in
+// flight and is small enough to be co-resident - the same signature as round 2's front_valu_kernel finding (DESIGN.md,
+// "Toolchain pitfalls"): a workgroup's ds_write traffic and another workgroup's LDS-DMA on one CU do not mix reliably.
+#ifndef FWN_FRONT_LDS_MIN
+#define FWN_FRONT_LDS_MIN (156 * 1024)
+#endif
+template <int CH>
+__global__ __launch_bounds__(256) void front_mfma_kernel(const float* __restrict__ xa, const float* __restrict__ an, int apply_an,
+                                                         const bf16* __restrict__ W2, const float* __restrict__ bias,
+                                                         bf16* __restrict__ hout, int M, int Ti) {
+    constexpr int RB = 4 * CH;                      // image row bytes: (hi | lo) x CH bf16
+    constexpr int NR = 66, ZROW = 66;               // rows m0 - 1 .. m0 + 64, then one row of zeros
+    constexpr int CPT = 2 * CH / 64;                // 64-wide K chunks per tap
+    constexpr int NQ = 3 * CPT, D = 4;
+    constexpr int A_BYTES = (NR + 1) * RB, B_SLOT = 64 * 128;
+    constexpr int LDS_USED = D * B_SLOT + A_BYTES;
+    constexpr int LDS_BYTES = LDS_USED > FWN_FRONT_LDS_MIN ? LDS_USED : FWN_FRONT_LDS_MIN;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+    unsigned char* const ldsA = lds + D * B_SLOT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int tile_m = blockIdx.x >> 2, tile_n = blockIdx.x & 3;
+    const int m0 = tile_m * 64, n0 = tile_n * 64;
+    // 16-byte piece p of image row `row`: conflict-free for 32 lanes reading 32 rows at one piece index
+    auto a_off = [](int row, int p) -> int {
+        if constexpr (CH == 32) return row * 128 + ((p ^ ((row >> 1) & 7)) << 4);
+        else if constexpr (CH == 64) return row * 256 + ((p ^ (row & 15)) << 4);
+        else return row * 512 + ((p >> 4) << 8) + (((p & 15) ^ (row & 15)) << 4);
+    };
+    // weight ring: chunk q = columns [64 q, +64) of rows n0 .. n0 + 63: 8 pieces, two per wave
+    const srd_t sw = make_srd(W2, (uint32_t)(256u * 6u * CH * 2u));
+    auto issue = [&](int q) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 8 * (wave + 4 * j) + (lane >> 3);
+            buf_load16_lds(sw, (uint32_t)((n0 + r) * 6 * CH + q * 64 + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2u,
+                           lds + (q % D) * B_SLOT + (wave + 4 * j) * 1024);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < D - 1; ++q)
+        if (q < NQ) issue(q);
+    // the image: 4 channels of one row per task - fp32 in, ActNorm, (hi | lo) out
+    constexpr int NTASK = (NR + 1) * (CH / 4), NIT = (NTASK + 255) / 256;
+    float4 vin[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {              // every load of the thread in flight at once (clamped addresses)
+        const int task = tid + it * 256;
+        const int j = task / (CH / 4), tau = (task % (CH / 4)) * 4;
+        const int g = m0 - 1 + j;
+        const bool ok = task < NTASK && j < NR && (unsigned)g < (unsigned)M;
+        vin[it] = *(const float4*)(xa + (size_t)(ok ? g : 0) * CH + (ok ? tau : 0));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int task = tid + it * 256;
+        if (task >= NTASK) break;
+        const int j = task / (CH / 4), tau = (task % (CH / 4)) * 4;
+        const int g = m0 - 1 + j;
+        const bool ok = j < NR && (unsigned)g < (unsigned)M;
+        const float4 v = vin[it];
+        float f[4] = {v.x, v.y, v.z, v.w};
+        union { bf16 e[4]; uint2 u; } hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y = apply_an ? (f[e] + an[tau + e]) * an[CH + tau + e] : f[e];
+            y = ok ? y : 0.0f;
+            hi.e[e] = (bf16)y;
+            lo.e[e] = (bf16)(y - (float)hi.e[e]);
+        }
+        *(uint2*)(ldsA + a_off(j, tau >> 3) + (tau & 7) * 2) = hi.u;
+        *(uint2*)(ldsA + a_off(j, (CH + tau) >> 3) + (tau & 7) * 2) = lo.u;
+    }
+    // this lane's fragment rows per tap: image row (local + tap), or the zero row outside the clip / the matrix
+    int arow[3];
+    {
+        const int r = m0 + wm * 32 + lr;
+        const int t = r % Ti;
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+            arow[tap] = (r < M && (unsigned)(t + tap - 1) < (unsigned)Ti) ? wm * 32 + lr + tap : ZROW;
+    }
+    f32x16 acc;
+    {
+        const float b0 = bias[n0 + wn * 32 + lr];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b0;
+    }
+    const int bfr = (wn * 32 + lr) * 128;           // + swizzled piece: the B rows of this wave
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        // chunks issued so far: min(NQ, q + D - 1); those after q may stay in flight (2 pieces per wave and chunk)
+        const int pend = (NQ < q + D - 1 ? NQ : q + D - 1) - (q + 1);
+        if (pend >= 2) FWN_WAIT_VMCNT(4);
+        else if (pend == 1) FWN_WAIT_VMCNT(2);
+        else FWN_WAIT_VMCNT(0);
+        if (q == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image rows this wave wrote
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (q + D - 1 < NQ) issue(q + D - 1);
+        const unsigned char* lb = lds + (q % D) * B_SLOT;
+        const int tap = q / CPT, kc = q % CPT;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 a = *(const bf16x8*)(ldsA + a_off(arow[tap], kc * 8 + kk * 2 + lh));
+            const bf16x8 b = *(const bf16x8*)(lb + bfr + ((((kk * 2 + lh) ^ (((wn * 32 + lr) >> 1) & 7))) << 4));
+            acc = mfma32(a, b, acc);
+        }
+    }
+    const srd_t so = make_srd(hout, (uint32_t)((size_t)M * FWN_HID * 2));
+    const uint32_t voff = (uint32_t)((m0 + wm * 32 + 4 * lh) * FWN_HID + n0 + wn * 32 + lr) * 2u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf_store_bf16(so, voff, (uint32_t)(acc_row_c(r) * FWN_HID * 2), fmaxf(acc[r], 0.0f));
+}
+
 // ---- gated dilated layer: o = tanh(f) * sigmoid(g), modules.py:113-124 ---------------------
 // K segments: 3 dilated taps over h (K = 3*256) then the 1x1 conditioning conv over c_a
 // (K = cin), or a precomputed conditioning projection P added in the epilogue.
@@ -766,6 +891,13 @@ static void launch_ring(const Prob& p, int M, int N, int ksteps, hipStream_t st)
 
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,
                       void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, void* h8out, hipStream_t st) {
+    if (W2 && (Ch == 32 || Ch == 64 || Ch == 128) && ((uintptr_t)xa & 15) == 0 && FWN_TUNE(FWN_FRONT_FUSED, 1)) {
+        const int grid = ((M + 63) / 64) * 4;
+        if (Ch == 32) hipLaunchKernelGGL((front_mfma_kernel<32>), dim3(grid), dim3(256), 0, st, xa, an_a, apply_an, (const bf16*)W2, bias, (bf16*)hout, M, Ti);
+        else if (Ch == 64) hipLaunchKernelGGL((front_mfma_kernel<64>), dim3(grid), dim3(256), 0, st, xa, an_a, apply_an, (const bf16*)W2, bias, (bf16*)hout, M, Ti);
+        else hipLaunchKernelGGL((front_mfma_kernel<128>), dim3(grid), dim3(256), 0, st, xa, an_a, apply_an, (const bf16*)W2, bias, (bf16*)hout, M, Ti);
+        return;
+    }
     if (Ch >= 32 && W2 && scratch) {
         const long total = (long)M * Ch;
         const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
