@@ -22,8 +22,8 @@ def passes_of(rows):
     cur = None
     for _, name, val in rows:
         base = name.replace("void ", "").split("(")[0]
-        if base.startswith("upsample_kernel"):
-            if cur is None or any(not n.startswith("upsample_kernel") for n, _ in cur):
+        if (base.startswith("upsample_kernel") or base.startswith("upsample8_kernel")):
+            if cur is None or any(not n.startswith("upsample") for n, _ in cur):
                 cur = []
             cur.append((base, val))
             continue

@@ -2,7 +2,7 @@
 
     python tools/pass_table.py <kernel_trace.csv> [--batch 8] [--samples 16128] [--json out.json]
 
-A pass is found by its launch order on the one stream (the trace sorted by start time): `upsample_kernel` x n_up opens a
+A pass is found by its launch order on the one stream (the trace sorted by start time): `upsample[8]_kernel` x n_up opens a
 pass, `prior_kernel` (forward) or `merge_kernel` (inverse) closes it.  Inside a pass every flow CLOSES with the launch that
 holds its coupling (`tail_kernel`, or the `TailZeroProb` ring GEMM), 6 flows make a block; `cond_batch_kernel` /
 `cond_reduce_kernel` launches belong to the block that follows them.  (A chained flow has no front launch of its own: the
@@ -29,7 +29,7 @@ def block_flop(i, samples):
 
 
 def stage_of(name):
-    if name.startswith("front_valu") or name.startswith("xprep") or "FrontRingProb" in name or "FrontProb" in name:
+    if name.startswith("front_valu") or name.startswith("front_mfma") or name.startswith("xprep") or "FrontRingProb" in name or "FrontProb" in name:
         return "front"
     if name.startswith("gate_halo") or "GateProb" in name:
         return "gate"
@@ -58,8 +58,8 @@ def main():
     passes, cur, direction = [], None, None
     for s, e, name in rows:
         base = name.split("(")[0]
-        if base.startswith("upsample_kernel"):
-            if cur is None or any(not n.startswith("upsample_kernel") for _, _, n in cur):
+        if (base.startswith("upsample_kernel") or base.startswith("upsample8_kernel")):
+            if cur is None or any(not n.startswith("upsample") for _, _, n in cur):
                 cur = []
             cur.append((s, e, base))
             continue
