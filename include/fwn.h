@@ -118,6 +118,8 @@ typedef struct fwn_flow_desc {
     const float* bgate[FWN_MAX_LAYERS];                     /* [512] conv bias + cond bias     */
     const void* Wres[FWN_MAX_LAYERS];                       /* [256][256] (layers 0..L-2)      */
     const float* bres[FWN_MAX_LAYERS];
+    /* Wskip / Wfinal: row n' holds output channel n' with bits 2 and 3 swapped (packing.acc_k_perm: the order the tail
+     * kernel's accumulator registers feed the next MFMA chain in), biases alike; every K axis in natural channel order */
     const void* Wskip;   const float* bskip;                /* [256][L*256], [256] (sum)       */
     const void* Wfinal;  const float* bfinal;               /* [256][256], [256]               */
     const void* Wzero;   const float* bzero; const float* ezero;   /* [npt*64][256], [npt*64]x2 */
@@ -183,6 +185,12 @@ int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit
 int fwn_tail_partials(int M);
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
              int inverse, void* scratch, void* stream);
+/* The same tail as the training step runs it (forward direction): it also keeps what the backward needs -
+ * save_s = S = ReLU(skip sum) and save_u = U = ReLU(final conv), bf16 [M][256] in natural channel order, and
+ * save_z = Z = U Wz + bz, fp32 [M][2 Ch] (log_s channels then t channels, plane order; before the exp(3 scale) factor).
+ * o: layer l at o + l * o_stride elements (the training step keeps every layer's output in a buffer of its own). */
+int fwn_tail_train(const fwn_flow_desc* d, const void* o, int64_t o_stride, float* xa, float* xb, float* partial, int M,
+                   void* save_s, void* save_u, float* save_z, void* stream);
 
 /* ---- one whole flow (replaces Flow.forward / Flow.reverse, model.py:185-202) ----
  * xa / xb: the planes holding in_a / in_b for this flow's swap parity, ca the matching
@@ -403,10 +411,12 @@ typedef struct fwn_flow_train_desc {
     const void* WdT[FWN_MAX_LAYERS];            /* [256][1536] dilated filter|gate, K = tap*512 + (f|g)*256 + n */
     const void* WcT[FWN_MAX_LAYERS];            /* [cin][512]  conditioning filter|gate, row stride wct_ld      */
     const void* WresT[FWN_MAX_LAYERS];          /* [256][256]  layers 0..L-2                                    */
-    const void* Wskip;  const void* WskipT_all; /* [256][L*256], [L*256][256]                                   */
-    const void* Wfin;   const void* WfinT;      /* [256][256] natural K order, and transposed                   */
-    const void* Wz;     const void* WzT;        /* [2Ch][256] rows in plane order, [256][ldz]                   */
-    const float* bskip; const float* bfin; const float* bz; const float* ez;    /* tables in device channel order */
+    /* Wskip / Wfin / Wz / bskip / bfin / bz: unused since the forward half runs the inference tail (fwn_tail_train) - may
+     * be NULL; the backward reads the transposed copies and ez */
+    const void* Wskip;  const void* WskipT_all; /* (unused), [L*256][256]                                       */
+    const void* Wfin;   const void* WfinT;      /* (unused), [256][256] transposed                              */
+    const void* Wz;     const void* WzT;        /* (unused), [256][ldz] columns in plane order                  */
+    const float* bskip; const float* bfin; const float* bz; const float* ez;    /* ez [2Ch] = exp(3 scale), plane order */
     int32_t ldz;                                /* max(8, 2Ch)                                                  */
     int32_t wct_ld;                             /* row stride of WcT in elements (0: 512).  L*512 with WcT[l] =
                                                    WcT[0] + l*512: the layers side by side in one [cin][L*512] matrix -
@@ -424,7 +434,8 @@ typedef struct fwn_train_desc {
     const int64_t* br[16]; const int64_t* zcol[16];
     const float* up_bias_dev[FWN_MAX_UPSAMPLE]; /* the bias masters (device scalars)                            */
     fwn_conv_grad up[FWN_MAX_UPSAMPLE];         /* V [2s][3], scalar g; dV, dg, db (bias)                       */
-    const float* an_logdet;                     /* device scalar: sum over flows of mean_C(3 logs) (model.py:80) */
+    const float* an_logdet;                     /* unused (the tail's log-det partials carry the ActNorm terms); any
+                                                   non-NULL device pointer */
     int32_t zero_dead_res, reserved;            /* != 0: also zero the gradients of the dead last-layer res_conv */
     /* Optional second hipStream_t (NULL: one stream).  The weight gradients of block i (grouped TN GEMMs + weight-norm
      * backward) and its conditioning-gradient GEMMs then run on it under the data-gradient chain of block i - 1 and are

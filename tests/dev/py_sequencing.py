@@ -80,7 +80,7 @@ def loss_and_grads(self, tp, params, x, c):
         cur = out
     planes = f32(2, B * T // 2)
     self._call("fwn_split_planes", x.data_ptr(), B, T, planes.data_ptr(), st)
-    saved, partials, an_logdet = [], [], 0.0
+    saved, partials = [], []
     p = 0
     for i in range(hp.n_block):
         ch = 1 << i
@@ -106,32 +106,29 @@ def loss_and_grads(self, tp, params, x, c):
             an = pm.an[(i, j)]                                   # [2][4][Ch]
             xa, xb = planes[p].view(m, ch), planes[p ^ 1].view(m, ch)
             ca = cplanes[p].view(m, cin)
-            self._call("fwn_actnorm_apply2", xa.data_ptr(), xb.data_ptr(), an.data_ptr(), m * ch, ch, st)
-            if tp.an_logdet is None:
-                an_logdet = an_logdet + an[:, 3, :].sum() / (2 * ch)    # mean_C(3 logs): parameter-only scalar
             h = [b16(m, 256) for _ in range(L)]
-            o = [b16(m, 256) for _ in range(L)]
+            o_all = b16(L, m, 256)
+            o = [o_all[l] for l in range(L)]
             aux = [b16(m, 512) for _ in range(L)]
             scr = torch.empty(m * 2 * ch, dtype=torch.bfloat16, device=dev) if ch >= 32 else None      # (hi | lo) image: ring-GEMM front
-            self._call("fwn_front", C.byref(d), xa.data_ptr(), h[0].data_ptr(), scr.data_ptr() if scr is not None else None, m, ti, 0, st)
+            # the inference kernels: the front conv applies the flow's ActNorm on the fly, the tail normalises both planes
+            self._call("fwn_front", C.byref(d), xa.data_ptr(), h[0].data_ptr(), scr.data_ptr() if scr is not None else None, m, ti, 1, st)
             for l in range(L):
                 self._call("fwn_gate_train", C.byref(d), l, h[l].data_ptr(), ca.data_ptr() if P is None else None,
                            P[j, l].data_ptr() if P is not None else None, o[l].data_ptr(), aux[l].data_ptr(), m, ti, st)
                 if l + 1 < L:
                     self._call("fwn_res", C.byref(d), l, o[l].data_ptr(), h[l].data_ptr(), h[l + 1].data_ptr(), m, st)
-            s_act = gemm([(o[l], 256, 0, l * 256) for l in range(L)], t["Wskip"], 256, m, bias=t["bskip"], relu=True)
-            u_act = gemm([(s_act, 256, 0, 0)], t["Wfin"], 256, m, bias=t["bfin"], relu=True)
-            z = gemm([(u_act, 256, 0, 0)], t["Wz"], 2 * ch, m, bias=t["bz"], out_f32=True)
-            nb = max(1, min(256, m * ch // 1024))
-            part = f32(nb)
-            self._call("fwn_coupling_fwd", xb.data_ptr(), z.data_ptr(), t["ez"].data_ptr(), m, ch, part.data_ptr(), nb, st)
+            s_act, u_act, z = b16(m, 256), b16(m, 256), f32(m, 2 * ch)
+            part = f32(int(self.lib.fwn_tail_partials(m)))
+            self._call("fwn_tail_train", C.byref(d), o_all.data_ptr(), m * 256, xa.data_ptr(), xb.data_ptr(), part.data_ptr(), m,
+                       s_act.data_ptr(), u_act.data_ptr(), z.data_ptr(), st)
             partials.append(part)
             saved.append((i, j, p, h, o, aux, s_act, u_act, z))
             p ^= 1
     partial_all = torch.cat(partials)
     out2 = f32(2)
     self._call("fwn_prior_logp", planes.data_ptr(), B * T, partial_all.data_ptr(), partial_all.numel(), out2.data_ptr(), st)
-    log_p, logdet = out2[0], out2[1] + (an_logdet if tp.an_logdet is None else tp.an_logdet)
+    log_p, logdet = out2[0], out2[1]          # (the tail's log-det partials carry the ActNorm terms)
     loss = -(log_p + logdet)
 
     # ---------------- backward ----------------

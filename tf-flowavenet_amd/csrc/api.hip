@@ -278,6 +278,22 @@ int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float*
     return check_launch("fwn_tail");
 }
 
+int fwn_tail_train(const fwn_flow_desc* d, const void* o, int64_t o_stride, float* xa, float* xb, float* partial, int M,
+                   void* save_s, void* save_u, float* save_z, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(o && xa && xb && M > 0 && o_stride >= 0, "fwn_tail_train: bad argument");
+    REQUIRE(save_s && save_u && save_z && ALIGNED16(save_s) && ALIGNED16(save_u) && ALIGNED16(save_z),
+            "fwn_tail_train: save_s / save_u / save_z (16-byte aligned) required");
+    REQUIRE(((int64_t)(d->L - 1) * o_stride + (int64_t)M * 256) * 2 < ((int64_t)1 << 31), "fwn_tail_train: o spans more than 2 GiB");
+    fwn_tail_chain tc;
+    memset(&tc, 0, sizeof(tc));
+    tc.save_s = save_s; tc.save_u = save_u; tc.save_z = save_z;
+    fwn_launch_tail(o, (long)o_stride, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero, d->ezero, d->an, xa, xb,
+                    partial, M, d->Ch, d->npt, 0, nullptr, nullptr, &tc, (hipStream_t)stream);
+    return check_launch("fwn_tail_train");
+}
+
 int fwn_tail_partials(int M) { return M > 0 ? fwn_tail_npartials(M) : 0; }
 
 // ddi: 0 none, 1 local two-pass init, 2 moments -> reduce callback (may be NULL) -> tables

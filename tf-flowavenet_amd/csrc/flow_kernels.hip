@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cond_batch_kernel(CondBatch cb, 
 // launch at 4 .. 126 workgroups).  Below the threshold the tail runs as three ring GEMMs whose weights are split over
 // workgroups by output column instead:  S = ReLU(sum_l o_l Wskip_l + bs)  ->  U = ReLU(S Wfinal + bf)  ->
 // (log_s | t) = U Wzero, coupling + ActNorm (+ log-det partials) in the epilogue.
-// S and U keep the K order the packed Wfinal / Wzero expect (packing.acc_k_perm = bits 2 and 3 of the channel index
+// Wskip / Wfinal rows are packed in accumulator order (packing.acc_k_perm = bits 2 and 3 of the channel index
 // swapped - an involution), applied to the COLUMN of the 2-byte epilogue stores.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int swap_bits23(int c) { return (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1); }
@@ -727,7 +727,7 @@ struct TailLinProb {      // Y' = ReLU(sum_l A_l[M][256] . W[:, l*256 ..]^T + bi
 struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of one 32-channel pair tile (tile_n = pt)
     static constexpr bool A_DMA = true;
     static constexpr bool ALLOW_256 = false;
-    const bf16* U;        // [M][256], K in acc order
+    const bf16* U;        // [M][256]
     const bf16* Wz;       // [npt*64][256]
     const float* bz;      // [npt*64]
     const float* ez;      // [npt*64]
@@ -736,6 +736,7 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
     float* xb;
     float* partial;       // [mtiles*8] (forward) or nullptr
     int M, Ch, npt, inverse;
+    float* save_z;        // optional (training): Z = U Wz + bz, fp32 [M][2 Ch] (log_s channels, then t channels)
     struct RowCtx { int row; };
     struct ChunkCtx { int k0; };
     template <int BK> __device__ int nchunks() const { return FWN_HID / BK; }
@@ -765,6 +766,8 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
         const srd_t sxa = make_srd(xa, plane_bytes), sxb = make_srd(xb, plane_bytes);
         const int rbase = mrow0 + 4 * (lane >> 5);
         const uint32_t voff = chok ? (uint32_t)(rbase * Ch + tau) * 4u : FWN_OOB;     // rows past M fall off the descriptor
+        const srd_t sz = make_srd(save_z ? save_z : xb, save_z ? (uint32_t)((size_t)M * 2 * Ch * 4) : 0u);
+        const uint32_t zoff = chok ? (uint32_t)(rbase * 2 * Ch + tau) * 4u : FWN_OOB;
         float lsum = 0.0f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -793,6 +796,10 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
                 }
                 buf_store_f32(sxb, voff, so, ob);
                 buf_store_f32(sxa, voff, so, oa);
+                if (save_z) {
+                    buf_store_f32(sz, zoff, 2 * so, acc[mi][0][r]);
+                    buf_store_f32(sz, zoff, 2 * so + (uint32_t)(Ch * 4), acc[mi][1][r]);
+                }
             }
         }
         if (partial) {          // one slot per (row tile, pair tile, wave row): fixed order, summed by prior_kernel
@@ -1061,6 +1068,9 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
     a.kfn = front ? chain->kfn : 0;
     a.Ti = front ? chain->Ti : 0;
     a.overlap = front ? 1 : 0;
+    a.save_s = chain ? (bf16*)chain->save_s : nullptr;
+    a.save_u = chain ? (bf16*)chain->save_u : nullptr;
+    a.save_z = chain ? chain->save_z : nullptr;
 #define TAIL_LAUNCH(NW, D, BK1, WDB, NPT, P1, FRONT)                                                                  \
     hipLaunchKernelGGL((tail_kernel<NW, D, BK1, WDB, NPT, P1, FRONT>),                                                 \
                        dim3((M + 32 * NW - (FRONT ? 2 : 0) - 1) / (32 * NW - (FRONT ? 2 : 0))), dim3(64 * NW), 0, st, a)
@@ -1072,8 +1082,9 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
         else TAIL_LAUNCH(NW, D, BK1, WDB, 4, P1, false);                                                              \
     } while (0)
     if (fwn_tail_is_split(M)) {          // scratch_s / scratch_u: [M][256] bf16 each (api.hip checks they are there)
-        bf16* S = (bf16*)scratch_s;
-        bf16* U = (bf16*)scratch_u;
+        bf16* S = a.save_s ? a.save_s : (bf16*)scratch_s;      // training keeps S and U: they are written where it wants them
+        bf16* U = a.save_u ? a.save_u : (bf16*)scratch_u;
+        a.save_s = nullptr;                                    // (S comes from the ring GEMM, not from the chained kernel)
         TailLinProb p1{(const bf16*)o, (const bf16*)Ws, bs, S, o_stride, L, M};
         launch_ring(p1, M, 256, L * 16, st);
         if (tail_split_chain(M)) {
@@ -1083,7 +1094,7 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
         }
         TailLinProb p2{S, (const bf16*)Wf, bfin, U, 0, 1, M};
         launch_ring(p2, M, 256, 16, st);
-        TailZeroProb p3{U, (const bf16*)Wz, bz, ez, an, xa, xb, partial, M, Ch, npt, inverse};
+        TailZeroProb p3{U, (const bf16*)Wz, bz, ez, an, xa, xb, partial, M, Ch, npt, inverse, a.save_z};
         hipLaunchKernelGGL((gemm_ring_kernel<64, 64, 2, 1, 128, 3, TailZeroProb, 2>), dim3(((M + 63) / 64) * npt), dim3(256), 0,
                            st, p3, npt);
         return;

@@ -46,6 +46,11 @@ struct fwn_tail_chain {
     const float* bfn;       // its bias [256]
     const float* an_next;   // forward: the next flow's ActNorm table; inverse: NULL
     int kfn, Ti;
+    // what the training backward keeps of the tail (each optional): S = ReLU(skip sum), U = ReLU(final conv) as bf16
+    // [M][256] in natural channel order, Z = U Wz + bz as fp32 [M][2 Ch] (log_s channels, then t channels, plane order)
+    void* save_s;
+    void* save_u;
+    float* save_z;
 };
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
                      const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,

@@ -4,9 +4,16 @@
 //
 // Weight-streaming: each wave owns 32 time rows and ALL 256 hidden channels.  The GEMMs are computed transposed
 // (channels on the accumulator registers, time on the lanes), so the fp32 accumulator tile of one GEMM, after bias +
-// ReLU + bf16 packing, IS the B operand of the next MFMA chain: no LDS round trip for S and U.  Wfinal / Wzero are
-// packed with their K axis in accumulator-register order (packing.acc_k_perm).  Weights (and in phase 1 the o rows)
-// stream through a D-slot LDS ring by LDS-DMA with counted vmcnt waits, shared by the NW waves of the workgroup.
+// ReLU + bf16 packing, IS the B operand of the next MFMA chain: no LDS round trip for S and U.  The ROWS of Wskip /
+// Wfinal (and their biases) are packed in accumulator-register order (packing.acc_k_perm), so the 8 packed elements of a
+// lane are 8 consecutive channels: S and U exist in natural channel order, the K axes of Wfinal / Wzero are natural.
+// Weights (and in phase 1 the o rows) stream through a D-slot LDS ring by LDS-DMA with counted vmcnt waits, shared by
+// the NW waves of the workgroup.
+//
+// Training (a.save_*): the backward needs S, U (bf16 [M][256]) and Z = U Wz + bz (fp32 [M][2 Ch], log_s | t in plane
+// channel order).  A lane stores its packed operands as 16-byte pieces right after each pack (32 rows x 32 bytes per
+// wave instruction) and Z beside the coupling's plane stores.  The stores count in vmcnt like the DMA pieces, in issue
+// order: the ring waits of the next LA chunks add them (step()).
 //
 // Ring sizing (round 3).  The 256-row form (8 waves) used to run two 64 KB slots - ONE chunk in flight: every chunk
 // paid its DMA latency (16 x ~2 us per launch, 37 us at block 0).  Phase-1 chunks are now BK1 = 32 columns wide there
@@ -33,11 +40,11 @@
 
 struct TailArgs {
     const bf16* o;        // [L][M][256]
-    const bf16* Ws;       // [256][L*256]
+    const bf16* Ws;       // [256][L*256]   rows in acc order (row n' = channel acc_k_perm(n'))
     const float* bs;      // [256]  (sum of the L skip biases)
-    const bf16* Wf;       // [256][256]   K in acc order
+    const bf16* Wf;       // [256][256]   rows in acc order, K natural
     const float* bfin;    // [256]
-    const bf16* Wz;       // [npt*64][256] K in acc order; pair tiles: 32 log_s rows then 32 t rows
+    const bf16* Wz;       // [npt*64][256] K natural; pair tiles: 32 log_s rows then 32 t rows
     const float* bz;      // [npt*64]
     const float* ez;      // [npt*64]  exp(3*scale)
     const float* an;      // [2][4][Ch]: (a|b) x (shift, scale, iscale, logs3)
@@ -48,17 +55,25 @@ struct TailArgs {
     int L, M, Ch, npt, inverse;
     // ---- chain extensions (all optional) ----
     float* xb_out;        // where out_b goes (nullptr: in place)
-    const bf16* S;        // HAS_P1 == false: S' [M][256] = ReLU(skip sum), columns in acc order
+    const bf16* S;        // HAS_P1 == false: S [M][256] = ReLU(skip sum)
     bf16* h0_next;        // != nullptr: also write the next flow's h0 = ReLU(front conv(out_b)) [M][256]
     const bf16* Wfn;      // next flow's front weights [256][kfn], k = (tap*Ch + tau)*2 + (hi|lo)
     const float* bfn;     // its bias [256]
     const float* an_next; // forward: the next flow's ActNorm table [2][4][Ch] (its a rows are applied); inverse: nullptr
     int kfn, Ti, overlap;
+    // ---- what the training backward keeps (all optional) ----
+    bf16* save_s;         // S = ReLU(skip sum)  [M][256]   (HAS_P1 only: otherwise S is a.S already)
+    bf16* save_u;         // U = ReLU(final conv)  [M][256]
+    float* save_z;        // Z = U Wz + bz  [M][2 Ch]: log_s channels, then t channels, plane order
 };
 
 __device__ __forceinline__ void fwn_wait_vm_le(int n) {
     // n wave-uniform: wait until at most n vector-memory operations are outstanding (waiting for fewer is safe)
-    if (n >= 24) FWN_WAIT_VMCNT(24);
+    if (n >= 48) FWN_WAIT_VMCNT(48);
+    else if (n >= 40) FWN_WAIT_VMCNT(40);
+    else if (n >= 32) FWN_WAIT_VMCNT(32);
+    else if (n >= 28) FWN_WAIT_VMCNT(28);
+    else if (n >= 24) FWN_WAIT_VMCNT(24);
     else if (n >= 20) FWN_WAIT_VMCNT(20);
     else if (n >= 16) FWN_WAIT_VMCNT(16);
     else if (n >= 12) FWN_WAIT_VMCNT(12);
@@ -213,15 +228,29 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     };
     auto pieces = [&](int c) -> int { return c >= NC ? 0 : (!HAS_P1 && c == 0) ? PS0 : c < c2 ? PW1 + PO1 : PW2; };
     // wait for chunk c (issued so far: chunks .. c + D - 2; those after c may stay in flight) and cross the barrier
+    constexpr int LA = D - 1;                                    // refill distance
+    // saved operands (training): 16 stores per lane, issued when chunks .. sv_upto had been issued - they are younger than
+    // those chunks' pieces and older than every later chunk's
+    constexpr int NSV = 16;
+    int sv_upto = -1;
     auto step = [&](int c) {
         if (FWN_TABL == 2) { if (c == 0) FWN_WAIT_VMCNT(0); __builtin_amdgcn_s_barrier(); return; }
-        int pend = 0;
+        int pend = c <= sv_upto ? NSV : 0;
 #pragma unroll
         for (int i = 1; i <= D - 2; ++i) pend += pieces(c + i);
         fwn_wait_vm_le(pend);
         __builtin_amdgcn_s_barrier();
     };
-    constexpr int LA = D - 1;                                    // refill distance
+    auto save_pk = [&](bf16* dst, const bf16x8 (&pk_)[8][2], int issued_upto) {
+        const srd_t sd = make_srd(dst, (uint32_t)((size_t)a.M * FWN_HID * 2));
+        const uint32_t base = owned ? (uint32_t)(row * FWN_HID + lh * 8) * 2u : FWN_OOB;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pk_[ct][s]), sd, base, (ct * 32 + s * 16) * 2, 0);
+        sv_upto = issued_upto;
+    };
 
     // fragment offsets inside a 32-row tile: the swizzles depend on the row only through lr
     int wfrag[4], wfrag1[G1::KS];
@@ -300,8 +329,9 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
             }
         }
         pack_relu();
+        if (a.save_s) save_pk(a.save_s, pk, c2 - 1 + LA);
     } else {
-        // S' rows of this wave straight into the operand registers: sub-tile q, k-step kk -> pk[2 q + kk / 2][kk % 2]
+        // S rows of this wave straight into the operand registers: sub-tile q, k-step kk -> pk[2 q + kk / 2][kk % 2]
         const unsigned char* sb = lds + wave * 4096;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -338,6 +368,7 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         }
     }
     pack_relu();
+    if (a.save_u) save_pk(a.save_u, pk, c3 - 1 + LA);
 
     // ---------------- phase 3: [log_s | t]^T = Wz @ U^T ----------------
     constexpr int NTZ = 2 * NPT;
@@ -460,6 +491,33 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) buf_store_f32(sxo, voff[r], 0, ov[r]);
+        }
+        if (a.save_z) {                   // Z = U Wz + bz for the training backward: [row][tau] = log_s, [row][Ch + tau] = t (before exp(3 scale))
+            const srd_t sz = make_srd(a.save_z, (uint32_t)((size_t)a.M * 2 * Ch * 4));
+            const int tsoff = Ch * 4;
+            if (vec4) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int j0 = 8 * g + 4 * lh;
+                    const uint32_t zoff = voff[4 * g] != FWN_OOB ? (uint32_t)(row * 2 * Ch + pt * 32 + j0) * 4u : FWN_OOB;
+                    u32x4 zl, zt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        zl[e] = __builtin_bit_cast(unsigned int, acc[2 * pt][4 * g + e] + bzl[pt * 64 + j0 + e]);
+                        zt[e] = __builtin_bit_cast(unsigned int, acc[2 * pt + 1][4 * g + e] + bzl[pt * 64 + 32 + j0 + e]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(zl, sz, zoff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(zt, sz, zoff, tsoff, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = acc_row(r, lane);
+                    const uint32_t zoff = voff[r] != FWN_OOB ? (uint32_t)(row * 2 * Ch + pt * 32 + j) * 4u : FWN_OOB;
+                    buf_store_f32(sz, zoff, 0, acc[2 * pt][r] + bzl[pt * 64 + j]);
+                    buf_store_f32(sz, zoff, tsoff, acc[2 * pt + 1][r] + bzl[pt * 64 + 32 + j]);
+                }
+            }
         }
         if (pt == 0 && front) {
             // the tile's out_b (every row, halo included) as the next flow's network input: ActNorm of that flow applied

@@ -54,7 +54,10 @@ __global__ void up_finish_kernel(const float* __restrict__ dg3, const float* __r
 }
 __global__ void finish_loss_kernel(const float* __restrict__ out2, const float* __restrict__ an_logdet, float* __restrict__ out3) {
     if (threadIdx.x == 0) {
-        const float log_p = out2[0], logdet = out2[1] + an_logdet[0];
+        // (the tail's log-det partials carry the ActNorm terms: an_logdet, the parameter-only scalar of the un-fused tail of
+        // round 2, is no longer added)
+        const float log_p = out2[0], logdet = out2[1];
+        (void)an_logdet;
         out3[0] = -(log_p + logdet);
         out3[1] = log_p;
         out3[2] = logdet;
@@ -186,8 +189,7 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
             s.s_act = b.take((size_t)m * 256 * 2);
             s.u_act = b.take((size_t)m * 256 * 2);
             s.z = (float*)b.take((size_t)m * 2 * ch * 4);
-            long nb = m * ch / 1024;
-            s.nb = (int)(nb < 1 ? 1 : nb > 256 ? 256 : nb);
+            s.nb = fwn_tail_npartials((int)m);          // log-det partial slots of the flow's tail launch
             npart += s.nb;
         }
     }
@@ -365,39 +367,30 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         }
         for (int j = 0; j < NF; ++j) {
             const fwn_flow_desc* d = &md->flows[i * NF + j];
-            const fwn_flow_train_desc* td = &t->flows[i * NF + j];
             FlowSaved& s = saved[i * NF + j];
             s.p = p;
             float* xa = pl.planes + (size_t)p * plane_elems;
             float* xb = pl.planes + (size_t)(p ^ 1) * plane_elems;
             const void* ca = (const bf16*)pl.cplanes + (size_t)p * cplane_elems;
-            if (i == 0 && j == 0) fwn_ew_actnorm_fwd2(xa, xb, d->an, m * ch, ch, st);      // later flows: in the previous coupling kernel
-            fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, s.h[0], ch >= 32 ? pl.xhl : nullptr, (int)m, (int)ti, ch, d->kfpad, 0, nullptr, st);
+            // the inference kernels, keeping what the backward needs: the front conv applies the flow's ActNorm on the fly, the
+            // tail (skip sum -> final conv -> ZeroConv -> coupling + ActNorm of both planes, csrc/tail_chain.h) leaves
+            // y_a / out_b in the planes - the state the backward starts from - and writes S, U and Z on its way
+            fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, s.h[0], ch >= 32 ? pl.xhl : nullptr, (int)m, (int)ti, ch, d->kfpad, 1, nullptr, st);
             for (int l = 0; l < L; ++l) {
                 const float* Pl = hoist ? pl.P + ((size_t)j * L + l) * m * 512 : nullptr;
                 fwn_launch_gate(s.h[l], hoist ? nullptr : ca, Pl, d->Wd[l], d->Wc[l], d->bgate[l], s.o[l], (int)m, (int)ti, dilation_of(l), d->cin,
                                 d->kcpad, s.aux[l], st);
                 if (l + 1 < L) fwn_launch_res(s.o[l], s.h[l], d->Wres[l], d->bres[l], s.h[l + 1], (int)m, nullptr, st);
             }
-            {   // the tail un-fused: skip -> final -> ZeroConv as three GEMMs (s, u, Z are needed by the backward)
-                Seg segs[FWN_MAX_LAYERS];
-                for (int l = 0; l < L; ++l) segs[l] = {s.o[l], m, 256, 256, 0, l * 256};
-                fwn_gemm_desc g = gemm_desc(segs, L, td->Wskip, L * 256, 256, m, 0, s.s_act, 256, false);
-                g.bias = td->bskip; g.relu = 1;
-                fwn_gemm_launch(&g, st);
-                Seg s1{s.s_act, m, 256, 256, 0, 0};
-                g = gemm_desc(&s1, 1, td->Wfin, 256, 256, m, 0, s.u_act, 256, false);
-                g.bias = td->bfin; g.relu = 1;
-                fwn_gemm_launch(&g, st);
-                Seg s2{s.u_act, m, 256, 256, 0, 0};
-                g = gemm_desc(&s2, 1, td->Wz, 256, 2 * ch, m, 0, s.z, 2 * ch, true);
-                g.bias = td->bz;
-                fwn_gemm_launch(&g, st);
-            }
-            {   // the coupling, and the next flow's ActNorm of both planes with it
-                const bool last = i == md->n_block - 1 && j == NF - 1;
-                const fwn_flow_desc* dn = last ? nullptr : &md->flows[i * NF + j + 1];
-                fwn_ew_coupling_fwd_ex(xb, s.z, td->ez, m * ch, ch, s.part, s.nb, dn ? dn->an : nullptr, j == NF - 1 ? 2 * ch : ch, xa, st);
+            {
+                const long o_stride = L > 1 ? (long)(((const char*)s.o[1] - (const char*)s.o[0]) / 2) : 0;
+                for (int l = 1; l < L; ++l)
+                    TREQUIRE((const char*)s.o[l] == (const char*)s.o[0] + (size_t)l * o_stride * 2, "fwn_train_loss_and_grads: o buffers not evenly spaced");
+                fwn_tail_chain tc;
+                memset(&tc, 0, sizeof(tc));
+                tc.save_s = s.s_act; tc.save_u = s.u_act; tc.save_z = s.z;
+                fwn_launch_tail(s.o[0], o_stride, L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero, d->ezero, d->an, xa, xb, s.part,
+                                (int)m, ch, d->npt, 0, nullptr, nullptr, &tc, st);
             }
             p ^= 1;
         }

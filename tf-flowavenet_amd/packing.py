@@ -120,11 +120,14 @@ def zero_src_n(block: int) -> np.ndarray:
 
 
 def acc_k_perm(k: int = FILTER) -> np.ndarray:
-    """K order of the weights whose activation operand comes straight out of an MFMA
-    accumulator (tail kernel, phases 2 and 3).  A 32x32 fp32 accumulator tile converted to
+    """Row order of the weights whose OUTPUT feeds the next MFMA chain straight from the accumulator
+    registers (tail kernel: skip sum -> final conv -> ZeroConv).  A 32x32 fp32 accumulator tile converted to
     bf16 serves as the B operand of the next v_mfma_f32_32x32x16_bf16 with element j of lane
-    half h of k-step s holding tile row 16s + 8(j>>2) + 4h + (j&3); the matching A-operand
-    fragment is 8 contiguous packed columns k' = tile*32 + s*16 + h*8 + j."""
+    half h of k-step s holding tile row 16s + 8(j>>2) + 4h + (j&3); the next A-operand
+    fragment is 8 contiguous packed columns k' = tile*32 + s*16 + h*8 + j.  Packing output channel
+    acc_k_perm(n') (= n' with bits 2 and 3 swapped, an involution) into weight row n' makes those 8 register
+    elements 8 CONSECUTIVE channels: S = ReLU(skip sum) and U = ReLU(final conv) exist in natural channel order
+    (K axes of Wfinal / Wzero natural; the copies of S and U the training step keeps are natural too)."""
     kp = np.arange(k)
     s, h, j = (kp >> 4) & 1, (kp >> 3) & 1, kp & 7
     return ((kp & ~31) + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)).astype(np.int32)
@@ -421,6 +424,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
     ident256 = dev_i32("id256", lambda: np.arange(FILTER))
     ident768 = dev_i32("id768", lambda: np.arange(3 * FILTER))
     accperm = dev_i32("accperm", lambda: acc_k_perm(FILTER))
+    accperm_host = acc_k_perm(FILTER).astype(np.int64)
     fg, gch = gate_row_channel()
     gate_rows = [dev_i32("gate_rows%d" % s, lambda s=s: np.where(fg == s, gch, -1)) for s in (0, 1)]
     scale_buf = torch.empty(FILTER, dtype=torch.float32, device=dev)
@@ -559,20 +563,21 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                     d.Wres[l] = wr.data_ptr()
                     put(lambda v, d=d, l=l: d.bres.__setitem__(l, v.data_ptr()), lambda rp=rp: hostp[rp + "/res_conv/bias"],
                         dict(terms=[(rp + "/res_conv/bias", np.arange(FILTER))]))
-                pack(rp + "/skip_conv", ident256, ident256, FILTER, FILTER, wskip, L * FILTER, col_off=l * FILTER)
+                # rows (output channels) in accumulator order: S leaves the tail's MFMA chain in natural channel order
+                pack(rp + "/skip_conv", ident256, accperm, FILTER, FILTER, wskip, L * FILTER, col_off=l * FILTER)
             d.Wskip = wskip.data_ptr()
             put(lambda v, d=d: setattr(d, "bskip", v.data_ptr()),
-                lambda wp=wp: sum(np.asarray(hostp["%s/ResBlock_%d/skip_conv/bias" % (wp, l)], np.float64) for l in range(L)),
-                dict(terms=[("%s/ResBlock_%d/skip_conv/bias" % (wp, l), np.arange(FILTER)) for l in range(L)]))
+                lambda wp=wp: sum(np.asarray(hostp["%s/ResBlock_%d/skip_conv/bias" % (wp, l)], np.float64).reshape(-1) for l in range(L))[accperm_host],
+                dict(terms=[("%s/ResBlock_%d/skip_conv/bias" % (wp, l), accperm_host) for l in range(L)]))
 
             wfin = bf16_zeros(FILTER, FILTER)
-            pack(wp + "/Conv_final", accperm, ident256, FILTER, FILTER, wfin, FILTER)
+            pack(wp + "/Conv_final", ident256, accperm, FILTER, FILTER, wfin, FILTER)
             d.Wfinal = wfin.data_ptr()
-            put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), lambda wp=wp: hostp[wp + "/Conv_final/bias"],
-                dict(terms=[(wp + "/Conv_final/bias", np.arange(FILTER))]))
+            put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), lambda wp=wp: np.asarray(hostp[wp + "/Conv_final/bias"]).reshape(-1)[accperm_host],
+                dict(terms=[(wp + "/Conv_final/bias", accperm_host)]))
 
             wz = bf16_zeros(npt * 64, FILTER)
-            pack(wp + "/ZeroConv1d", accperm, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
+            pack(wp + "/ZeroConv1d", ident256, z_src_n, FILTER, npt * 64, wz, FILTER, weight_norm=False)
             def zero_tables(which, wp=wp, zsn_host=zsn_host, npt=npt):
                 valid = zsn_host >= 0
                 if which == 0:

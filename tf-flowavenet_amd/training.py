@@ -359,7 +359,6 @@ class _TrainPack:
         for tap in range(3):
             job(wp + "/Conv_front", self._i32(("fk", i, tap), fk[tap * ch:(tap + 1) * ch]), ch, id256, 256, t["WfT"], tap * 256, True)
         t["WdT"], t["WcT"], t["WresT"], t["WskipT"] = [], [], [], []
-        t["Wskip"] = bz(256, L * 256)
         for l in range(L):
             rp = "%s/ResBlock_%d" % (wp, l)
             wdt = bz(256, 1536)
@@ -377,14 +376,13 @@ class _TrainPack:
                 wrt = bz(256, 256)
                 job(rp + "/res_conv", id256, 256, id256, 256, wrt, 0, True)
                 t["WresT"].append(wrt)
-            job(rp + "/skip_conv", id256, 256, id256, 256, t["Wskip"], l * 256, False)
             if l == 0:
                 t["WskipT_all"] = bz(L * 256, 256)              # the L transposed skip convs stacked along N: one GEMM for all do_l
             wst = t["WskipT_all"][l * 256:(l + 1) * 256]
             job(rp + "/skip_conv", id256, 256, id256, 256, wst, 0, True)
             t["WskipT"].append(wst)
-        t["Wfin"], t["WfinT"] = bz(256, 256), bz(256, 256)
-        job(wp + "/Conv_final", id256, 256, id256, 256, t["Wfin"], 0, False)
+        # (the forward half runs the inference tail on the inference packing: no natural-order Wskip / Wfin / Wz copies)
+        t["WfinT"] = bz(256, 256)
         job(wp + "/Conv_final", id256, 256, id256, 256, t["WfinT"], 0, True)
         zcol = np.concatenate([br, ch + br])
         t["zcol"] = self._i64(("zcol", i), zcol)
@@ -392,8 +390,7 @@ class _TrainPack:
         zc32 = self._i32(("zcol", i), zcol)
         n2 = 2 * ch
         t["ldz"] = max(8, n2)
-        t["Wz"], t["WzT"] = bz(n2, 256), bz(256, t["ldz"])
-        job(wp + "/ZeroConv1d", id256, 256, zc32, n2, t["Wz"], 0, False, weight_norm=False)
+        t["WzT"] = bz(256, t["ldz"])
         job(wp + "/ZeroConv1d", id256, 256, zc32, n2, t["WzT"], 0, True, weight_norm=False)
         return t
 
@@ -456,7 +453,6 @@ class _TrainPack:
         wft = transpose_shift(wf, 256, 3 * ch, ld_dst=256)                      # [3Ch][256]
         t["WfT"] = wft.view(3, ch, 256).permute(1, 0, 2).reshape(ch, 768).contiguous()       # [Ch][tap*256 + n]
         t["Wd"], t["WdT"], t["Wc"], t["WcT"], t["WresT"], t["WskipT"] = [], [], [], [], [], []
-        wskip = bz(256, L * 256)
         for l in range(L):
             rp = "%s/ResBlock_%d" % (wp, l)
             wd = bz(512, 768)
@@ -477,13 +473,11 @@ class _TrainPack:
                 t["WresT"].append(transpose_shift(wr, 256, 256, ld_dst=256))
             ws = bz(256, 256)
             self._pack(rp + "/skip_conv", id256, id256, 256, 256, ws)
-            wskip[:, l * 256:(l + 1) * 256] = ws
             t["WskipT"].append(transpose_shift(ws, 256, 256, ld_dst=256))
-        t["Wskip"] = wskip
         t["WskipT_all"] = torch.cat(t["WskipT"], 0).contiguous()
         wfin = bz(256, 256)
         self._pack(wp + "/Conv_final", id256, id256, 256, 256, wfin)
-        t["Wfin"], t["WfinT"] = wfin, transpose_shift(wfin, 256, 256, ld_dst=256)
+        t["WfinT"] = transpose_shift(wfin, 256, 256, ld_dst=256)
         # ZeroConv rows in plane order: row fg*Ch + tau serves logical channel fg*Ch + bitrev(tau)
         zcol = np.concatenate([br, ch + br])
         t["zcol"] = self._i64(("zcol", i), zcol)
@@ -492,7 +486,6 @@ class _TrainPack:
         ldz = max(8, n2)
         wz = bz(n2, 256)
         self._pack(wp + "/ZeroConv1d", id256, self._i32(("zcol", i), zcol), 256, n2, wz, weight_norm=False)
-        t["Wz"] = wz
         t["WzT"] = transpose_shift(wz, n2, 256, ld_dst=packing.roundup(n2, 64))[:, :ldz].contiguous()   # [256][ldz], zero padded
         t["ldz"] = ldz
         return t
@@ -615,8 +608,8 @@ class GradEngine:
                     f, t = flows[i * hp.n_flow + j], tp.flows[(i, j)]
                     fp = weights.flow_prefix(i, j)
                     wp = fp + "/WaveNet"
-                    f.WfT, f.Wskip, f.WskipT_all = ptr(t["WfT"]), ptr(t["Wskip"]), ptr(t["WskipT_all"])
-                    f.Wfin, f.WfinT, f.Wz, f.WzT, f.ldz = ptr(t["Wfin"]), ptr(t["WfinT"]), ptr(t["Wz"]), ptr(t["WzT"]), int(t["ldz"])
+                    f.WfT, f.WskipT_all = ptr(t["WfT"]), ptr(t["WskipT_all"])
+                    f.WfinT, f.WzT, f.ldz = ptr(t["WfinT"]), ptr(t["WzT"]), int(t["ldz"])
                     f.wct_ld = int(t["WcT_all"].stride(0))
                     for l in range(L):
                         rp = "%s/ResBlock_%d" % (wp, l)
