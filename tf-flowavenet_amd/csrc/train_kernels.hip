@@ -48,20 +48,28 @@ struct LinProb {
     // With one column per lane the direct epilogue below issues up to 64 two- / four-byte VMEM instructions per lane and
     // operand (absent operands included: their zero-sized descriptors still cost the issue); the training GEMMs with 256-row
     // tiles spent more time there than in the K loop.  Same arithmetic in the same order: results are bit-identical.
-    // Needs 8-column groups that are whole and 16-byte aligned; the gate-derivative tiles keep the accumulator layout.
+    // Needs 8-column groups that are whole and 16-byte aligned.  The gate-derivative tiles (round 3) too: a lane's 8
+    // columns take their tanh / sigmoid factors as two 16-byte loads and leave as two 16-byte stores (the accumulator
+    // layout made the skip-gradient GEMM of block 0 a 49 us launch for 6.7 GFLOP).
     static constexpr bool LDS_EPI = true;
     __device__ bool rows_launch() const {
         const bool al = ((uintptr_t)g.Y & 15) == 0 && (!g.R || ((uintptr_t)g.R & 15) == 0) && (!g.mask || ((uintptr_t)g.mask & 15) == 0) &&
-                        (!g.bias || ((uintptr_t)g.bias & 15) == 0);
+                        (!g.bias || ((uintptr_t)g.bias & 15) == 0) &&
+                        (!g.gate_aux || ((((uintptr_t)g.gate_aux | (uintptr_t)g.gate_out) & 15) == 0 && !g.out_f32 && g.gate_col0 % 64 == 0));
         return al && g.N % 8 == 0 && g.ldy % 8 == 0 && (!g.R || g.ldr % 8 == 0) && (!g.mask || g.ldmask % 8 == 0) &&
                (!g.out_f32 || (size_t)g.split_stride % 4 == 0);
     }
-    __device__ bool rows_tile(int ncol0) const {
-        const int c0 = ncol0 - g.gate_col0;
-        return !(g.gate_aux && c0 >= 0 && c0 < 256);
-    }
+    __device__ bool rows_tile(int) const { return true; }
     template <int MI>
     __device__ void epilogue_rows(const float* wt, int mrow0, int ncol0, int lane) const {
+        // the 64 columns of a wave tile lie inside or outside the gated range together (gate_col0 is a multiple of 64); two
+        // instances of the body so that the registers of either (fp32 accumulate | gate factors) do not add up
+        const int c0 = ncol0 - g.gate_col0;
+        if (g.gate_aux && c0 >= 0 && c0 < 256) rows_body<MI, true>(wt, mrow0, ncol0, lane);
+        else rows_body<MI, false>(wt, mrow0, ncol0, lane);
+    }
+    template <int MI, bool GATED>
+    __device__ __forceinline__ void rows_body(const float* wt, int mrow0, int ncol0, int lane) const {
         const int col = ncol0 + (lane & 7) * 8;
         const bool cok = col < g.N;                              // the whole group of 8 (N % 8 == 0)
         const int cc = cok ? col : 0;                            // clamped: loads stay inside, stores of such lanes are dropped
@@ -73,13 +81,15 @@ struct LinProb {
 #pragma unroll
             for (int e = 0; e < 8; ++e) bb[e] = 0.0f;
         }
-        const bool relu_on = g.relu != 0, acc_on = g.out_f32 && g.accumulate;
+        const bool relu_on = g.relu != 0, acc_on = !GATED && g.out_f32 && g.accumulate;
+        constexpr bool gated = GATED;
+        const int gc = ncol0 - g.gate_col0 + (lane & 7) * 8;     // column inside the gate's 256 channels
         const float mdef = g.mask ? 0.0f : 1.0f;
         const uint32_t ybytes = (uint32_t)((size_t)g.M * g.ldy * (g.out_f32 ? 4 : 2));
         const srd_t sY = make_srd(g.out_f32 ? (const void*)y32 : (const void*)g.Y, ybytes);
         constexpr int NIT = 4 * MI;
-        Pack16 rv[NIT], mv[NIT];
-        float4 ya[NIT][2];
+        Pack16 rv[NIT], mv[NIT], tfv[GATED ? NIT : 1], sgv[GATED ? NIT : 1];
+        float4 ya[GATED ? 1 : NIT][2];
         int rowc[NIT];
         bool ok[NIT];
 #pragma unroll
@@ -103,22 +113,38 @@ struct LinProb {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) mv[it].u = zero16();
         }
-        if (acc_on) {
+        if constexpr (GATED) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const float* yp = y32 + (size_t)rowc[it] * g.ldy + cc;
-                ya[it][0] = *(const float4*)yp;
-                ya[it][1] = *(const float4*)(yp + 4);
+                const bf16* ap = (const bf16*)g.gate_aux + (size_t)rowc[it] * 512 + (cok ? gc : 0);
+                tfv[it].u = *(const uint4*)ap;
+                sgv[it].u = *(const uint4*)(ap + 256);
             }
         } else {
+            if (acc_on) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) ya[it][0] = ya[it][1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int it = 0; it < NIT; ++it) {
+                    const float* yp = y32 + (size_t)rowc[it] * g.ldy + cc;
+                    ya[it][0] = *(const float4*)yp;
+                    ya[it][1] = *(const float4*)(yp + 4);
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) ya[it][0] = ya[it][1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             float a[8], out[8];
             lds_epi_take(wt, it, lane, a);
-            const float yv[8] = {ya[it][0].x, ya[it][0].y, ya[it][0].z, ya[it][0].w, ya[it][1].x, ya[it][1].y, ya[it][1].z, ya[it][1].w};
+            float yv[8];
+            if constexpr (GATED) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) yv[e] = 0.0f;
+            } else {
+                yv[0] = ya[it][0].x; yv[1] = ya[it][0].y; yv[2] = ya[it][0].z; yv[3] = ya[it][0].w;
+                yv[4] = ya[it][1].x; yv[5] = ya[it][1].y; yv[6] = ya[it][1].z; yv[7] = ya[it][1].w;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = a[e] + bb[e] + g.rscale * (float)rv[it].e[e];
@@ -127,7 +153,7 @@ struct LinProb {
                 out[e] = v * g.oscale + yv[e];
             }
             const int row = mrow0 + it * 8 + (lane >> 3);
-            if (g.out_f32) {
+            if (!GATED && g.out_f32) {
                 const uint32_t voff = ok[it] ? (uint32_t)(row * g.ldy + col) * 4u : FWN_OOB;
                 const u32x4 o0 = {__builtin_bit_cast(unsigned int, out[0]), __builtin_bit_cast(unsigned int, out[1]),
                                   __builtin_bit_cast(unsigned int, out[2]), __builtin_bit_cast(unsigned int, out[3])};
@@ -135,6 +161,20 @@ struct LinProb {
                                   __builtin_bit_cast(unsigned int, out[6]), __builtin_bit_cast(unsigned int, out[7])};
                 __builtin_amdgcn_raw_buffer_store_b128(o0, sY, voff, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, sY, voff == FWN_OOB ? FWN_OOB : voff + 16u, 0, 0);
+            } else if constexpr (gated) {
+                // the gate's derivative instead of a store + fwn_gate_bwd: d (rounded to bf16 as it would have been stored)
+                // times the kept factors; same expressions as gate_bwd_kernel and the direct epilogue below
+                Pack16 of, og;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = (float)(bf16)out[e], tf = (float)tfv[it].e[e], sg = (float)sgv[it].e[e];
+                    of.e[e] = (bf16)(d * sg * (1.0f - tf * tf));
+                    og.e[e] = (bf16)(d * tf * sg * (1.0f - sg));
+                }
+                const srd_t sGo = make_srd(g.gate_out, (uint32_t)((size_t)g.M * 512 * 2));
+                const uint32_t vo = ok[it] ? (uint32_t)(row * 512 + gc) * 2u : FWN_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(of.w, sGo, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(og.w, sGo, vo, 512, 0);
             } else {
                 Pack16 o;
 #pragma unroll

@@ -10,5 +10,6 @@ cat $O/bench_train.json
 T=$(ls $O/rp/*/*kernel_trace.csv $O/rp/*kernel_trace.csv 2>/dev/null | head -1)
 python3 tools/kernel_summary.py $T 14 > $O/kernel_summary_train.txt
 python3 tools/diag/train_timeline.py $T > $O/timeline.txt 2>&1
+python3 tools/diag/train_blocks.py $T > $O/blocks.txt 2>&1
 rm -rf $O/rp
 head -50 $O/kernel_summary_train.txt
