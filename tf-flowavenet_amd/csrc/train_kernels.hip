@@ -1,6 +1,5 @@
 // Training-side primitives (work in progress): a generic
-// multi-segment GEMM on the LDS-DMA ring core, used for the un-fused training forward of the tail,
-// every data gradient (transposed packed weights, tap shifts with clip-edge masks, ReLU masks,
+// multi-segment GEMM on the LDS-DMA ring core, used for every data gradient (transposed packed weights, tap shifts with clip-edge masks, ReLU masks,
 // residual adds) and every weight gradient (transposed activation copies, K = rows, split over
 // workgroups into fp32 partials that a second pass sums in a fixed order).
 #include "common.h"

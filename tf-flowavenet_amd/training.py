@@ -261,7 +261,7 @@ class _TrainPack:
         self._small_tables()
 
     def _small_tables(self):
-        """Per-flow bias / scale vectors of the un-fused tail, in device channel order (parameter-sized).  With the
+        """Per-flow bias / scale vectors in device channel order (parameter-sized; the backward reads ez).  With the
         masters in one flat vector all flows are done by a handful of batched gathers (``_batched_tables``)."""
         import torch
         hp = self.hp
