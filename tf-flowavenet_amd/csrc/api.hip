@@ -58,7 +58,7 @@ int fwn_pack_jobs(const fwn_scale_job* scale_jobs, int n_scale_jobs, const fwn_p
                   float* scales, int scale_ld, void* stream) {
     REQUIRE(n_scale_jobs >= 0 && n_pack_jobs >= 0 && (n_scale_jobs == 0 || (scale_jobs && scales)) &&
                 (n_pack_jobs == 0 || pack_jobs) && scale_ld > 0 && scale_ld % 32 == 0, "fwn_pack_jobs: bad argument");
-    REQUIRE(n_scale_jobs < 65536 * 32 && n_pack_jobs < 65536 * 32, "fwn_pack_jobs: too many jobs");
+    REQUIRE(n_scale_jobs < 65536 * 32 && n_pack_jobs < 65536, "fwn_pack_jobs: too many jobs (the pack job index is gridDim.y)");
     fwn_launch_pack_jobs(scale_jobs, n_scale_jobs, pack_jobs, n_pack_jobs, scales, scale_ld, (hipStream_t)stream);
     return check_launch("fwn_pack_jobs");
 }

@@ -268,7 +268,10 @@ class PackPlan:
         for i, (v, g, k, n) in enumerate(self.sjobs):
             sj[i].v, sj[i].g, sj[i].k_src, sj[i].n_src = v, g, k, n
         pj = (_lib.PackJob * max(1, len(self.jobs)))()
-        for i, (v, sk, sn, out, ld, n_src, kd, nd, slot, tr, mul) in enumerate(self.jobs):
+        # jobs that read the same master back to back (stable sort: the jobs are independent of one another), so that the
+        # second reader finds it in the Infinity Cache (pack_jobs_kernel dispatches the jobs in table order)
+        order = sorted(range(len(self.jobs)), key=lambda i: self.jobs[i][0]) if os.environ.get("FWN_PACK_SORT", "1") != "0" else range(len(self.jobs))
+        for i, (v, sk, sn, out, ld, n_src, kd, nd, slot, tr, mul) in enumerate(self.jobs[k] for k in order):
             j = pj[i]
             j.v, j.src_k, j.src_n, j.out, j.ld_dst = v, sk, sn, out, ld
             j.n_src, j.k_dst, j.n_dst, j.scale_slot, j.transposed, j.mul = n_src, kd, nd, slot, tr, mul
