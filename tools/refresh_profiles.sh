@@ -32,5 +32,6 @@ cp $(ls $O/rocprof_train/*/*kernel_stats.csv $O/rocprof_train/*kernel_stats.csv 
 TT=$(ls $O/rocprof_train/*/*kernel_trace.csv $O/rocprof_train/*kernel_trace.csv 2>/dev/null | head -1)
 python3 tools/kernel_summary.py $TT 14 > $O/${TAG}_kernel_summary_train.txt
 python3 tools/diag/train_timeline.py $TT > $O/${TAG}_train_timeline.txt 2>&1
+python3 tools/diag/train_blocks.py $TT > $O/${TAG}_train_blocks.txt 2>&1
 rm -rf $O/rocprof $O/rocprof_train
 ls -la $O
