@@ -361,6 +361,56 @@ def test_conditioning_split_k_equals_the_one_pass_projection(full_model, blk, m)
     assert lib.fwn_cond_split(ca.data_ptr(), d0.Wc[0], P1.data_ptr(), 512 * kc, m * 512, 0, 1, nf, L, m, cin, kc, None, 0, 4, st) == -1
 
 
+@pytest.mark.parametrize("blk,m", [(0, 50000), (0, 13000), (6, 13000), (7, 12500), (2, 7000), (7, 7000), (3, 2000), (5, 700), (6, 300), (7, 150)])
+def test_tail_train_keeps_s_u_z_and_equals_the_plain_tail(full_model, blk, m):
+    """fwn_tail_train (the tail as the training step's forward half runs it) at every tail variant - 256-row and 128-row
+    register-chained kernel, N-split + chained kernel, three ring GEMMs; 1, 2 and 4 ZeroConv pair tiles: the planes and the
+    log-det partials are the bits fwn_tail gives, and what it keeps for the backward matches fp64 arithmetic on the
+    reference's weights (modules.py:175-180,51-56): S = ReLU(sum_l skip_l(o_l)), U = ReLU(final(S)), Z = ZeroConv(U) before
+    its exp(3 scale) factor, columns = (log_s | t) in plane channel order."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    L, ch = hp.n_layer, 1 << blk
+    d = model._packed.flow_descs[blk * hp.n_flow]
+    p64 = onp.to_f64(W.synthetic_params(hp, 1234))
+    wp = W.flow_prefix(blk, 0) + "/WaveNet"
+    rng = np.random.default_rng(blk * 1000 + m)
+    o = torch.from_numpy((rng.random((L, m, 256)) * 0.8).astype(np.float32)).cuda().to(torch.bfloat16)
+    planes = torch.from_numpy(rng.standard_normal((2, m, ch)).astype(np.float32)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    npart = lib.fwn_tail_partials(m)
+    pa, pb = planes.clone(), planes.clone()
+    part_a, part_b = torch.zeros(npart, device="cuda"), torch.zeros(npart, device="cuda")
+    scratch = torch.empty(2, m, 256, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.fwn_tail(C.byref(d), o.data_ptr(), pa[0].data_ptr(), pa[1].data_ptr(), part_a.data_ptr(), m, 0, scratch.data_ptr(), st), "fwn_tail")
+    S = torch.full((m, 256), float("nan"), device="cuda", dtype=torch.bfloat16)
+    U = torch.full((m, 256), float("nan"), device="cuda", dtype=torch.bfloat16)
+    Z = torch.full((m, 2 * ch), float("nan"), device="cuda", dtype=torch.float32)
+    _lib.check(lib.fwn_tail_train(C.byref(d), o.data_ptr(), m * 256, pb[0].data_ptr(), pb[1].data_ptr(), part_b.data_ptr(), m,
+                                  S.data_ptr(), U.data_ptr(), Z.data_ptr(), st), "fwn_tail_train")
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(part_a, part_b)
+    o64 = o.float().cpu().numpy().astype(np.float64)
+    s_ref = sum(onp.conv1x1(p64, "%s/ResBlock_%d/skip_conv" % (wp, l), o64[l][None])[0] for l in range(L))
+    s_ref = np.maximum(s_ref, 0.0)
+    s_dev = S.float().cpu().numpy().astype(np.float64)
+    # bf16 weights and a bf16 output of magnitude ~10: half an output ulp is 3e-2
+    err = np.abs(s_dev - s_ref)
+    assert err.max() < 1.5e-2 * max(1.0, np.abs(s_ref).max()) and err.mean() < 2e-3 * max(1.0, np.abs(s_ref).mean()), (err.max(), err.mean())
+    u_ref = np.maximum(onp.conv1x1(p64, wp + "/Conv_final", s_dev[None])[0], 0.0)
+    u_dev = U.float().cpu().numpy().astype(np.float64)
+    err = np.abs(u_dev - u_ref)
+    assert err.max() < 1.5e-2 * max(1.0, np.abs(u_ref).max()) and err.mean() < 2e-3 * max(1.0, np.abs(u_ref).mean()), (err.max(), err.mean())
+    z_log = onp.conv1x1(p64, wp + "/ZeroConv1d", u_dev[None], weight_norm=False)[0]          # logical channels: log_s (Ch), t (Ch)
+    br = packing.bitrev_table(blk).astype(np.int64)
+    z_ref = z_log[:, np.concatenate([br, ch + br])]
+    err = np.abs(Z.cpu().numpy().astype(np.float64) - z_ref)
+    assert err.max() < 5e-3 * max(1.0, np.abs(z_ref).max()), (err.max(), np.abs(z_ref).max())
+    # and the entry point checks its arguments
+    assert lib.fwn_tail_train(C.byref(d), o.data_ptr(), m * 256, pb[0].data_ptr(), pb[1].data_ptr(), part_b.data_ptr(), m,
+                              None, U.data_ptr(), Z.data_ptr(), st) == -1
+
+
 FLOW_CASES = [(0, 13, 1000), (0, 26, 1000), (1, 7, 1000), (3, 9, 700), (5, 4, 200), (7, 3, 70)]
 
 
