@@ -49,6 +49,13 @@ for b in range(nb - 1, -1, -1):
     print("          %5d  %8.3f  %13.1f  %10.1f  %6.1f %6.1f" % (b, ms(s), (e - s) / 1e3, (e - s) / 1e3 / NF, tnb, wnb))
 last_sg = step[sg[-1]]["e"]
 print("after the chain (joins, up-sampling backward, norm, Adam): %.3f .. %.3f ms" % (ms(last_sg), ms(step[-1]["e"])))
+print("after the last chain (weight-gradient kernels of the last blocks left out):")
+for r in step[sg[-1] + 1:]:
+    if not r["n"].startswith(side_names):
+        print("   %8.3f ms  %6.1f us  grid %8s  %s" % (ms(r["s"]), (r["e"] - r["s"]) / 1e3, r["Grid_Size_X"], r["n"][:70]))
+print("before the forward pass:")
+for r in step[:first_fwd]:
+    print("   %8.3f ms  %6.1f us  grid %8s  %s" % (ms(r["s"]), (r["e"] - r["s"]) / 1e3, r["Grid_Size_X"], r["n"][:70]))
 # one flow of block 0 and one of the last block: the chain's launches
 for k, name in [(nflow - 1 - b * NF, "backward, block %d, last flow processed" % b) for b in range(nb)]:
     i0 = cb[k]
