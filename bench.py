@@ -178,6 +178,20 @@ def path_roofline(hp, b, t, fwd_s, inv_s):
     return out
 
 
+def _median_pass_s(fn, iters):
+    """Median duration (s) of `iters` calls of fn, each between its own pair of HIP events on the launch stream (a secondary
+    leg of a few passes: one slow pass - a clock dip - must not move the figure the way it moves a mean)."""
+    import torch
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return ts[len(ts) // 2] * 1e-3
+
+
 def latency_b1(model, hp, t, dev, iters=10):
     """configs[1] at the latency shape: ONE 16128-sample clip, forward and inverse, HIP events on the launch stream."""
     import torch
@@ -188,13 +202,7 @@ def latency_b1(model, hp, t, dev, iters=10):
     def timed(fn):
         for _ in range(3):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e-3 / iters
+        return _median_pass_s(fn, iters)
 
     fwd, inv = timed(lambda: model.forward(x, c)), timed(lambda: model.reverse(z, c))
     flop = flop_per_sample(hp) * t
@@ -203,7 +211,7 @@ def latency_b1(model, hp, t, dev, iters=10):
             "fwd_mfma_frac": flop / fwd / 1e12 / MFMA_PEAK_TFLOPS, "inv_mfma_frac": flop / inv / 1e12 / MFMA_PEAK_TFLOPS,
             "survey_bound_us": bound, "fwd_frac_of_survey_bound": bound * 1e-6 / fwd if bound else None,
             "inv_frac_of_survey_bound": bound * 1e-6 / inv if bound else None,
-            "realtime_factor_inverse": t / inv / hp.sample_rate}
+            "realtime_factor_inverse": t / inv / hp.sample_rate, "timing": "median of %d passes, one HIP event pair each" % iters}
 
 
 def gate_source_hash():
@@ -230,7 +238,7 @@ def gate_traffic(rows):
     return None, "no PMC profile of the current kernel sources (hash %s) under profiles/" % gate_source_hash()
 
 
-def rtf_10s(model, hp, dev, world, iters=5):
+def rtf_10s(model, hp, dev, world, iters=7):
     """BASELINE configs[3]: inverse synthesis of a 10 s clip @ 22.05 kHz (T = 220672 = 862 frames), one clip per GPU
     (the batch shard of the 8-clip job), HIP events on the launch stream."""
     import torch
@@ -241,18 +249,14 @@ def rtf_10s(model, hp, dev, world, iters=5):
     for _ in range(2):
         wav = model.reverse(z, c)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        wav = model.reverse(z, c)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    out = []
+    sec = _median_pass_s(lambda: out.__setitem__(slice(None), [model.reverse(z, c)]), iters)
+    wav = out[0]
     assert bool(torch.isfinite(wav).all())
     audio_s = t / hp.sample_rate
     bound = BOUND_US.get("B1_T%d" % t)
     return {"workload": "configs[3]: inverse synthesis, one %.3f s clip (T=%d) per GPU, B=1" % (audio_s, t),
-            "inverse_ms": sec * 1e3, "rtf_per_gpu": audio_s / sec, "rtf_whole_job": world * audio_s / sec,
+            "inverse_ms": sec * 1e3, "timing": "median of %d passes, one HIP event pair each" % iters, "rtf_per_gpu": audio_s / sec, "rtf_whole_job": world * audio_s / sec,
             "samples_per_s_whole_job": world * t / sec, "n_gpus": world,
             "mfma_frac": flop_per_sample(hp) * t / sec / 1e12 / MFMA_PEAK_TFLOPS,
             "survey_bound_us": bound, "frac_of_survey_bound": bound * 1e-6 / sec if bound else None}
