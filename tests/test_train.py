@@ -339,6 +339,53 @@ def test_an_exception_in_the_block_callback_stops_the_call_and_reaches_the_calle
             os.environ.pop("FWN_TRAIN_SIDE", None)
 
 
+@pytest.mark.parametrize("m,ch", [(700, 1), (333, 8), (65, 128)])
+def test_elementwise_stage_entry_points_match_numpy(m, ch):
+    """fwn_actnorm_apply2 / fwn_coupling_fwd / fwn_coupling_bwd (model.py:86-94,124-141; stage entry points of the C-ABI:
+    the C-sequenced step folds the first two into the inference tail since round 3) against fp64 numpy."""
+    from tf_flowavenet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(m + ch)
+    st = torch.cuda.current_stream().cuda_stream
+    an = rng.standard_normal((2, 4, ch)).astype(np.float32) * 0.3
+    an[:, 1] = np.exp(an[:, 1]); an[:, 2] = 1.0 / an[:, 1]
+    xa, xb = rng.standard_normal((m, ch)).astype(np.float32), rng.standard_normal((m, ch)).astype(np.float32)
+    dxa, dxb, dan = torch.from_numpy(xa).cuda(), torch.from_numpy(xb).cuda(), torch.from_numpy(an).cuda()
+    _lib.check(lib.fwn_actnorm_apply2(dxa.data_ptr(), dxb.data_ptr(), dan.data_ptr(), m * ch, ch, st), "fwn_actnorm_apply2")
+    ya = (xa.astype(np.float64) + an[0, 0]) * an[0, 1]
+    yb = (xb.astype(np.float64) + an[1, 0]) * an[1, 1]
+    assert np.abs(dxa.cpu().numpy() - ya).max() < 1e-5 and np.abs(dxb.cpu().numpy() - yb).max() < 1e-5
+    Z = (rng.standard_normal((m, 2 * ch)) * 0.3).astype(np.float32)
+    ez = np.exp(rng.standard_normal(2 * ch) * 0.1).astype(np.float32)
+    dZ, dez = torch.from_numpy(Z).cuda(), torch.from_numpy(ez).cuda()
+    nb = 3
+    part = torch.zeros(nb, device="cuda")
+    yb32 = dxb.clone()
+    _lib.check(lib.fwn_coupling_fwd(yb32.data_ptr(), dZ.data_ptr(), dez.data_ptr(), m, ch, part.data_ptr(), nb, st), "fwn_coupling_fwd")
+    ls, t = Z[:, :ch].astype(np.float64) * ez[:ch], Z[:, ch:].astype(np.float64) * ez[ch:]
+    ob = (dxb.cpu().numpy().astype(np.float64) - t) * np.exp(-ls)
+    assert np.abs(yb32.cpu().numpy() - ob).max() < 1e-5 * max(1.0, np.abs(ob).max())
+    assert abs(float(part.sum()) - float(-ls.sum())) < 1e-4 * max(1.0, np.abs(ls).sum())
+    # backward: from out_b back to y_b, dZ with the log-det term
+    g = rng.standard_normal((m, ch)).astype(np.float32)
+    dg = torch.from_numpy(g).cuda()
+    ldz = max(8, 2 * ch)
+    dz = torch.zeros(m, ldz, device="cuda", dtype=torch.bfloat16)
+    dzz = torch.zeros(m, 2 * ch, device="cuda")
+    cls = 1.0 / (2.0 * m * ch)
+    _lib.check(lib.fwn_coupling_bwd(dg.data_ptr(), yb32.data_ptr(), dZ.data_ptr(), dez.data_ptr(), m, ch, cls, dz.data_ptr(), ldz,
+                                    dzz.data_ptr(), st), "fwn_coupling_bwd")
+    torch.cuda.synchronize()
+    assert np.abs(yb32.cpu().numpy() - dxb.cpu().numpy()).max() < 2e-5 * max(1.0, np.abs(xb).max())       # out_b -> y_b again
+    e = np.exp(-ls)
+    dls, dt = -g * ob + cls, -g * e
+    want = np.concatenate([dls * ez[:ch], dt * ez[ch:]], 1)
+    got = dz.float().cpu().numpy()[:, :2 * ch]
+    assert np.abs(got - want).max() < 1e-2 * max(1.0, np.abs(want).max())                                 # bf16 output
+    assert np.abs(dg.cpu().numpy() - g * e).max() < 1e-5 * max(1.0, np.abs(g * e).max())
+    assert np.abs(dzz.cpu().numpy() - np.concatenate([dls * ls, dt * t], 1)).max() < 1e-4 * max(1.0, np.abs(dls * ls).max())
+
+
 def test_train_entry_point_rejects_bad_arguments_with_a_message():
     """fwn_train_loss_and_grads / fwn_train_workspace_bytes: argument errors come back as codes with fwn_last_error()
     set (workspace too small: FWN_ERR_WORKSPACE), nothing is launched, and the same descriptors still work afterwards."""

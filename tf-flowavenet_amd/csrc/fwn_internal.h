@@ -103,8 +103,6 @@ void fwn_ew_actnorm_fwd(float* x, const float* an, long n, int Ch, hipStream_t s
 void fwn_ew_actnorm_fwd2(float* xa, float* xb, const float* an2, long n, int Ch, hipStream_t st);
 void fwn_ew_coupling_fwd(float* yb, const float* Z, const float* ez, long n, int Ch, float* partial, int nblocks,
                          hipStream_t st);
-void fwn_ew_coupling_fwd_ex(float* yb, const float* Z, const float* ez, long n, int Ch, float* partial, int nblocks,
-                            const float* an_next, int Chn, float* ya, hipStream_t st);
 void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
                          int ldz, float* dzz, hipStream_t st);
 void fwn_ew_coupling_bwd_ex(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,

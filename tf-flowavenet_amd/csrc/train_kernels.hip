@@ -378,13 +378,10 @@ __global__ __launch_bounds__(256) void actnorm_fwd2_kernel(float* __restrict__ x
 // Z here is the ZeroConv output BEFORE its exp(3 scale) factor ez (modules.py:51-56): (log_s | t) = Z * ez.
 // coupling forward (model.py:124-141): out_b = (y_b - t) exp(-log_s), in place over y_b;
 // partial[block] = sum(-log_s) of the block's elements (fixed order).
-// an_next (optional): the NEXT flow's ActNorm table [2][4][Chn] - this flow's out_b plane is that flow's plane a, this
-// flow's y_a plane (ya) its plane b; both are normalised here, in place (one launch less per flow; Chn = Ch or, across a
-// squeeze, 2 Ch: the planes are the same memory, only the channel period changes).
+// (A stage entry point since round 3: the training forward runs the inference tail, whose epilogue holds the coupling.)
 __global__ __launch_bounds__(256) void coupling_fwd_kernel(float* __restrict__ yb, const float* __restrict__ Z,
                                                            const float* __restrict__ ez, long n, int Ch,
-                                                           float* __restrict__ partial, const float* __restrict__ an_next,
-                                                           int Chn, float* __restrict__ ya) {
+                                                           float* __restrict__ partial) {
     __shared__ float red[256];
     float acc = 0.0f;
     const long per = (n + gridDim.x - 1) / gridDim.x;
@@ -393,13 +390,7 @@ __global__ __launch_bounds__(256) void coupling_fwd_kernel(float* __restrict__ y
         const long m = i / Ch;
         const int c = (int)(i - m * Ch);
         const float ls = Z[m * 2 * Ch + c] * ez[c], t = Z[m * 2 * Ch + Ch + c] * ez[Ch + c];
-        float v = (yb[i] - t) * __expf(-ls);
-        if (an_next) {
-            const int cn = (int)(i & (Chn - 1));
-            v = (v + an_next[cn]) * an_next[Chn + cn];
-            ya[i] = (ya[i] + an_next[4 * Chn + cn]) * an_next[5 * Chn + cn];
-        }
-        yb[i] = v;
+        yb[i] = (yb[i] - t) * __expf(-ls);
         acc -= ls;
     }
     red[threadIdx.x] = acc;
@@ -786,12 +777,7 @@ void fwn_ew_actnorm_fwd2(float* xa, float* xb, const float* an2, long n, int Ch,
 }
 void fwn_ew_coupling_fwd(float* yb, const float* Z, const float* ez, long n, int Ch, float* partial, int nblocks,
                          hipStream_t st) {
-    hipLaunchKernelGGL(coupling_fwd_kernel, dim3(nblocks), dim3(256), 0, st, yb, Z, ez, n, Ch, partial, (const float*)nullptr, 0,
-                       (float*)nullptr);
-}
-void fwn_ew_coupling_fwd_ex(float* yb, const float* Z, const float* ez, long n, int Ch, float* partial, int nblocks,
-                            const float* an_next, int Chn, float* ya, hipStream_t st) {
-    hipLaunchKernelGGL(coupling_fwd_kernel, dim3(nblocks), dim3(256), 0, st, yb, Z, ez, n, Ch, partial, an_next, Chn, ya);
+    hipLaunchKernelGGL(coupling_fwd_kernel, dim3(nblocks), dim3(256), 0, st, yb, Z, ez, n, Ch, partial);
 }
 void fwn_ew_coupling_bwd(float* g, float* ob, const float* Z, const float* ez, long n, int Ch, float cls, void* dZ,
                          int ldz, float* dzz, hipStream_t st) {
