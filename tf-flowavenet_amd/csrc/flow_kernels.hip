@@ -256,7 +256,10 @@ __global__ __launch_bounds__(256) void front_mfma_kernel(const float* __restrict
     constexpr int RB = 4 * CH;                      // image row bytes: (hi | lo) x CH bf16
     constexpr int NR = 66, ZROW = 66;               // rows m0 - 1 .. m0 + 64, then one row of zeros
     constexpr int CPT = 2 * CH / 64;                // 64-wide K chunks per tap
-    constexpr int NQ = 3 * CPT, D = 4;
+    // every weight chunk of the workgroup's 64 output rows in flight from the prologue on (8 KB each, 96 KB for CH = 128:
+    // the LDS is this workgroup's alone anyway, FWN_FRONT_LDS_MIN): one DMA latency for the whole slice instead of one per
+    // three chunks - at a handful of workgroups per launch the K loop is nothing but that latency chain
+    constexpr int NQ = 3 * CPT, D = NQ + 1;
     constexpr int A_BYTES = (NR + 1) * RB, B_SLOT = 64 * 128;
     constexpr int LDS_USED = D * B_SLOT + A_BYTES;
     constexpr int LDS_BYTES = LDS_USED > FWN_FRONT_LDS_MIN ? LDS_USED : FWN_FRONT_LDS_MIN;
@@ -288,6 +291,12 @@ __global__ __launch_bounds__(256) void front_mfma_kernel(const float* __restrict
         if (q < NQ) issue(q);
     // the image: 4 channels of one row per task - fp32 in, ActNorm, (hi | lo) out
     constexpr int NTASK = (NR + 1) * (CH / 4), NIT = (NTASK + 255) / 256;
+    static_assert(256 % (CH / 4) == 0, "a thread's channel group is the same for all its tasks");
+    // (CH / 4 divides 256: every task of a thread has the same tau - its ActNorm shift / scale are loaded ONCE, together with
+    // the plane rows; looked up per task they were 9 dependent L2 round trips in front of the K loop at CH = 128)
+    const int tau_t = (tid % (CH / 4)) * 4;
+    const float4 an_sh = apply_an ? *(const float4*)(an + tau_t) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 an_sc = apply_an ? *(const float4*)(an + CH + tau_t) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     float4 vin[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {              // every load of the thread in flight at once (clamped addresses)
@@ -305,11 +314,11 @@ __global__ __launch_bounds__(256) void front_mfma_kernel(const float* __restrict
         const int g = m0 - 1 + j;
         const bool ok = j < NR && (unsigned)g < (unsigned)M;
         const float4 v = vin[it];
-        float f[4] = {v.x, v.y, v.z, v.w};
+        const float f[4] = {v.x, v.y, v.z, v.w}, sh[4] = {an_sh.x, an_sh.y, an_sh.z, an_sh.w}, sc[4] = {an_sc.x, an_sc.y, an_sc.z, an_sc.w};
         union { bf16 e[4]; uint2 u; } hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float y = apply_an ? (f[e] + an[tau + e]) * an[CH + tau + e] : f[e];
+            float y = apply_an ? (f[e] + sh[e]) * sc[e] : f[e];
             y = ok ? y : 0.0f;
             hi.e[e] = (bf16)y;
             lo.e[e] = (bf16)(y - (float)hi.e[e]);
@@ -336,14 +345,14 @@ __global__ __launch_bounds__(256) void front_mfma_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         // chunks issued so far: min(NQ, q + D - 1); those after q may stay in flight (2 pieces per wave and chunk)
-        const int pend = (NQ < q + D - 1 ? NQ : q + D - 1) - (q + 1);
-        if (pend >= 2) FWN_WAIT_VMCNT(4);
-        else if (pend == 1) FWN_WAIT_VMCNT(2);
-        else FWN_WAIT_VMCNT(0);
-        if (q == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image rows this wave wrote
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (q + D - 1 < NQ) issue(q + D - 1);
+        // every chunk was issued in the prologue and the image was built behind the plane loads, which were issued after
+        // them (vmcnt retires in order): ONE barrier makes all of it visible, the K loop runs without waits
+        if (q == 0) {
+            FWN_WAIT_VMCNT(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the image rows this wave wrote
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         const unsigned char* lb = lds + (q % D) * B_SLOT;
         const int tap = q / CPT, kc = q % CPT;
 #pragma unroll

@@ -49,6 +49,24 @@ struct RingGeom {
 #endif
 
 #define FWN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// n wave-uniform (run time): wait until at most n vector-memory operations are outstanding (waiting for fewer is safe)
+__device__ __forceinline__ void fwn_wait_vm_le(int n) {
+    // n wave-uniform: wait until at most n vector-memory operations are outstanding (waiting for fewer is safe)
+    if (n >= 48) FWN_WAIT_VMCNT(48);
+    else if (n >= 40) FWN_WAIT_VMCNT(40);
+    else if (n >= 32) FWN_WAIT_VMCNT(32);
+    else if (n >= 28) FWN_WAIT_VMCNT(28);
+    else if (n >= 24) FWN_WAIT_VMCNT(24);
+    else if (n >= 20) FWN_WAIT_VMCNT(20);
+    else if (n >= 16) FWN_WAIT_VMCNT(16);
+    else if (n >= 12) FWN_WAIT_VMCNT(12);
+    else if (n >= 8) FWN_WAIT_VMCNT(8);
+    else if (n >= 6) FWN_WAIT_VMCNT(6);
+    else if (n >= 4) FWN_WAIT_VMCNT(4);
+    else if (n >= 2) FWN_WAIT_VMCNT(2);
+    else if (n >= 1) FWN_WAIT_VMCNT(1);
+    else FWN_WAIT_VMCNT(0);
+}
 
 #ifdef FWN_STAMP      // tools/probe/lin_stamps.hip: s_memtime per wave of workgroup 0: [chunk][before wait | after wait | after barrier | after MFMAs]
 __device__ unsigned long long fwn_ring_stamps[16 * 64 * 4 + 64];

@@ -67,23 +67,6 @@ struct TailArgs {
     float* save_z;        // Z = U Wz + bz  [M][2 Ch]: log_s channels, then t channels, plane order
 };
 
-__device__ __forceinline__ void fwn_wait_vm_le(int n) {
-    // n wave-uniform: wait until at most n vector-memory operations are outstanding (waiting for fewer is safe)
-    if (n >= 48) FWN_WAIT_VMCNT(48);
-    else if (n >= 40) FWN_WAIT_VMCNT(40);
-    else if (n >= 32) FWN_WAIT_VMCNT(32);
-    else if (n >= 28) FWN_WAIT_VMCNT(28);
-    else if (n >= 24) FWN_WAIT_VMCNT(24);
-    else if (n >= 20) FWN_WAIT_VMCNT(20);
-    else if (n >= 16) FWN_WAIT_VMCNT(16);
-    else if (n >= 12) FWN_WAIT_VMCNT(12);
-    else if (n >= 8) FWN_WAIT_VMCNT(8);
-    else if (n >= 6) FWN_WAIT_VMCNT(6);
-    else if (n >= 4) FWN_WAIT_VMCNT(4);
-    else if (n >= 2) FWN_WAIT_VMCNT(2);
-    else if (n >= 1) FWN_WAIT_VMCNT(1);
-    else FWN_WAIT_VMCNT(0);
-}
 
 // NW waves x 32 rows per workgroup, D ring slots, BK1 = phase-1 chunk width, WDB = double-buffered weight fragments
 // (worth it at one wave per SIMD), NPT = ZeroConv pair tiles (Ch <= 32 NPT), HAS_P1 = the skip GEMM runs here.
