@@ -420,8 +420,33 @@ struct GateProb {
         return (uint32_t)(n * ldb + cc.bcol + c8 * 8) * 2u;
     }
     __device__ float acc_init(int col) const { return bias[col]; }   // packed-N order, like the columns
+    // gemm_ring.h PREFETCH (small tiles): the hoisted conditioning projection of this tile, filter then gate columns
+    static constexpr bool PREFETCH = true;
+    template <int MI>
+    __device__ void prefetch(float (&pre)[MI][32], int mrow0, int ncol0, int lane) const {
+        if (!P) return;
+        const srd_t sp = make_srd(P, (uint32_t)((size_t)M * 512 * 4));
+        const uint32_t vp = (uint32_t)((mrow0 + 4 * (lane >> 5)) * 512 + ncol0 + (lane & 31)) * 4u;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t sro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 4);
+                pre[mi][r] = buf_load_f32(sp, vp, sro);
+                pre[mi][16 + r] = buf_load_f32(sp, vp, sro + 128);
+            }
+    }
+    template <int MI>
+    __device__ void epilogue_pre(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
+        epilogue_impl<MI, true>(acc, mrow0, ncol0, lane, pre);
+    }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
+        const float none[MI][32] = {};
+        epilogue_impl<MI, false>(acc, mrow0, ncol0, lane, none);
+    }
+    template <int MI, bool PRE>
+    __device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
         // packed-N: ncol0 = nb*128 + wn*64; columns [ncol0, +32) = filter, [+32, +64) = gate of
         // channels nb*64 + wn*32 + lr.
         const int lr = lane & 31;
@@ -441,8 +466,8 @@ struct GateProb {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t sro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 4);
-                    pf[r] = P ? buf_load_f32(sp, vp, sro) : 0.0f;
-                    pg[r] = P ? buf_load_f32(sp, vp, sro + 128) : 0.0f;
+                    pf[r] = !P ? 0.0f : PRE ? pre[mi][r] : buf_load_f32(sp, vp, sro);
+                    pg[r] = !P ? 0.0f : PRE ? pre[mi][16 + r] : buf_load_f32(sp, vp, sro + 128);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -464,8 +489,8 @@ struct GateProb {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t sro = (uint32_t)((mi * 32 + acc_row_c(r)) * 512 * 4);
-                    pf[r] = buf_load_f32(sp, vp, sro);
-                    pg[r] = buf_load_f32(sp, vp, sro + 128);
+                    pf[r] = PRE ? pre[mi][r] : buf_load_f32(sp, vp, sro);
+                    pg[r] = PRE ? pre[mi][16 + r] : buf_load_f32(sp, vp, sro + 128);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
@@ -554,8 +579,32 @@ struct ResProb {
             }
         }
     }
+    // gemm_ring.h PREFETCH (small tiles): the residual rows of this tile
+    static constexpr bool PREFETCH = true;
+    template <int MI>
+    __device__ void prefetch(float (&pre)[MI][32], int mrow0, int ncol0, int lane) const {
+        const srd_t si = make_srd(hin, (uint32_t)((size_t)M * FWN_HID * 2));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const uint32_t voff = (uint32_t)((mrow0 + 4 * (lane >> 5)) * FWN_HID + ncol0 + ni * 32 + (lane & 31)) * 2u;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    pre[mi][ni * 16 + r] = buf_load_bf16(si, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2));
+        }
+    }
+    template <int MI>
+    __device__ void epilogue_pre(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
+        epilogue_impl<MI, true>(acc, mrow0, ncol0, lane, pre);
+    }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
+        const float none[MI][32] = {};
+        epilogue_impl<MI, false>(acc, mrow0, ncol0, lane, none);
+    }
+    template <int MI, bool PRE>
+    __device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
         const int lr = lane & 31;
         const uint32_t bytes = (uint32_t)((size_t)M * FWN_HID * 2);
         const srd_t si = make_srd(hin, bytes), so = make_srd(hout, bytes);
@@ -569,7 +618,7 @@ struct ResProb {
                 float hv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    hv[r] = buf_load_bf16(si, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2));
+                    hv[r] = PRE ? pre[mi][ni * 16 + r] : buf_load_bf16(si, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2));
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     buf_store_bf16(so, voff, (uint32_t)((mi * 32 + acc_row_c(r)) * FWN_HID * 2),
@@ -760,8 +809,34 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
         return (uint32_t)(n * FWN_HID + cc.k0 + c8 * 8) * 2u;
     }
     __device__ float acc_init(int col) const { return bz[col]; }     // ZeroConv bias: (acc + b) * exp(3 scale)
+    // gemm_ring.h PREFETCH (small tiles): the two planes' elements this lane transforms in place (no other lane touches them)
+    static constexpr bool PREFETCH = true;
+    template <int MI>
+    __device__ void prefetch(float (&pre)[MI][32], int mrow0, int ncol0, int lane) const {
+        const int tau = (ncol0 >> 6) * 32 + (lane & 31);
+        const uint32_t plane_bytes = (uint32_t)((size_t)M * Ch * 4);
+        const srd_t sxa = make_srd(xa, plane_bytes), sxb = make_srd(xb, plane_bytes);
+        const uint32_t voff = tau < Ch ? (uint32_t)((mrow0 + 4 * (lane >> 5)) * Ch + tau) * 4u : FWN_OOB;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t so = (uint32_t)((mi * 32 + acc_row_c(r)) * Ch * 4);
+                pre[mi][r] = buf_load_f32(sxb, voff, so);
+                pre[mi][16 + r] = buf_load_f32(sxa, voff, so);
+            }
+    }
+    template <int MI>
+    __device__ void epilogue_pre(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
+        epilogue_impl<MI, true>(acc, mrow0, ncol0, lane, pre);
+    }
     template <int MI>
     __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
+        const float none[MI][32] = {};
+        epilogue_impl<MI, false>(acc, mrow0, ncol0, lane, none);
+    }
+    template <int MI, bool PRE>
+    __device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
         const int lr = lane & 31, pt = ncol0 >> 6;
         const int tau = pt * 32 + lr;
         const bool chok = tau < Ch;
@@ -784,8 +859,8 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t so = (uint32_t)((mi * 32 + acc_row_c(r)) * Ch * 4);
-                xbv[r] = buf_load_f32(sxb, voff, so);
-                xav[r] = buf_load_f32(sxa, voff, so);
+                xbv[r] = PRE ? pre[mi][r] : buf_load_f32(sxb, voff, so);
+                xav[r] = PRE ? pre[mi][16 + r] : buf_load_f32(sxa, voff, so);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -95,6 +95,16 @@ __device__ __forceinline__ void wait_vmcnt_le(int pending_chunks) {
 template <class P, class = void> struct prob_lds_epi { static constexpr bool value = false; };
 template <class P> struct prob_lds_epi<P, decltype((void)P::LDS_EPI)> { static constexpr bool value = P::LDS_EPI; };
 
+// Small tiles (KSP > 1: launches of a handful of workgroups - latency chains from end to end): a problem that declares
+// PREFETCH requests the operands of its epilogue (hoisted conditioning projection, residual rows, flow state) right behind
+// the prologue DMAs, 32 floats per 32-row tile and lane, and gets them back in epilogue_pre(): their round trip runs under
+// the K loop instead of after it (~0.7 us of a 5 - 8 us launch).  Ordinary loads: they retire in issue order with the DMA
+// pieces, so the first ring wait also covers them (everything of the prologue lands together); the compiler's own wait
+// sits at their first use, after the loop.  Big tiles keep their loads in the epilogue: ahead of the K loop of an HBM-bound
+// launch they compete with its LDS-DMA stream (res layer of block 0: 21.0 -> 24.7 us).
+template <class P, class = void> struct prob_prefetch { static constexpr bool value = false; };
+template <class P> struct prob_prefetch<P, decltype((void)P::PREFETCH)> { static constexpr bool value = P::PREFETCH; };
+
 template <int MI>
 __device__ __forceinline__ void lds_epi_park(const f32x16 (&acc)[MI][2], float* wt, int lane) {
     const int lr = lane & 31, lh = lane >> 5;
@@ -208,6 +218,12 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = c0;
     }
 
+    constexpr bool PF = KSP > 1 && prob_prefetch<Prob>::value;
+    float pre[PF ? MI : 1][32];
+    if constexpr (PF) {
+        if (wk == 0) p.template prefetch<MI>(pre, m0 + wm * 32 * MI, n0 + wn * 64, lane);
+    }
+
     // context of the chunk the NEXT refill loads: looked up one iteration ahead (a problem whose chunk_ctx reads a
     // descriptor table - fwn_gemm's segments - then has its scalar loads in flight under the previous chunk's MFMAs)
     typename Prob::ChunkCtx ccn = p.template chunk_ctx<BK>(D - 1 < nq ? D - 1 : 0);
@@ -300,7 +316,9 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         return;
     }
     FWN_RING_STAMP_X(2);
-    if constexpr (prob_lds_epi<Prob>::value && KSP == 1 && NWV * 32 * MI * 64 * 4 <= D * SLOT) {
+    if constexpr (PF) {
+        p.template epilogue_pre<MI>(acc, m0 + wm * 32 * MI, n0 + wn * 64, lane, pre);
+    } else if constexpr (prob_lds_epi<Prob>::value && KSP == 1 && NWV * 32 * MI * 64 * 4 <= D * SLOT) {
         // Row-major epilogue through LDS (problems that declare LDS_EPI): the accumulator layout gives a lane ONE column of
         // 16 rows, so a direct epilogue moves 2 bytes per lane and instruction (32 loads + 32 stores per lane for a
         // residual layer).  Each wave parks its (32 MI) x 64 fp32 tile in the drained ring and takes it back as rows of
