@@ -470,6 +470,10 @@ def test_full_size_round_trip_and_determinism(full_model):
     xr = model.reverse(zf, c)
     assert float((xr - x).abs().max()) < 2e-2          # bf16 net inputs: not bit-exact across flows
     assert float((xr - x).abs().mean()) < 1e-3
+    # the reference's return type on request (model.py:356-357,396): the same samples, rounded once
+    xh = model.reverse(zf, c, dtype="hparams")
+    assert xh.dtype == {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32}[str(hp.dtype)]
+    assert torch.equal(xh, xr.to(xh.dtype)) and model.reverse(zf, c, dtype=torch.float16).dtype == torch.float16
     # clips are independent: clip 3 alone gives the same latent as clip 3 inside the batch
     _, _, z3 = model.forward(x[3:4], c[3:4], return_z=True)
     # (a single clip runs other tile shapes, whose fp32 summation order differs: bf16 rounding flips)

@@ -9,7 +9,8 @@ Differences that are deliberate (DESIGN.md "Deviations"):
   * ``hparams.dtype`` float16 -> bfloat16 hidden activations / weights with fp32
     accumulation; the flow state, ActNorm, coupling and all reductions stay fp32
     (the reference takes its means in fp16, model.py:135,343);
-  * ``reverse`` returns fp32 (the reference returns ``hparams.dtype``);
+  * ``reverse`` returns fp32 by default (the flow state is fp32 here); ``reverse(..., dtype="hparams")`` returns
+    ``hparams.dtype`` like the reference (model.py:356-357,396);
   * global (speaker) conditioning is inert in the reference (``WaveNet.__call__``
     drops ``g``, modules.py:188-189): ``g`` is validated like the reference does
     (model.py:320-321,353-354) and otherwise ignored;
@@ -182,17 +183,20 @@ class FloWaveNet:
             raise failure[0]
         _lib.check(rc, "fwn_model_forward_init")
 
-    def reverse(self, z, c, g=None):
-        """z [B,T,1], c [B,T/hop,num_mels] -> x [B,T,1] fp32 (model.py:350-396)."""
+    def reverse(self, z, c, g=None, dtype=None):
+        """z [B,T,1], c [B,T/hop,num_mels] -> x [B,T,1] (model.py:350-396).  fp32 unless ``dtype`` is given: a torch dtype, or
+        "hparams" for the reference's return type, ``hparams.dtype`` (float16 / bfloat16 / float32; model.py:356-357,396)."""
         import torch
         self._check_g(g)
+        if dtype == "hparams":
+            dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32}[str(self._hparams.dtype).replace("tf.", "")]
         b, t, z32, c32 = self._prep(z, c, "z")
         wsp, wsn = self._workspace(b, t)
         x = torch.empty(b, t, 1, dtype=torch.float32, device=self._device)
         rc = self._lib.fwn_model_reverse(C.byref(self._packed.model_desc), b, t, z32.data_ptr(), c32.data_ptr(),
                                          wsp, wsn, x.data_ptr(), self._stream())
         _lib.check(rc, "fwn_model_reverse")
-        return x
+        return x if dtype is None or dtype == torch.float32 else x.to(dtype)
 
     def upsample(self, c):
         """c [B,F,num_mels] -> [B,F*hop,num_mels] fp32 (model.py:398-404)."""
