@@ -259,11 +259,11 @@ def full_model():
 
 
 @pytest.mark.parametrize("layer", [0, 1])
-@pytest.mark.parametrize("b,ti", [(3, 100), (13, 1000), (26, 1000)])
+@pytest.mark.parametrize("b,ti", [(3, 100), (7, 1000), (13, 1000), (26, 1000)])
 def test_gate_stage_kernel_matches_oracle(full_model, b, ti, layer):
     """fwn_gate alone (block 0, flow 0; dilation 1 and 3) against the oracle's ResBlock gate
     (modules.py:113-124) on rows that straddle clip edges inside every tile: M = 300 runs the
-    plain ring tiles, 13000 the 256x128 and 26000 the 256x256 tap-sharing tiles (gate_halo.h)."""
+    plain ring tiles, 7000 the 128x128, 13000 the 256x128 and 26000 the 256x256 tap-sharing tiles (gate_halo.h)."""
     hp, model, _, _, _ = full_model
     lib = _lib.load()
     p64 = onp.to_f64(W.synthetic_params(hp, 1234))

@@ -1029,6 +1029,14 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
             hipLaunchKernelGGL((gate_halo_kernel<256, 128, GateProb>), dim3(t256 * 4), dim3(1024), 0, st, p, 4);
         return;
     }
+    // 128 x 128 tap-sharing tiles (8 waves, 66 KB of LDS: two workgroups per CU) where 256-row tiles would leave CUs empty
+    // but 128-row tiles still fill the chip: block 3 of the 8-clip pass (8064 rows) - the ring tile there stages the
+    // dilated taps three times (720 KB per workgroup against 593 KB) at one workgroup per CU
+    const int t128 = (M + 127) / 128;
+    if (dil <= FWN_HALO_MAXDIL && t128 * 4 >= 192 && FWN_TUNE(FWN_HALO128, 1)) {
+        hipLaunchKernelGGL((gate_halo_kernel<128, 128, GateProb>), dim3(t128 * 4), dim3(512), 0, st, p, 4);
+        return;
+    }
     launch_ring(p, M, 512, (768 + (ca ? kcpad : 0)) / 16, st);
 }
 
