@@ -507,12 +507,21 @@ __global__ __launch_bounds__(256) void flow_small_grads_kernel(float* __restrict
     for (long i = r0 * 2 * Ch + t; i < r1 * 2 * Ch; i += 256) sz += dzz[i];
     red[0][t] = s1a; red[1][t] = s2a; red[2][t] = s1b; red[3][t] = s2b; red[4][t] = sz;
     __syncthreads();
+    // thread k holds the sums of channel k mod Ch (k mod 2 Ch for the ZeroConv scale): fold the 256 entries down to one
+    // period by halving - a fixed order, and 8 steps where the early blocks (Ch = 1: one thread adding 256 doubles
+    // from LDS one after the other) spent 6 us of a 14 us launch on the flow's chain
+    for (int st = 128; st >= Ch; st >>= 1) {
+        if (t < st) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][t] += red[q][t + st];
+            if (st >= 2 * Ch) red[4][t] += red[4][t + st];
+        }
+        __syncthreads();
+    }
     double* o = partial + (size_t)blockIdx.x * 6 * Ch;
     for (int idx = t; idx < 6 * Ch; idx += 256) {
-        const int q = idx < 4 * Ch ? idx / Ch : 4, col = idx < 4 * Ch ? idx % Ch : idx - 4 * Ch, period = q < 4 ? Ch : 2 * Ch;
-        double a = 0.0;
-        for (int k = col; k < 256; k += period) a += red[q][k];
-        o[idx] = a;
+        const int q = idx < 4 * Ch ? idx / Ch : 4, col = idx < 4 * Ch ? idx % Ch : idx - 4 * Ch;
+        o[idx] = red[q][col];
     }
 }
 __global__ __launch_bounds__(256) void flow_small_grads_final_kernel(const double* __restrict__ partial, int nb, int Ch,
