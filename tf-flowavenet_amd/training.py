@@ -331,8 +331,7 @@ class _TrainPack:
         st = _stream(flat)
         _lib.check(lib.fwn_gather_tables(flat.data_ptr(), bt["idx"].data_ptr(), bt["L"], bt["total"], bt["post"].data_ptr(),
                                          bt["mode"].data_ptr(), bt["out"].data_ptr(), st), "fwn_gather_tables")
-        _lib.check(lib.fwn_sum_f32(bt["anp"].data_ptr(), bt["anp"].numel(), bt["an_logdet"].data_ptr(), st), "fwn_sum_f32")
-        self.an_logdet = bt["an_logdet"]
+        self.an_logdet = None       # (unused since the forward half runs the inference tail: its log-det partials carry the ActNorm terms)
 
     def _pack_flow_plan(self, i, j):
         """The backward's transposed / natural-order copies as jobs of the plan (transposed packing:
@@ -637,12 +636,10 @@ class GradEngine:
         else:
             td, flows = self._desc, self._desc_flows
         # per-step tables (recomputed from the masters before every step: their addresses may move)
-        an_ld = tp.an_logdet
-        if an_ld is None:       # host-packed parameters: sum over flows of mean_C(3 logs) from the packed ActNorm tables
-            an_ld = 0.0
-            for (i, j) in tp.flows:
-                an_ld = an_ld + tp.pm.an[(i, j)][:, 3, :].sum() / (2 << i)
-        an_ld = torch.as_tensor(an_ld, dtype=torch.float32, device=dev).reshape(1).contiguous()
+        # fwn_train_desc.an_logdet: unused by the library since round 3 (any device pointer)
+        an_ld = getattr(self, "_an_ld0", None)
+        if an_ld is None or an_ld.device != dev:
+            an_ld = self._an_ld0 = torch.zeros(1, dtype=torch.float32, device=dev)
         for i in range(hp.n_block):
             for j in range(hp.n_flow):
                 f, t = flows[i * hp.n_flow + j], tp.flows[(i, j)]

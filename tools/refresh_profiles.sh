@@ -21,6 +21,11 @@ python3 tools/pass_table.py $T --json $O/${TAG}_pass_table.json > $O/${TAG}_pass
 cp $O/${TAG}_pass_table.json $R/profiles/ 2>/dev/null
 cp $(ls $O/rocprof/*/*kernel_stats.csv $O/rocprof/*kernel_stats.csv 2>/dev/null | head -1) $O/${TAG}_rocprofv3_kernel_stats_B8.csv
 rm -f $T   # tens of MB; the stats CSV and the summary are what is kept
+# the same table for ONE clip (the latency shape: every block at its dependent-launch floor)
+(cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/rocprof_b1 -o ${TAG}b1 -- python3 $R/bench.py --no-cpu-baseline --serial --no-train --no-rtf --no-fp8 --no-latency --steps 12 --warmup 3 --batch 1 > $O/rocprof_b1.log 2>&1)
+T1=$(ls $O/rocprof_b1/*/*kernel_trace.csv $O/rocprof_b1/*kernel_trace.csv 2>/dev/null | head -1)
+python3 tools/pass_table.py $T1 --batch 1 > $O/${TAG}_pass_table_B1.txt
+rm -rf $O/rocprof_b1
 # the bench lines last: they quote the per-block table and the traffic figures collected above
 python3 bench.py > $O/${TAG}_bench_B8.json 2> $O/bench_B8.err
 python3 bench.py --no-cpu-baseline --serial --no-train --no-rtf --no-fp8 > $O/${TAG}_bench_B8_serial.json 2>> $O/bench_B8.err
