@@ -110,7 +110,8 @@ typedef struct fwn_flow_desc {
     int32_t npt;         /* ZeroConv pair tiles = max(1, ceil(Ch/32)) */
     int32_t L;           /* n_layer */
     const void* Wfront;  const float* bfront;               /* [256][kfpad], [256]            */
-    const void* Wfront2;                                    /* Ch >= 32 only, else NULL: [256][6*Ch], K = tap*2Ch + (hi|lo)*Ch + tau */
+    const void* Wfront2;                                    /* Ch >= 32: [256][6*Ch], K = tap*2Ch + (hi|lo)*Ch + tau; Ch = 16: the same
+                                                               with 32 channels per half, tau >= 16 zero ([256][192]); else NULL */
     /* Gate operands are stored pre-multiplied by the exponent scale of their nonlinearity: filter
      * rows by -2*log2(e), gate rows by -log2(e) (tanh(f)*sigmoid(g) from two exp2, packing.py GATE_MUL). */
     const void* Wd[FWN_MAX_LAYERS];                         /* [512][768] gate-packed rows     */

@@ -249,7 +249,9 @@ struct FrontRingProb {
 #ifndef FWN_FRONT_LDS_MIN
 #define FWN_FRONT_LDS_MIN (156 * 1024)
 #endif
-template <int CH>
+// CHP = channels of the plane (CHP < CH: the image and the packed weights are zero padded to CH = 32 channels per half - Ch = 16,
+// whose K = 96 does not divide into 64-wide chunks per tap; the VALU kernel it replaces took 8 - 10 us per launch)
+template <int CH, int CHP = CH>
 __global__ __launch_bounds__(256) void front_mfma_kernel(const float* __restrict__ xa, const float* __restrict__ an, int apply_an,
                                                          const bf16* __restrict__ W2, const float* __restrict__ bias,
                                                          bf16* __restrict__ hout, int M, int Ti) {
@@ -290,27 +292,34 @@ __global__ __launch_bounds__(256) void front_mfma_kernel(const float* __restrict
     for (int q = 0; q < D - 1; ++q)
         if (q < NQ) issue(q);
     // the image: 4 channels of one row per task - fp32 in, ActNorm, (hi | lo) out
-    constexpr int NTASK = (NR + 1) * (CH / 4), NIT = (NTASK + 255) / 256;
-    static_assert(256 % (CH / 4) == 0, "a thread's channel group is the same for all its tasks");
+    constexpr int NTASK = (NR + 1) * (CHP / 4), NIT = (NTASK + 255) / 256;
+    static_assert(256 % (CHP / 4) == 0, "a thread's channel group is the same for all its tasks");
+    if constexpr (CHP < CH) {                       // the padded channels of both halves: zeros (their weights are zeros too, but 0 x NaN is not)
+        constexpr int PP = (CH - CHP) / 8;          // 16-byte pieces per half and row
+        for (int i = tid; i < (NR + 1) * 2 * PP; i += 256) {
+            const int j = i / (2 * PP), q = i % (2 * PP);
+            *(uint4*)(ldsA + a_off(j, (q / PP) * (CH / 8) + CHP / 8 + q % PP)) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
     // (CH / 4 divides 256: every task of a thread has the same tau - its ActNorm shift / scale are loaded ONCE, together with
     // the plane rows; looked up per task they were 9 dependent L2 round trips in front of the K loop at CH = 128)
-    const int tau_t = (tid % (CH / 4)) * 4;
+    const int tau_t = (tid % (CHP / 4)) * 4;
     const float4 an_sh = apply_an ? *(const float4*)(an + tau_t) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float4 an_sc = apply_an ? *(const float4*)(an + CH + tau_t) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    const float4 an_sc = apply_an ? *(const float4*)(an + CHP + tau_t) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     float4 vin[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {              // every load of the thread in flight at once (clamped addresses)
         const int task = tid + it * 256;
-        const int j = task / (CH / 4), tau = (task % (CH / 4)) * 4;
+        const int j = task / (CHP / 4), tau = (task % (CHP / 4)) * 4;
         const int g = m0 - 1 + j;
         const bool ok = task < NTASK && j < NR && (unsigned)g < (unsigned)M;
-        vin[it] = *(const float4*)(xa + (size_t)(ok ? g : 0) * CH + (ok ? tau : 0));
+        vin[it] = *(const float4*)(xa + (size_t)(ok ? g : 0) * CHP + (ok ? tau : 0));
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int task = tid + it * 256;
         if (task >= NTASK) break;
-        const int j = task / (CH / 4), tau = (task % (CH / 4)) * 4;
+        const int j = task / (CHP / 4), tau = (task % (CHP / 4)) * 4;
         const int g = m0 - 1 + j;
         const bool ok = j < NR && (unsigned)g < (unsigned)M;
         const float4 v = vin[it];
@@ -982,9 +991,10 @@ static void launch_ring(const Prob& p, int M, int N, int ksteps, hipStream_t st)
 
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,
                       void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, void* h8out, hipStream_t st) {
-    if (W2 && (Ch == 32 || Ch == 64 || Ch == 128) && ((uintptr_t)xa & 15) == 0 && FWN_TUNE(FWN_FRONT_FUSED, 1)) {
+    if (W2 && (Ch == 32 || Ch == 64 || Ch == 128 || (Ch == 16 && !h8out)) && ((uintptr_t)xa & 15) == 0 && FWN_TUNE(FWN_FRONT_FUSED, 1)) {
         const int grid = ((M + 63) / 64) * 4;
-        if (Ch == 32) hipLaunchKernelGGL((front_mfma_kernel<32>), dim3(grid), dim3(256), 0, st, xa, an_a, apply_an, (const bf16*)W2, bias, (bf16*)hout, M, Ti);
+        if (Ch == 16) hipLaunchKernelGGL((front_mfma_kernel<32, 16>), dim3(grid), dim3(256), 0, st, xa, an_a, apply_an, (const bf16*)W2, bias, (bf16*)hout, M, Ti);
+        else if (Ch == 32) hipLaunchKernelGGL((front_mfma_kernel<32>), dim3(grid), dim3(256), 0, st, xa, an_a, apply_an, (const bf16*)W2, bias, (bf16*)hout, M, Ti);
         else if (Ch == 64) hipLaunchKernelGGL((front_mfma_kernel<64>), dim3(grid), dim3(256), 0, st, xa, an_a, apply_an, (const bf16*)W2, bias, (bf16*)hout, M, Ti);
         else hipLaunchKernelGGL((front_mfma_kernel<128>), dim3(grid), dim3(256), 0, st, xa, an_a, apply_an, (const bf16*)W2, bias, (bf16*)hout, M, Ti);
         return;

@@ -74,6 +74,19 @@ def front2_src_k(block: int) -> np.ndarray:
     return out
 
 
+def front2_pad32_src_k(block: int) -> np.ndarray:
+    """Ch = 16 in the Ch = 32 form of ``front2_src_k`` (front_mfma_kernel<32, 16>: K = 96 does not divide into 64-wide chunks
+    per tap): [192], K = tap*64 + half*32 + tau with tau >= 16 zero padding (-1)."""
+    ch = 1 << block
+    assert ch == 16
+    br = bitrev_table(block)
+    out = np.full(6 * 32, -1, dtype=np.int32)
+    for tap in range(3):
+        for half in range(2):
+            out[tap * 64 + half * 32: tap * 64 + half * 32 + ch] = tap * ch + br
+    return out
+
+
 def front3_src_k(block: int) -> np.ndarray:
     """[kf3] -> source row of the (3*Ch, 256) front kernel for the chained front conv of tail_chain.h (Ch <= 8):
     K = (tap*Ch + tau)*2 + half - the same weight serves the hi and the lo bf16 half of the fp32 state, and the pair sits
@@ -525,6 +538,11 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                 f2 = dev_i32(("front2", i), lambda: front2_src_k(i))
                 wfront2 = bf16_zeros(FILTER, 6 * ch)
                 pack(wp + "/Conv_front", f2, ident256, 6 * ch, FILTER, wfront2, 6 * ch)
+                d.Wfront2 = wfront2.data_ptr()
+            if ch == 16:     # the MFMA front kernel on a zero-padded 32-channel image (front_mfma_kernel<32, 16>)
+                f2 = dev_i32(("front2p", i), lambda: front2_pad32_src_k(i))
+                wfront2 = bf16_zeros(FILTER, 192)
+                pack(wp + "/Conv_front", f2, ident256, 192, FILTER, wfront2, 192)
                 d.Wfront2 = wfront2.data_ptr()
             if ch <= 8:      # chained front conv (the previous flow's tail computes this flow's h0, tail_chain.h)
                 f3 = dev_i32(("front3", i), lambda: front3_src_k(i))
