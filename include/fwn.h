@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define FWN_VERSION 200            /* 0.2.0: fwn_tail takes scratch; training, fp8 and multi-rank init entry points */
+#define FWN_VERSION 300            /* 0.3.0: fwn_flow_desc gained Wfront3 / kf3 (round 3) and Wgs (round 4), fwn_model_desc
+                                    * chain_mode, fwn_block_done_fn returns int; Wskip / Wfinal rows and biases are in
+                                    * acc_k_perm order, Wzero's K axis is natural.  A host built against 0.2.0 must be
+                                    * rebuilt and repack its weights. */
 #define FWN_MAX_LAYERS 8
 #define FWN_MAX_UPSAMPLE 4
 
@@ -134,7 +137,20 @@ typedef struct fwn_flow_desc {
      * this flow's h0 (csrc/tail_chain.h); the stage entry points ignore it. */
     const void* Wfront3;
     int32_t kf3, reserved;
+    /* Register-streamed gate (csrc/gate_rs.h; NULL = not packed): Wd[l] and Wc[l] once more in MFMA-fragment order
+     * (fwn_pack_gate_stream), read by the gate kernel of the largest row counts (fwn_gate_stream_rows) instead of them. */
+    const void* Wgs[FWN_MAX_LAYERS];
 } fwn_flow_desc;
+
+/* ---- fragment-order gate weights (round 4, csrc/gate_rs.h; replaces nothing in the reference: a second packing of the
+ * operands of modules.py:113-124 for the kernel that streams them to registers).
+ * fwn_gate_stream_bytes: size of the stream for `cin` conditioning channels, 0 if no kernel is built for that cin;
+ * fwn_pack_gate_stream : Wd [512][768], Wc [512][kcpad] (gate-packed rows, as in fwn_flow_desc) -> out;
+ * fwn_gate_stream_rows : smallest M from which fwn_gate / the flow and model calls use the stream (dilation <= 3,
+ *                        Ti >= 256, conditioning fused: ca given, no training aux). */
+int64_t fwn_gate_stream_bytes(int cin);
+int fwn_pack_gate_stream(const void* Wd, const void* Wc, int cin, int kcpad, void* out, void* stream);
+int fwn_gate_stream_rows(void);
 
 /* ---- stage entry points (K4..K8), exposed so each kernel can be parity-tested alone ---- */
 /* K4 front conv k=3 + ReLU over in_a (modules.py:144,164-165); apply_an: ActNorm on load.

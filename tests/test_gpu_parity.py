@@ -56,7 +56,7 @@ def check_scalars(log_p, logdet, lp0, ld0):
 
 def test_native_library_is_loaded():
     lib = _lib.load()
-    assert lib.fwn_version() == 200
+    assert lib.fwn_version() == 300
     assert os.path.basename(_lib.LIB_PATH) == "libfwn.so" and os.path.exists(_lib.LIB_PATH)
     assert any("libfwn.so" in line for line in open("/proc/self/maps"))
 
@@ -263,7 +263,8 @@ def full_model():
 def test_gate_stage_kernel_matches_oracle(full_model, b, ti, layer):
     """fwn_gate alone (block 0, flow 0; dilation 1 and 3) against the oracle's ResBlock gate
     (modules.py:113-124) on rows that straddle clip edges inside every tile: M = 300 runs the
-    plain ring tiles, 7000 the 128x128, 13000 the 256x128 and 26000 the 256x256 tap-sharing tiles (gate_halo.h)."""
+    plain ring tiles, 7000 the 128x128, 13000 the 256x128 tap-sharing tiles (gate_halo.h) and 26000 the register-streamed
+    kernel (gate_rs.h: clip edges every 1000 rows inside its 256-row tiles, a partial last tile)."""
     hp, model, _, _, _ = full_model
     lib = _lib.load()
     p64 = onp.to_f64(W.synthetic_params(hp, 1234))
@@ -287,6 +288,59 @@ def test_gate_stage_kernel_matches_oracle(full_model, b, ti, layer):
     err = np.abs(o.float().cpu().numpy() - want)
     # bf16 weights and a bf16 output in (-1, 1): half an output ulp is 2e-3, the weight rounding adds ~1e-2
     assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max(), err.mean(), np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.mark.parametrize("blk,b,ti,layer", [(0, 26, 1000, 0), (0, 4, 8064, 1), (1, 8, 4032, 0), (1, 25, 1000, 1), (1, 97, 256, 1)])
+def test_gate_stream_kernel_against_tap_sharing_kernel(full_model, blk, b, ti, layer):
+    """The register-streamed gate (gate_rs.h, through fwn_gate with the flow's fragment stream Wgs) against the tap-sharing
+    tile (the same call with Wgs = NULL) on the same operands: both multiply the same bf16 values and differ only in the
+    order of the fp32 accumulation (the stream takes the conditioning chunks after the first slice), so the bf16 outputs
+    agree except for roundings at a tie - one output ulp, on a small fraction of the elements.
+    Blocks 0 and 1 (5 and 10 conditioning k-steps), both dilations, clip edges on and off tile boundaries, Ti = 256
+    (the smallest the kernel takes), partial last tiles."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    d = model._packed.flow_descs[blk * hp.n_flow + 1]
+    m = b * ti
+    assert d.Wgs[layer] and m >= lib.fwn_gate_stream_rows() and lib.fwn_gate_stream_bytes(d.cin) > 0
+    d_plain = _lib.FlowDesc.from_buffer_copy(d)
+    for l in range(_lib.FWN_MAX_LAYERS):
+        d_plain.Wgs[l] = None
+    rng = np.random.default_rng(blk * 100 + b + layer)
+    h = torch.from_numpy(rng.standard_normal((m, 256)).astype(np.float32) * 0.5).cuda().to(torch.bfloat16)
+    ca = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for desc in (d, d_plain):
+        o = torch.full((m + 8, 256), 7.0, device="cuda", dtype=torch.bfloat16)     # 8 guard rows behind the matrix
+        _lib.check(lib.fwn_gate(C.byref(desc), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
+        assert bool((o[m:] == 7.0).all()), "the kernel wrote past row M"
+        outs.append(o[:m].float().cpu().numpy())
+    diff = np.abs(outs[0] - outs[1])
+    # one output ulp is 2^-8 = 3.9e-3 just below 1 and 2^-9 below 0.5
+    assert diff.max() <= 4e-3, diff.max()
+    assert (diff != 0).mean() < 1e-3, (diff != 0).mean()
+
+
+def test_gate_stream_is_what_the_model_runs(full_model):
+    """The packed model carries fragment streams for the blocks the kernel is built for (cin = 80, 160 at num_mels = 80) and
+    none elsewhere; fwn_pack_gate_stream refuses a cin without a kernel; a descriptor that claims a stream for such a cin
+    is rejected."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    for i in range(hp.n_block):
+        d = model._packed.flow_descs[i * hp.n_flow]
+        have = lib.fwn_gate_stream_bytes(d.cin) > 0
+        assert have == (i < 2)
+        assert all(bool(d.Wgs[l]) == have for l in range(hp.n_layer))
+    d3 = _lib.FlowDesc.from_buffer_copy(model._packed.flow_descs[3 * hp.n_flow])
+    buf = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.fwn_pack_gate_stream(d3.Wd[0], d3.Wc[0], d3.cin, d3.kcpad, buf.data_ptr(), st) == -1
+    d3.Wgs[0] = buf.data_ptr()
+    h = torch.zeros(64, 256, device="cuda", dtype=torch.bfloat16)
+    ca = torch.zeros(64, d3.cin, device="cuda", dtype=torch.bfloat16)
+    assert lib.fwn_gate(C.byref(d3), 0, h.data_ptr(), ca.data_ptr(), None, h.data_ptr(), 64, 64, st) == -1
 
 
 def _flow_case(full_model, blk, b, ti, seed):

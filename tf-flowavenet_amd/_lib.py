@@ -31,7 +31,7 @@ class FlowDesc(C.Structure):
         ("Wzero", vp), ("bzero", vp), ("ezero", vp),
         ("an", vp),
         ("Wd8", vp * FWN_MAX_LAYERS), ("wd8_exp", i32 * FWN_MAX_LAYERS),
-        ("Wfront3", vp), ("kf3", i32), ("reserved", i32),
+        ("Wfront3", vp), ("kf3", i32), ("reserved", i32), ("Wgs", vp * FWN_MAX_LAYERS),
     ]
 
 
@@ -148,6 +148,9 @@ SIGNATURES = {
     "fwn_actnorm_from_moments": (C.c_int, [vp, C.c_int, vp, vp]),
     "fwn_front": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "fwn_gate": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "fwn_gate_stream_bytes": (i64, [C.c_int]),
+    "fwn_pack_gate_stream": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "fwn_gate_stream_rows": (C.c_int, []),
     "fwn_gate_fp8_supported": (C.c_int, [C.c_int, C.c_int]),
     "fwn_gate_fp8": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
     "fwn_cast_e4m3": (C.c_int, [vp, vp, i64, vp]),

@@ -144,6 +144,12 @@ static int check_desc(const fwn_flow_desc* d) {
     }
     REQUIRE(ALIGNED16(d->Wfront) && ALIGNED16(d->Wskip) && ALIGNED16(d->Wfinal) && ALIGNED16(d->Wzero),
             "flow desc: weights must be 16-byte aligned");
+    for (int l = 0; l < d->L; ++l)
+        REQUIRE(!d->Wgs[l] || (ALIGNED16(d->Wgs[l]) && fwn_gate_stream_size(d->cin) != 0),
+                "flow desc: Wgs[%d] given but no register-streamed gate kernel exists for cin = %d (or misaligned)", l, d->cin);
+    if (d->Wfront3)
+        REQUIRE(d->Ch <= 8 && d->kf3 == (6 * d->Ch + 15) / 16 * 16 && ALIGNED16(d->Wfront3),
+                "flow desc: Wfront3 needs Ch <= 8 and kf3 = 6 Ch rounded up to 16 (Ch %d, kf3 %d)", d->Ch, d->kf3);
     return FWN_OK;
 }
 
@@ -173,7 +179,7 @@ int fwn_gate(const fwn_flow_desc* d, int layer, const void* h, const void* ca, c
     REQUIRE(h && o && M > 0 && Ti > 0 && M % Ti == 0, "fwn_gate: bad argument");
     REQUIRE((ca != nullptr) != (P != nullptr), "fwn_gate: exactly one of ca / P");
     REQUIRE(ALIGNED16(h) && ALIGNED16(o) && ALIGNED16(ca), "fwn_gate: buffers must be 16-byte aligned");
-    fwn_launch_gate(h, ca, P, d->Wd[layer], d->Wc[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
+    fwn_launch_gate(h, ca, P, d->Wd[layer], d->Wc[layer], d->Wgs[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
                     d->cin, d->kcpad, nullptr, (hipStream_t)stream);
     return check_launch("fwn_gate");
 }
@@ -186,9 +192,19 @@ int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void*
     REQUIRE(h && o && aux && M > 0 && Ti > 0 && M % Ti == 0, "fwn_gate_train: bad argument");
     REQUIRE((ca != nullptr) != (P != nullptr), "fwn_gate_train: exactly one of ca / P");
     REQUIRE(ALIGNED16(h) && (!ca || ALIGNED16(ca)), "fwn_gate_train: buffers must be 16-byte aligned");
-    fwn_launch_gate(h, ca, P, d->Wd[layer], d->Wc[layer], d->bgate[layer], o, M, Ti, dilation_of(layer),
+    fwn_launch_gate(h, ca, P, d->Wd[layer], d->Wc[layer], nullptr, d->bgate[layer], o, M, Ti, dilation_of(layer),
                     d->cin, d->kcpad, aux, (hipStream_t)stream);
     return check_launch("fwn_gate_train");
+}
+
+int64_t fwn_gate_stream_bytes(int cin) { return cin > 0 ? (int64_t)fwn_gate_stream_size(cin) : 0; }
+int fwn_gate_stream_rows(void) { return fwn_gate_stream_min_rows(); }
+int fwn_pack_gate_stream(const void* Wd, const void* Wc, int cin, int kcpad, void* out, void* stream) {
+    REQUIRE(Wd && Wc && out && cin > 0 && kcpad >= cin && kcpad % 64 == 0, "fwn_pack_gate_stream: bad argument");
+    REQUIRE(fwn_gate_stream_size(cin) != 0, "fwn_pack_gate_stream: no register-streamed gate kernel for cin = %d", cin);
+    REQUIRE(ALIGNED16(Wd) && ALIGNED16(Wc) && ALIGNED16(out), "fwn_pack_gate_stream: buffers must be 16-byte aligned");
+    fwn_launch_gate_stream_pack(Wd, Wc, cin, kcpad, out, (hipStream_t)stream);
+    return check_launch("fwn_pack_gate_stream");
 }
 
 int fwn_gate_fp8_supported(int M, int layer) {
@@ -349,7 +365,7 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
             fwn_launch_gate_fp8(h8c, ca, d->Wd8[l], d->wd8_exp[l], d->Wc[l], d->bgate[l], ol, M, Ti, dilation_of(l), d->cin,
                                 d->kcpad, st);
         else
-            fwn_launch_gate(hc, ca, P ? P + (size_t)l * M * 512 : nullptr, d->Wd[l], d->Wc[l], d->bgate[l], ol, M,
+            fwn_launch_gate(hc, ca, P ? P + (size_t)l * M * 512 : nullptr, d->Wd[l], d->Wc[l], d->Wgs[l], d->bgate[l], ol, M,
                             Ti, dilation_of(l), d->cin, d->kcpad, nullptr, st);
         if (l + 1 < d->L) {
             fwn_launch_res(ol, hc, d->Wres[l], d->bres[l], hn, M, fp8_layer(l + 1) ? h8n : nullptr, st);

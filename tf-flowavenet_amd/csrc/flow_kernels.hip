@@ -525,6 +525,7 @@ struct GateProb {
 };
 
 #include "gate_halo.h"
+#include "gate_rs.h"
 
 // ---- residual 1x1: h' = (h + res_conv(o)) * sqrt(0.5), modules.py:126-128 ------------------
 struct ResProb {
@@ -1022,9 +1023,40 @@ void fwn_launch_front(const float* xa, const float* an_a, const void* W, const v
     launch_gemm128(p, M, 2, st);
 }
 
-void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc,
+// ---- register-streamed gate (gate_rs.h): one instantiation per number of conditioning k-steps
+#define FWN_RS_CASES(X) X(5) X(10)          // cin = 80 (block 0), 160 (block 1) at num_mels = 80
+long fwn_gate_stream_size(int cin) {
+    const int nkc = (cin + 15) / 16;
+#define X(n) if (nkc == n) return 16L * RsPlan<n>::NK * 1024;
+    FWN_RS_CASES(X)
+#undef X
+    return 0;
+}
+int fwn_gate_stream_min_rows() { return FWN_TUNE(FWN_RS_MIN_ROWS, 24576); }
+int fwn_gate_stream_ok(int M, int Ti, int dil, int cin, bool fused_cond, bool aux) {
+    // 256-row tiles x 2 channel halves must fill the chip (as for the 256 x 256 tap-sharing tile); a tile may cross one
+    // clip edge only; dilations whose halo fits the slot
+    return fused_cond && !aux && dil <= FWN_HALO_MAXDIL && Ti >= 256 && M >= fwn_gate_stream_min_rows() &&
+           fwn_gate_stream_size(cin) != 0 && cin % 8 == 0;
+}
+void fwn_launch_gate_stream_pack(const void* Wd, const void* Wc, int cin, int kcpad, void* out, hipStream_t st) {
+    const int nkc = (cin + 15) / 16;
+#define X(n) if (nkc == n) hipLaunchKernelGGL(gate_stream_pack_kernel<n>, dim3(128), dim3(256), 0, st, (const bf16*)Wd, (const bf16*)Wc, kcpad, (bf16*)out);
+    FWN_RS_CASES(X)
+#undef X
+}
+
+void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc, const void* Wgs,
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, void* aux,
                      hipStream_t st) {
+    if (Wgs && fwn_gate_stream_ok(M, Ti, dil, cin, ca != nullptr && P == nullptr, aux != nullptr)) {
+        GateRsArgs a{(const bf16*)h, (const bf16*)ca, (const bf16*)Wgs, bias, (bf16*)o, M, Ti, dil, cin};
+        const int nkc = (cin + 15) / 16, grid = ((M + 255) / 256) * 2;
+#define X(n) if (nkc == n) hipLaunchKernelGGL((gate_rs_kernel<n>), dim3(grid), dim3(512), 0, st, a);
+        FWN_RS_CASES(X)
+#undef X
+        return;
+    }
     GateProb p{(const bf16*)h, (const bf16*)ca, P, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o,
                M, Ti, dil, cin, kcpad};
     p.aux = (bf16*)aux;

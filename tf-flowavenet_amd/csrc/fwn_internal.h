@@ -15,9 +15,15 @@ static inline int fwn_tune_env(const char* name, int dflt) { const char* v = get
 // h8out (may be NULL): also write the e4m3 copy of the output the fp8 gate reads (front: Ch <= 16 only)
 void fwn_launch_front(const float* xa, const float* an_a, const void* W, const void* W2, const float* bias,
                       void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, void* h8out, hipStream_t st);
-void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc,
+// Wgs: the same weights in fragment order (fwn_launch_gate_stream_pack) or nullptr; used instead of Wd / Wc where
+// fwn_gate_stream_ok says so
+void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc, const void* Wgs,
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, void* aux,
                      hipStream_t st);
+long fwn_gate_stream_size(int cin);        // bytes, 0: no kernel for this cin
+int fwn_gate_stream_min_rows();
+int fwn_gate_stream_ok(int M, int Ti, int dil, int cin, bool fused_cond, bool aux);
+void fwn_launch_gate_stream_pack(const void* Wd, const void* Wc, int cin, int kcpad, void* out, hipStream_t st);
 // the gate with its dilated taps in fp8 (h8 e4m3 [M][256], Wd8 e4m3 [512][768] stored as W 2^wexp); fwn_gate_fp8_ok says
 // whether this shape has such a kernel (the tap-sharing tiles: M >= 12288 rows, dilation <= 3, conditioning fused)
 int fwn_gate_fp8_ok(int M, int dil);

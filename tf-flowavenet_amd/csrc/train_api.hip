@@ -378,7 +378,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, s.h[0], ch >= 32 ? pl.xhl : nullptr, (int)m, (int)ti, ch, d->kfpad, 1, nullptr, st);
             for (int l = 0; l < L; ++l) {
                 const float* Pl = hoist ? pl.P + ((size_t)j * L + l) * m * 512 : nullptr;
-                fwn_launch_gate(s.h[l], hoist ? nullptr : ca, Pl, d->Wd[l], d->Wc[l], d->bgate[l], s.o[l], (int)m, (int)ti, dilation_of(l), d->cin,
+                fwn_launch_gate(s.h[l], hoist ? nullptr : ca, Pl, d->Wd[l], d->Wc[l], nullptr, d->bgate[l], s.o[l], (int)m, (int)ti, dilation_of(l), d->cin,
                                 d->kcpad, s.aux[l], st);
                 if (l + 1 < L) fwn_launch_res(s.o[l], s.h[l], d->Wres[l], d->bres[l], s.h[l + 1], (int)m, nullptr, st);
             }

@@ -572,6 +572,16 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                     return np.where(fg == 0, bsum[0][gch], bsum[1][gch])
                 d.Wd[l] = wd.data_ptr()
                 d.Wc[l] = wc.data_ptr()
+                # the same operands in MFMA-fragment order for the register-streamed gate kernel (csrc/gate_rs.h): packed
+                # once, so only without a PackPlan (a plan re-packs Wd / Wc every training step, whose forward pass keeps
+                # the training gate kernel anyway)
+                gs_bytes = int(lib.fwn_gate_stream_bytes(cin)) if plan is None else 0
+                if gs_bytes:
+                    wgs = pm.keep(torch.empty(gs_bytes, dtype=torch.uint8, device=dev))
+                    pm.weight_bytes += gs_bytes
+                    _lib.check(lib.fwn_pack_gate_stream(wd.data_ptr(), wc.data_ptr(), cin, kcpad, wgs.data_ptr(), stream),
+                               "fwn_pack_gate_stream")
+                    d.Wgs[l] = wgs.data_ptr()
                 if gate_fp8:
                     pack_gate_fp8(rp, d, l, (i * hp.n_flow + j) * L + l)
                 put(lambda v, d=d, l=l: d.bgate.__setitem__(l, v.data_ptr()), gate_bias,
