@@ -76,13 +76,29 @@ def cpu_baseline(hp, params, t, budget_s=20.0, max_passes=16):
             if time.perf_counter() - t_start > budget_s and len(times) >= 3:
                 break
     med = float(np.median(times))
+    # SURVEY section 8(d) asks for configs[0] ("the reference's own CPU-runnable case") always: forward log-p of the
+    # n_block = 2, n_flow = 2 model on one clip
+    import copy
+    hp0 = copy.copy(hp)
+    hp0.n_block, hp0.n_flow = 2, 2
+    fp0 = ot.fold(W.synthetic_params(hp0, 1234), hp0, dtype=torch.float32)
+    t0s = []
+    with torch.no_grad():
+        for it in range(6):
+            t0 = time.perf_counter()
+            ot.forward(fp0, x, c, hp0)
+            if it > 0:
+                t0s.append(time.perf_counter() - t0)
+    med0 = float(np.median(t0s))
     return {"value": 2.0 * t / med, "unit": "samples/s", "cores": ncore, "kind": "port",
+            "config0": {"workload": "configs[0]: forward log-p, n_block=2 n_flow=2, one %d-sample clip" % t,
+                        "value": t / med0, "unit": "samples/s", "ms": med0 * 1e3, "passes": len(t0s)},
             "sample": "torch-CPU fp32 restatement (TF 1.12 unavailable), full n_block=%d model, B=1, T=%d, "
                       "forward+inverse, median of %d timed passes after 1 warm-up (spread %.0f%%)"
                       % (hp.n_block, t, len(times), 100.0 * (max(times) - min(times)) / med)}
 
 
-def gate_roofline(model, hp, b, t, iters=30):
+def gate_roofline(model, hp, b, t, iters=200):
     """Time the dominant kernel (block-0 gated dilated layer) alone with HIP events on the
     launch stream and price it against the dense bf16 MFMA peak."""
     import ctypes as C
@@ -101,26 +117,46 @@ def gate_roofline(model, hp, b, t, iters=30):
     def launch():
         _lib.check(lib.fwn_gate(C.byref(d), 0, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
 
-    for _ in range(5):
+    for _ in range(10):
         launch()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        launch()
-    e1.record()
+    # `iters` launches as groups of 20 back to back, every group between its own pair of HIP events on the launch stream
+    # (inside a pass the launches of a flow follow each other without event packets in between: this is the duration a
+    # chain of launches sees, and what rocprofv3's per-dispatch duration agrees with); the MEDIAN of the group means is the
+    # figure - a clock dip or a neighbour on the box moves a mean -, min and max beside it
+    group = 20
+    ngroups = max(1, iters // group)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ngroups)]
+    for e0, e1 in ev:
+        e0.record()
+        for _ in range(group):
+            launch()
+        e1.record()
     torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    us = np.sort(np.array([e0.elapsed_time(e1) for e0, e1 in ev]) * 1e3 / group)
+    # and every launch between its own event pair (adds the event packets' gap to every launch: an upper bound)
+    ev1 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(group * 2)]
+    for e0, e1 in ev1:
+        e0.record()
+        launch()
+        e1.record()
+    torch.cuda.synchronize()
+    single_us = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev1])) * 1e3
+    sec = float(np.median(us)) * 1e-6
     flops = 2.0 * m * (768 + d.cin) * 512
     ach = flops / sec / 1e12
     traffic, traffic_source = gate_traffic(m)
-    return {"bound": "mfma", "kernel": "gate_halo_kernel<256,256,GateProb> (block 0 gated dilated layer, fwn_gate)",
+    streamed = bool(d.Wgs[0]) and m >= lib.fwn_gate_stream_rows()
+    kernel = ("gate_rs_kernel<5> (register-streamed weights, csrc/gate_rs.h)" if streamed
+              else "gate_halo_kernel<256,256,GateProb> (tap-sharing tile, csrc/gate_halo.h)")
+    return {"bound": "mfma", "kernel": kernel + ": block 0 gated dilated layer, fwn_gate",
             "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_source, "launch_us": sec * 1e6, "flop_per_launch": flops,
-            "rows": m}
+            "rows": m, "timing": "median over %d groups of %d back-to-back launches, one HIP event pair per group" % (ngroups, group),
+            "launch_us_min": float(us[0]), "launch_us_max": float(us[-1]), "launch_us_single_event_pair": single_us}
 
 
-GATE_SOURCES = ("gate_halo.h", "gemm_ring.h", "common.h", "flow_kernels.hip")
+GATE_SOURCES = ("gate_rs.h", "gate_halo.h", "gemm_ring.h", "common.h", "flow_kernels.hip")
 # per-block lower bound sum_i max(FLOP_i / 2.5 PF, bytes_i / 8 TB/s) of one pass at datasheet peaks
 BOUND_US = {"B8_T16128": 853.0, "B1_T16128": 130.8, "B1_T220672": 1459.0}
 
@@ -149,7 +185,47 @@ def committed_profile(pattern):
     return None, "no profile of the current kernel sources (hash %s) under profiles/%s" % (sha, pattern)
 
 
-def path_roofline(hp, b, t, fwd_s, inv_s):
+BLOCK_PASSES = 9
+
+
+def block_table(model, hp, b, t, x, c, z):
+    """us per block of the one-stream forward and inverse pass, measured live: fwn_model_desc.block_events makes the
+    whole-model calls record a HIP event in front of every block (and behind the last); median over BLOCK_PASSES passes."""
+    import ctypes as C
+    import torch
+    md = model._packed.model_desc
+    nb = hp.n_block
+    half = hp.num_mels // 2
+    out = {}
+    for dname, fn in (("fwd", lambda: model.forward(x, c)), ("inv", lambda: model.reverse(z, c))):
+        samples = []
+        for _ in range(BLOCK_PASSES + 1):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(nb + 1)]
+            for e in evs:
+                e.record()                      # creates the handle
+            handles = (C.c_void_p * (nb + 1))(*[e.cuda_event for e in evs])
+            md.block_events = C.cast(handles, C.POINTER(C.c_void_p))
+            try:
+                fn()
+            finally:
+                md.block_events = None
+            torch.cuda.synchronize()
+            samples.append([evs[k].elapsed_time(evs[k + 1]) * 1e3 for k in range(nb)])
+        med = np.median(np.array(samples[1:]), axis=0)
+        rows = []
+        for k in range(nb):
+            i = k if dname == "fwd" else nb - 1 - k
+            cc = 2 << i
+            cin = half * cc
+            mac = 3 * (cc // 2) * 256 + hp.n_layer * (2 * 3 * 256 * 256 + 2 * cin * 256) + (2 * hp.n_layer - 1) * 256 * 256 + 256 * 256 + 256 * cc
+            gflop = 2.0 * mac * hp.n_flow / cc * b * t / 1e9
+            rows.append({"block": i, "rows": b * t // cc, "us": round(float(med[k]), 1), "gflop": round(gflop, 1),
+                         "mfma_frac": round(gflop / float(med[k]) * 1e3 / MFMA_PEAK_TFLOPS, 4)})
+        out[dname] = sorted(rows, key=lambda r: r["block"])
+    return out
+
+
+def path_roofline(hp, b, t, fwd_s, inv_s, live_blocks=None):
     """The PATH against its rooflines (SURVEY section 8d asks for both): whole-pass MFMA fraction from the live timings,
     the per-block table and the whole-pass HBM bytes from the committed rocprofv3 profiles of these kernel sources."""
     flop = flop_per_sample(hp) * b * t
@@ -159,13 +235,19 @@ def path_roofline(hp, b, t, fwd_s, inv_s):
     for name, sec in (("fwd", fwd_s), ("inv", inv_s)):
         out[name] = {"ms": sec * 1e3, "mfma_frac": flop / sec / 1e12 / MFMA_PEAK_TFLOPS,
                      "frac_of_survey_bound": (bound * 1e-6 / sec) if bound else None}
+    # per block: measured in THIS run (HIP events the whole-model calls record at the block boundaries,
+    # fwn_model_desc.block_events); the launch counts are those of the committed rocprofv3 pass table when it was taken on
+    # these kernel sources
     tab, src = committed_profile("r*_pass_table.json")
-    out["blocks_source"] = src
-    out["blocks"] = None
-    if tab:
-        out["blocks"] = {d: [{"block": r["block"], "rows": r["rows"], "us": round(r["us"], 1), "gflop": round(r["gflop"], 1),
-                              "mfma_frac": round(r["frac"], 4), "launches": r["launches"]} for r in tab[d]["blocks"]]
-                         for d in ("fwd", "inv") if d in tab}
+    out["blocks_source"] = "live: HIP events at the block boundaries of one-stream passes (median of %d)" % BLOCK_PASSES
+    out["blocks_launch_counts_source"] = src
+    out["blocks"] = live_blocks
+    if tab and live_blocks:
+        for dname in ("fwd", "inv"):
+            if dname in tab and dname in live_blocks:
+                by_block = {r["block"]: r["launches"] for r in tab[dname]["blocks"]}
+                for r in live_blocks[dname]:
+                    r["launches"] = by_block.get(r["block"])
     tr, src = committed_profile("r*_pass_traffic.json")
     out["hbm_source"] = src
     out["hbm"] = None
@@ -349,7 +431,10 @@ def train_leg(hp, params, rank, world, dev, steps=10, batch=8, samples=6400, for
            # forward + backward = 3 x the forward FLOP of the samples (the recompute by inversion is not counted)
            "mfma_frac": 3.0 * flop_per_sample(hp) * batch * samples / step_s / 1e12 / MFMA_PEAK_TFLOPS,
            # lock-step: every rank holds bit-identical master weights after the timed steps (all-reduce of a 64-bit hash)
-           "weights_identical": bool(tr.opt.weights_identical())}
+           "weights_identical": bool(tr.opt.weights_identical()),
+           # what the process group itself reports (N > 1: RCCL over xGMI; one rank with --force-collectives: a one-rank RCCL group)
+           "collective": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rank": dist.get_rank()}
+                          if dist.is_available() and dist.is_initialized() else None)}
     if exchanging:
         tr.exchange = False              # same step without the gradient exchange (weights drift apart: timing only)
         compute_s, _ = timed(max(3, steps // 2))
@@ -401,7 +486,7 @@ def launch_ranks(n):
 class Deadline:
     """The optional legs (10 s clip, training step) must never cost the headline line: if one of them is still
     running `seconds` after it started (a stuck collective on an untested topology), rank 0 prints the line with what
-    it has and every rank leaves."""
+    it has and every rank leaves with exit code 3 (the line carries a "note"; a caller must not mistake the run for a complete one)."""
 
     def __init__(self, emit):
         import threading
@@ -411,7 +496,7 @@ class Deadline:
         def fire():
             self._emit("%s did not finish within %d s" % (what, seconds))
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)                  # the partial line is out; the run did not complete
         self._timer = self._threading.Timer(seconds, fire)
         self._timer.daemon = True
         self._timer.start()
@@ -608,7 +693,7 @@ def main():
             "realtime_factor_inverse": b * t / inv_s / hp.sample_rate,
         }
         out["roofline"] = gate_roofline(model, hp, b, t)
-        out["path"] = path_roofline(hp, b, t, fwd_s, inv_s)
+        out["path"] = path_roofline(hp, b, t, fwd_s, inv_s, block_table(model, hp, b, t, x, c, z))
         out["latency_b1"] = None if args.no_latency else latency_b1(model, hp, t, dev)
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None

@@ -385,6 +385,10 @@ typedef struct fwn_model_desc {
     int32_t chain_mode;                       /* 0: chain the flows of a block (out_b to a third plane buffer, the next flow's
                                                * front conv in the previous flow's tail: csrc/tail_chain.h); 1: every flow on its own */
     int32_t reserved;
+    /* Diagnostic (bench.py's per-block table), normally NULL: HOST array of n_block + 1 hipEvent_t handles.  The whole-model
+     * calls record [k] on `stream` in front of the first launch of the k-th block they run (forward: block k, reverse: block
+     * n_block - 1 - k) and [n_block] behind the last launch of the last one. */
+    void* const* block_events;
 } fwn_model_desc;
 
 size_t fwn_workspace_bytes(const fwn_model_desc* m, int64_t B, int64_t T);

@@ -48,6 +48,7 @@ class ModelDesc(C.Structure):
         ("gate_fp8", i32),
         ("chain_mode", i32),
         ("reserved", i32),
+        ("block_events", C.POINTER(vp)),
     ]
 
 

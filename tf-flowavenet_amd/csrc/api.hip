@@ -807,6 +807,11 @@ static FlowChain flow_chain(const fwn_model_desc* m, const fwn_flow_desc* d, con
     return ch;
 }
 
+static int record_block_event(const fwn_model_desc* m, int k, hipStream_t st) {
+    if (!m->block_events || !m->block_events[k]) return 0;
+    return hipEventRecord((hipEvent_t)m->block_events[k], st) != hipSuccess;
+}
+
 static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
                               void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
                               fwn_reduce_fn reduce, void* user, void* stream) {
@@ -831,6 +836,7 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
     int poff = 0;
     Planes pl{{planes, planes + plane_elems}, (float*)(ws + c.plane3), {planes, planes + plane_elems}};
     for (int i = 0; i < m->n_block; ++i) {
+        if (record_block_event(m, i, st)) return fail(FWN_ERR_HIP, "fwn_model_forward: hipEventRecord failed");
         const int64_t M = B * T / ((int64_t)2 << i);
         const bool hoist = hoist_cond(m, M, m->flows[i * m->n_flow].cin);
         if (hoist) {
@@ -858,6 +864,7 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
             p ^= 1;   // change_order (model.py:190)
         }
     }
+    if (record_block_event(m, m->n_block, st)) return fail(FWN_ERR_HIP, "fwn_model_forward: hipEventRecord failed");
     if (planes_go_home(pl, plane_elems * 4, st)) return fail(FWN_ERR_HIP, "fwn_model_forward: plane copy failed");
     fwn_launch_prior(planes, (long)(B * T), partial, poff, 1.0 / (double)(B * T), out2, st);
     if (z_planes) {
@@ -902,6 +909,7 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
     int p = 0;
     Planes pl{{planes, planes + plane_elems}, (float*)(ws + c.plane3), {planes, planes + plane_elems}};
     for (int i = m->n_block - 1; i >= 0; --i) {
+        if (record_block_event(m, m->n_block - 1 - i, st)) return fail(FWN_ERR_HIP, "fwn_model_reverse: hipEventRecord failed");
         const int64_t M = B * T / ((int64_t)2 << i);
         const bool hoist = hoist_cond(m, M, m->flows[i * m->n_flow].cin);
         if (hoist) {
@@ -933,6 +941,7 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
             if (have_h0 && ch.h0_next != hA) { void* t = hA; hA = hB; hB = t; }
         }
     }
+    if (record_block_event(m, m->n_block, st)) return fail(FWN_ERR_HIP, "fwn_model_reverse: hipEventRecord failed");
     if (planes_go_home(pl, plane_elems * 4, st)) return fail(FWN_ERR_HIP, "fwn_model_reverse: plane copy failed");
     fwn_launch_merge(planes, B, T, x_out, st);
     return check_launch("fwn_model_reverse");

@@ -370,7 +370,10 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
 
 // NKC: conditioning k-steps of 16 (cin / 16 rounded up); R: ring stages of weight fragments per wave (R - 1 k-steps in
 // flight)
-template <int NKC, int R = 6>
+#ifndef FWN_RS_R
+#define FWN_RS_R 6
+#endif
+template <int NKC, int R = FWN_RS_R>
 __global__ __launch_bounds__(512) void gate_rs_kernel(GateRsArgs p) {
     static_assert(R >= 3 && R <= 12, "ring depth");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * FWN_RS_PP * 1024];
@@ -382,6 +385,9 @@ __global__ __launch_bounds__(512) void gate_rs_kernel(GateRsArgs p) {
     const int m0 = tile_m * 256;
     const int grp = tile_n * 8 + wave;                // channel group: 16 channels
     RS_STAMP(0); RS_STAMP_RT(30);
+#ifdef FWN_RS_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(FWN_RS_PRIO);
+#endif
     auto stamp = [&](int i) { RS_STAMP(i); };
     if (wave >= 4) gate_rs_wave<NKC, R, true>(p, lds, wave, lane, m0, grp, stamp);
     else gate_rs_wave<NKC, R, false>(p, lds, wave, lane, m0, grp, stamp);
