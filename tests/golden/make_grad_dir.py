@@ -15,7 +15,8 @@ signal (<g, d> ~ |g| / sqrt(n) against an error of the same size), so d_f is the
 SAME parameters on the toy batch (B = 2, T = 1024: `oracle/grad_torch.py`), restricted to the family - it correlates with
 the gradient at the training shape and both the generator and the test can compute it on the CPU.  Families: dilated
 kernels (Conv_filter / Conv_gate), conditioning kernels (filter_conv_c / gate_conv_c), per-channel scales (ActNorm b /
-logs, ZeroConv scale), up-sampling kernels.  Each derivative is taken at eps and 2 eps, which must agree to 2e-3, and the
+logs, ZeroConv scale), up-sampling kernels, the 1 x 1 / front / ZeroConv kernels, every weight-norm g and bias, and all
+trainable tensors at once.  Each derivative is taken at eps and 2 eps, which must agree to 2e-3, and the
 fixture holds their Richardson extrapolation (4 fd(eps) - fd(2 eps)) / 3 (error O(eps^4)).
 """
 import os
@@ -37,19 +38,22 @@ NAME = "grad_dir_b8f6_B8_T6400"
 SEED, B, T = 1234, 8, 6400                        # hparams.py:28,36 (max_time_steps, batch_size)
 TOY_B, TOY_T = 2, 1024
 
+# family -> (name suffixes ("" = every trainable tensor), eps).  Round 4: "pointwise" - the 1 x 1 /
+# front / ZeroConv kernels, i.e. most jobs of the grouped TN weight-gradient GEMM (modules.py:74-95,144,158-159) -,
+# "gbias" - every weight-norm g and every bias (convolutional.py:73-80: the weight-norm backward) - and "all".
 FAMILIES = {
     "dilated": (("/Conv_filter/kernel", "/Conv_gate/kernel"), 5e-3),
     "cond": (("/filter_conv_c/kernel", "/gate_conv_c/kernel"), 5e-3),
     "scale": (("/ActNorm/b", "/ActNorm/logs", "/ZeroConv1d/scale"), 5e-4),
     "upsample": (("upsample_0/kernel", "upsample_1/kernel"), 5e-4),
+    "pointwise": (("/res_conv/kernel", "/skip_conv/kernel", "/Conv_final/kernel", "/ZeroConv1d/kernel", "/Conv_front/kernel"), 2e-3),
+    "gbias": (("/g", "/bias"), 5e-4),
+    "all": (("",), 2e-4),
 }
 
 
-def family_of(name):
-    for fam, (pats, _) in FAMILIES.items():
-        if any(name.endswith(p) or name == p for p in pats):
-            return fam
-    return None
+def in_family(fam, name):
+    return any(name.endswith(p) for p in FAMILIES[fam][0])
 
 
 def directions(params, hp):
@@ -58,7 +62,7 @@ def directions(params, hp):
     _, _, _, g = G.loss_and_grads(params, inp["x"], inp["c"], hp)
     out = {}
     for fam in FAMILIES:
-        d = {k: np.asarray(v, dtype=np.float64) for k, v in g.items() if family_of(k) == fam}
+        d = {k: np.asarray(v, dtype=np.float64) for k, v in g.items() if in_family(fam, k)}
         nrm = np.sqrt(sum(float((v * v).sum()) for v in d.values()))
         assert d and nrm > 0, fam
         out[fam] = {k: v / nrm for k, v in d.items()}
@@ -79,9 +83,17 @@ def main():
     inp = W.synthetic_inputs(hp, B, T)
     x, c = inp["x"].astype(np.float64), inp["c"].astype(np.float64)
     base = onp.to_f64(params)
-    out = dict(b=B, t=T, seed=SEED, toy_b=TOY_B, toy_t=TOY_T, loss=loss(base, x, c, hp))
+    path = os.path.join(HERE, NAME + ".npz")
+    old = dict(np.load(path)) if os.path.exists(path) else {}
+    if old and (int(old["b"]), int(old["t"]), int(old["seed"]), int(old["toy_b"]), int(old["toy_t"])) == (B, T, SEED, TOY_B, TOY_T):
+        out = {k: (v.item() if v.shape == () else v) for k, v in old.items()}      # families already taken at this eps are kept
+    else:
+        out = dict(b=B, t=T, seed=SEED, toy_b=TOY_B, toy_t=TOY_T, loss=loss(base, x, c, hp))
     print("loss %.9f (%.0f s)" % (out["loss"], time.time() - t0), flush=True)
     for fam, (_, eps) in FAMILIES.items():
+        if "fd_" + fam in out and float(out["eps_" + fam]) == eps:
+            print("%-9s kept" % fam, flush=True)
+            continue
         fds = []
         for e in (eps, 2 * eps):
             vals = []
@@ -95,7 +107,7 @@ def main():
         print("%-9s fd %.9e  (eps: %.9e, 2 eps: %.9e, rel diff %.2e)  %.0f s" % (fam, out["fd_" + fam], fds[0], fds[1],
                                                                                 abs(fds[0] - fds[1]) / abs(fds[0]), time.time() - t0), flush=True)
         assert abs(fds[0] - fds[1]) <= 2e-3 * abs(fds[0]), "curvature: shrink eps"
-    np.savez(os.path.join(HERE, NAME + ".npz"), **out)
+        np.savez(path, **out)
 
 
 if __name__ == "__main__":

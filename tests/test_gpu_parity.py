@@ -600,6 +600,42 @@ def test_concurrent_streams_reproduce_the_serial_result(full_model, nb, nt):
         assert torch.equal(got, ref_wav if kind == "inv" else ref_nll), kind
 
 
+@pytest.mark.parametrize("nb,lanes,steps", [(8, 3, 312), (1, 6, 312)])
+def test_overlapped_streams_soak(full_model, nb, lanes, steps):
+    """The soak behind the headline mode (tools/diag/lanes_flake.py as a test): `steps` overlapped steps
+    in bench.py's arrangement - `lanes` HIP streams per direction, forward and inverse passes of independent steps in
+    flight together, kernels of every kind sharing CUs - and every one of them bit-identical to the one-stream pass.
+    The two silent-corruption findings of this project fired in about 1 step of 10 (SLP packed math, round 2) and 1 of
+    50 (a ring refilled behind a barrier crossed with LDS reads in flight, round 3: DESIGN.md section 3.5); front_mfma_kernel
+    runs at its real LDS size here, co-resident with other workgroups."""
+    hp, model, x, c, z = full_model
+    nt = 16128
+    xs, cs, zs = x[:nb, :nt].contiguous(), c[:nb, :nt // hp.hop_size].contiguous(), z[:nb, :nt].contiguous()
+    ref_nll = torch.stack(model.forward(xs, cs)).clone()
+    ref_wav = model.reverse(zs, cs).clone()
+    torch.cuda.synchronize()
+    lf = [torch.cuda.Stream() for _ in range(lanes)]
+    li = [torch.cuda.Stream() for _ in range(lanes)]
+    bad_f = bad_i = 0
+    cur = torch.cuda.current_stream()
+    for _ in range(steps // 12):
+        outs = []
+        for s_ in lf + li:
+            s_.wait_stream(cur)
+        for k in range(12):
+            with torch.cuda.stream(lf[k % lanes]):
+                nll = torch.stack(model.forward(xs, cs))
+            with torch.cuda.stream(li[k % lanes]):
+                wav = model.reverse(zs, cs).clone()
+            outs.append((nll, wav))
+        for s_ in lf + li:
+            cur.wait_stream(s_)
+        torch.cuda.synchronize()
+        bad_f += sum(int(not torch.equal(nll, ref_nll)) for nll, _ in outs)
+        bad_i += sum(int(not torch.equal(wav, ref_wav)) for _, wav in outs)
+    assert (bad_f, bad_i) == (0, 0), "%d forward / %d inverse passes of %d differ from the one-stream result" % (bad_f, bad_i, steps // 12 * 12)
+
+
 def test_ten_second_clip_batch_of_clips_is_clipwise_identical(full_model):
     """BASELINE configs[3] shards 10 s clips over GPUs; one GPU may also take several: every clip of a B=2 call equals
     the same clip synthesised alone at the B=1 tile shapes up to bf16 rounding flips (values are checked against the

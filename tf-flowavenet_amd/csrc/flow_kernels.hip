@@ -240,14 +240,15 @@ struct FrontRingProb {
 // applied, zero rows outside the clip - and the three taps read that one image at row offsets 0, 1, 2 (the tap sharing of
 // gate_halo.h); only the weights (Wfront2, K = tap*2Ch + half*Ch + tau) stream through a 4-slot LDS-DMA ring.
 // Tile 64 rows x 64 channels, 4 waves as 2 x 2, one 32 x 32 accumulator tile each.
-// LDS allocation: the kernel needs 64 - 66 KB, but it asks for 156 KB so that NO other LDS-using workgroup shares its CU.
-// With 66 KB (or 100 KB) it sat beside workgroups of other kernels from the bench's other streams and ~1 overlapped step in
-// 100 came back with one clip off by ~1e-2 (tools/diag/lanes_flake.py: 4 of 240 steps; 0 of 3 600 with the CU to itself;
-// 0 of 720 without this kernel).  It is the only kernel here that writes LDS with ds_write WHILE LDS-DMA pieces are in
-// flight and is small enough to be co-resident - the same signature as round 2's front_valu_kernel finding (DESIGN.md,
-// "Toolchain pitfalls"): a workgroup's ds_write traffic and another workgroup's LDS-DMA on one CU do not mix reliably.
+// LDS allocation: what it uses (64 - 98 KB).  Round 3 padded it to 156 KB because with its real size ~1 overlapped step in
+// 100 came back with one clip off by ~1e-2 whenever other workgroups shared the CU.  Root cause (round 4, DESIGN.md section
+// 3.5): that version refilled its weight ring inside the K loop, and hipcc had sunk the s_waitcnt lgkmcnt of the previous
+// chunk's fragment reads below the raw s_barrier that licensed the refill - the LDS-DMA could overtake reads still in
+// flight once a neighbour slowed the LDS.  This version issues every chunk in the prologue (no slot is ever reused), the
+// ring kernels retire their LDS reads before their barriers (FWN_RING_BARRIER), and the real allocation soaks clean
+// (tests/test_gpu_parity.py::test_overlapped_streams_soak).  FWN_FRONT_LDS_MIN remains as a developer switch.
 #ifndef FWN_FRONT_LDS_MIN
-#define FWN_FRONT_LDS_MIN (156 * 1024)
+#define FWN_FRONT_LDS_MIN 0
 #endif
 // CHP = channels of the plane (CHP < CH: the image and the packed weights are zero padded to CH = 32 channels per half - Ch = 16,
 // whose K = 96 does not divide into 64-wide chunks per tap; the VALU kernel it replaces took 8 - 10 us per launch)

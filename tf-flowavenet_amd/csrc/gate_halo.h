@@ -243,7 +243,7 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
             if (prev_a) FWN_WAIT_VMCNT(1);
             else FWN_WAIT_VMCNT(0);
             FWN_STAMP_AT(s, 1);
-            __builtin_amdgcn_s_barrier();
+            FWN_RING_BARRIER();
             FWN_STAMP_AT(s, 2);
             const unsigned char* lb = ldsB + (s & 1) * B_BYTES;
             auto hooks = [&](int ki) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BM * 4) void gate_halo_kernel(Prob p, int ntn) {
     const int rbc[2] = {ic * G::RB, (ic + 32) * G::RB};
     for (int qc = 0; qc < ncond; ++qc, ++s) {
         FWN_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
+        FWN_RING_BARRIER();
         const unsigned char* la = ldsA + (qc & 1) * A_BYTES;
         const unsigned char* lb = ldsB + (s & 1) * B_BYTES;
         const int kleft = cin - qc * 64;             // valid K columns of this chunk (the rest is zero padding)

@@ -271,7 +271,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
         constexpr int b = decltype(B)::value;
         if constexpr (b < NI) rs_vmwait<C::wait_barrier(b)>();
         stamp(1 + 2 * b);
-        if (FWN_RABL != 3) __builtin_amdgcn_s_barrier();
+        if (FWN_RABL != 3) FWN_RING_BARRIER();       // (nothing is in flight here by construction: the last k-step of an item prefetches nothing)
         stamp(2 + 2 * b);
     };
     if constexpr (LAG) {

@@ -49,6 +49,14 @@ struct RingGeom {
 #endif
 
 #define FWN_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// The barrier of a ring: behind it a slot that waves may still have been READING is refilled (LDS-DMA) or reused
+// (ds_write).  An s_barrier orders nothing by itself, and hipcc is free to sink the consumers of a ds_read (MFMAs are
+// register-only instructions) together with the s_waitcnt lgkmcnt that retires it BELOW a raw s_barrier: the wave then
+// arrives with reads of the old slot contents in flight and the refill can overtake them.  That was the round-3
+// front_mfma_kernel finding (wrong weights in ~1 overlapped step in 50, only with another kernel on
+// the CU slowing the LDS); tools/check_barrier_lgkm.py finds the pattern in the ISA.  Every ring barrier therefore retires
+// the wave's own LDS operations first - free where nothing is in flight, and exactly the missing wait where something is.
+#define FWN_RING_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 // n wave-uniform (run time): wait until at most n vector-memory operations are outstanding (waiting for fewer is safe)
 __device__ __forceinline__ void fwn_wait_vm_le(int n) {
     // n wave-uniform: wait until at most n vector-memory operations are outstanding (waiting for fewer is safe)
@@ -234,7 +242,7 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         if (FWN_ABL_DMA) wait_vmcnt_le<PW>(pending);
         else if (q == 0) FWN_WAIT_VMCNT(0);
         FWN_RING_STAMP(q, 1);
-        if (FWN_ABL != 5) __builtin_amdgcn_s_barrier();
+        if (FWN_ABL != 5) FWN_RING_BARRIER();
         FWN_RING_STAMP(q, 2);
         // The refill of the slot freed by this barrier (chunk q+D-1) is spread over the k-steps,
         // so every DMA issue (~100 cycles of this wave's issue time) hides under MFMAs in flight.
@@ -281,7 +289,7 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         constexpr int TILE_F = MI * 2 * 16 * 64;           // floats per wave
         static_assert((KSP - 1) * WM * WN * TILE_F * 4 <= D * SLOT, "reduction scratch must fit the ring");
         float* red = (float*)lds;
-        __builtin_amdgcn_s_barrier();
+        FWN_RING_BARRIER();      // the partial sums are parked in the ring's slots: the last fragment reads must have returned
         if (wk > 0) {
             float* dst = red + ((wk - 1) * WM * WN + wmn) * TILE_F + lane;
 #pragma unroll

@@ -217,12 +217,12 @@ __global__ __launch_bounds__(64 * NW) void tail_kernel(TailArgs a) {
     constexpr int NSV = 16;
     int sv_upto = -1;
     auto step = [&](int c) {
-        if (FWN_TABL == 2) { if (c == 0) FWN_WAIT_VMCNT(0); __builtin_amdgcn_s_barrier(); return; }
+        if (FWN_TABL == 2) { if (c == 0) FWN_WAIT_VMCNT(0); FWN_RING_BARRIER(); return; }
         int pend = c <= sv_upto ? NSV : 0;
 #pragma unroll
         for (int i = 1; i <= D - 2; ++i) pend += pieces(c + i);
         fwn_wait_vm_le(pend);
-        __builtin_amdgcn_s_barrier();
+        FWN_RING_BARRIER();
     };
     auto save_pk = [&](bf16* dst, const bf16x8 (&pk_)[8][2], int issued_upto) {
         const srd_t sd = make_srd(dst, (uint32_t)((size_t)a.M * FWN_HID * 2));
