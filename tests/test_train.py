@@ -305,6 +305,52 @@ def test_directional_derivatives_at_the_training_shape_match_the_oracle_forward(
         assert abs(got - want) <= 2e-2 * abs(want), (fam, got, want)
 
 
+def test_side_stream_training_steps_soak_against_the_one_stream_call():
+    """50 gradient calls at the bench's training shape (n_block = 8, 8 crops of 6400 samples) with the
+    side stream on - each block's weight-gradient GEMMs under the next block's backward chain, kernels of both queues
+    sharing CUs - every one bit-identical, loss and all 181 M gradient elements, to the same call on ONE stream."""
+    from tf_flowavenet_amd import weights as W
+    from tf_flowavenet_amd.hparams import default_hparams
+    from tf_flowavenet_amd.training import GradEngine
+    hp = default_hparams()
+    b, t = hp.batch_size, hp.max_time_steps
+    p = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in W.synthetic_params(hp, 1234, actnorm="random").items()}
+    inp = W.synthetic_inputs(hp, b, t)
+    x, c = torch.from_numpy(inp["x"]).reshape(b, t).cuda(), torch.from_numpy(inp["c"]).cuda()
+    shp = W.param_shapes(hp)
+    total = sum(int(np.prod(v)) for v in shp.values())
+
+    def views(flat):
+        out, off = {}, 0
+        for k, v in shp.items():
+            n = int(np.prod(v))
+            out[k] = flat[off:off + n].view(*v)
+            off += n
+        return out
+
+    ref = {}
+    for side, steps in (("0", 2), ("1", 50)):
+        os.environ["FWN_TRAIN_SIDE"] = side
+        try:
+            eng = GradEngine(hp)
+            flat = torch.zeros(total, dtype=torch.float32, device="cuda")
+            go = views(flat)
+            bad = 0
+            for _ in range(steps):
+                flat.zero_()                         # (the dead res_conv gradients are written once per engine: zeros either way)
+                loss, lp, ld, _ = eng.loss_and_grads(p, x, c, grad_out=go)
+                torch.cuda.synchronize()
+                if side == "0":
+                    ref = dict(loss=float(loss), lp=float(lp), ld=float(ld), flat=flat.clone())
+                else:
+                    bad += int(not ((float(loss), float(lp), float(ld)) == (ref["loss"], ref["lp"], ref["ld"])
+                                    and torch.equal(flat, ref["flat"])))
+            assert bad == 0, "%d of %d side-stream calls differ from the one-stream call" % (bad, steps)
+        finally:
+            os.environ.pop("FWN_TRAIN_SIDE", None)
+    assert bool(torch.isfinite(ref["flat"]).all())
+
+
 def test_an_exception_in_the_block_callback_stops_the_call_and_reaches_the_caller():
     """ctypes prints and drops an exception raised inside a callback.  A failed all-reduce / graph cut in
     on_block_done must stop the C sequencer (FWN_ERR_CALLBACK) and be re-raised by GradEngine, with one stream and two."""
