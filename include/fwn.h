@@ -457,7 +457,11 @@ typedef struct fwn_train_desc {
     fwn_conv_grad up[FWN_MAX_UPSAMPLE];         /* V [2s][3], scalar g; dV, dg, db (bias)                       */
     const float* an_logdet;                     /* unused (the tail's log-det partials carry the ActNorm terms); any
                                                    non-NULL device pointer */
-    int32_t zero_dead_res, reserved;            /* != 0: also zero the gradients of the dead last-layer res_conv */
+    int32_t zero_dead_res;                      /* != 0: also zero the gradients of the dead last-layer res_conv */
+    /* != 0 (with side_stream): nothing consumes a block's gradients before the end of the call (one rank: no all-reduce),
+     * so the side stream is NOT joined into `stream` block by block - the data-gradient chain never waits for the weight
+     * gradients - but once, behind block 0; on_block_done(n_block - 1 .. 0) are then all called at that point, in order. */
+    int32_t defer_block_done;
     /* Optional second hipStream_t (NULL: one stream).  The weight gradients of block i (grouped TN GEMMs + weight-norm
      * backward) and its conditioning-gradient GEMMs then run on it under the data-gradient chain of block i - 1 and are
      * joined into `stream` before on_block_done(i); the workspace grows by per-flow copies of the temporaries they

@@ -77,7 +77,7 @@ class TrainDesc(C.Structure):
     _fields_ = [("model", C.POINTER(ModelDesc)), ("flows", C.POINTER(FlowTrainDesc)),
                 ("cond_rows", vp * 16), ("front_rows", vp * 16), ("zinv32", vp * 16), ("br", vp * 16), ("zcol", vp * 16),
                 ("up_bias_dev", vp * FWN_MAX_UPSAMPLE), ("up", ConvGrad * FWN_MAX_UPSAMPLE),
-                ("an_logdet", vp), ("zero_dead_res", i32), ("reserved", i32), ("side_stream", vp)]
+                ("an_logdet", vp), ("zero_dead_res", i32), ("defer_block_done", i32), ("side_stream", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/fwn.h declares.

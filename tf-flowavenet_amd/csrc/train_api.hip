@@ -480,10 +480,17 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         hipEvent_t e = evp->get();
         return e && hipEventRecord(e, side) == hipSuccess && hipStreamWaitEvent(st, e, 0) == hipSuccess;
     };
+    // fwn_train_desc.defer_block_done: no consumer of a block's gradients before the end of the call - the chain never
+    // waits for the side stream; ONE join behind block 0, then every block is reported (same order)
+    const bool defer = side && t->defer_block_done != 0;
     auto join_pending = [&]() -> bool {      // the block handed over last: join it into `st`, then report it
         if (pending_block < 0) return true;
+        if (defer && pending_block > 0) { pending_block = -1; return true; }
         if (!join_side()) return false;
-        if (on_block_done && on_block_done(user, pending_block) != 0) hook_failed = true;
+        if (defer) {
+            for (int b_ = md->n_block - 1; b_ >= 0 && !hook_failed; --b_)
+                if (on_block_done && on_block_done(user, b_) != 0) hook_failed = true;
+        } else if (on_block_done && on_block_done(user, pending_block) != 0) hook_failed = true;
         pending_block = -1;
         return true;
     };

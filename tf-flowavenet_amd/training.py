@@ -507,6 +507,8 @@ class GradEngine:
         # True: the caller refreshes the host-computed tables itself (``refresh_host_tables``) - a recorded
         # step keeps that device -> host -> device round trip outside its hipGraph
         self.external_host_tables = False
+        # True: no consumer of a block's gradients before the end of the call (fwn_train_desc.defer_block_done; slower, see _run)
+        self.defer_block_done = False
 
     def refresh_host_tables(self):
         """Host-computed small tables (only when the parameters are not views of one flat device vector: then
@@ -527,7 +529,8 @@ class GradEngine:
         if os.environ.get("FWN_TRAIN_SIDE", "1") == "0":
             return None
         if getattr(self, "_side", None) is None:            # an engine serves one device
-            self._side = torch.cuda.Stream(torch.device(dev))
+            prio = os.environ.get("FWN_TRAIN_SIDE_PRIO")       # developer switch (same-box A/B): HIP stream priority
+            self._side = torch.cuda.Stream(torch.device(dev), priority=int(prio)) if prio else torch.cuda.Stream(torch.device(dev))
         return self._side
 
     def _call(self, name, *args):
@@ -650,6 +653,12 @@ class GradEngine:
         # the weight gradients of a block run on a second stream under the next block's chain (fwn.h fwn_train_desc.side_stream)
         side = self._side_stream(dev)
         td.side_stream = side.cuda_stream if side is not None else None
+        # fwn_train_desc.defer_block_done: with nothing to exchange the data-gradient chain need not wait for the side
+        # stream block by block.  Measured (round 4, same box, recorded step at 8 x 6400): 14.30 ms against 13.48 with
+        # the per-block joins - without them the chain's small launches queue behind ever more chip-filling weight-gradient
+        # GEMMs - so it stays off; FWN_TRAIN_DEFER=1 turns it on (same-box A/B)
+        defer = os.environ.get("FWN_TRAIN_DEFER")
+        td.defer_block_done = int(defer) if defer in ("0", "1") else int(bool(self.defer_block_done))
         wkey = (B, T, str(dev), bool(td.side_stream))
         if getattr(self, "_ws_key", None) != wkey:
             need = int(lib.fwn_train_workspace_bytes(C.byref(td), B, T))
@@ -758,7 +767,8 @@ class Trainer:
             cs = torch.empty(tuple(c.shape), dtype=torch.float32, device=dev)
             params, gv = self.opt.master_views(), self.opt.grad_views()
             segs, pool = [], torch.cuda.graph_pool_handle()
-            side = torch.cuda.Stream(dev)
+            mprio = os.environ.get("FWN_TRAIN_MAIN_PRIO")     # developer switch (same-box A/B)
+            side = torch.cuda.Stream(dev, priority=int(mprio)) if mprio else torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             self.engine.external_host_tables = True
             cur = [None]
