@@ -202,6 +202,15 @@ int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit
 int fwn_tail_partials(int M);
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
              int inverse, void* scratch, void* stream);
+/* The tail as the whole-model calls chain it (csrc/tail_chain.h), exposed for stage-level parity tests: out_b goes to
+ * xb_out (a third plane buffer: xb is left untouched) and, when `next` is given (the flow that runs after d: Ch <= 8,
+ * next->Wfront3 packed), next's front conv + ReLU (modules.py:144,164-165; forward: behind next's ActNorm) is computed in
+ * the same launch into h0_next [M][256] bf16.  partial (forward) receives fwn_tail_partials_chained(M, d->Ch, next != NULL)
+ * sums.  scratch as in fwn_tail.  Returns FWN_ERR_ARG where the tail at this shape cannot chain (fwn_tail_can_chain). */
+int fwn_tail_can_chain(const fwn_flow_desc* d, int M, int with_front);
+int fwn_tail_partials_chained(int M, int Ch, int with_front);
+int fwn_tail_chained(const fwn_flow_desc* d, const fwn_flow_desc* next, const void* o, float* xa, const float* xb, float* xb_out,
+                     void* h0_next, float* partial, int M, int Ti, int inverse, void* scratch, void* stream);
 /* The same tail as the training step runs it (forward direction): it also keeps what the backward needs -
  * save_s = S = ReLU(skip sum) and save_u = U = ReLU(final conv), bf16 [M][256] in natural channel order, and
  * save_z = Z = U Wz + bz, fp32 [M][2 Ch] (log_s channels then t channels, plane order; before the exp(3 scale) factor).

@@ -149,6 +149,9 @@ SIGNATURES = {
     "fwn_actnorm_from_moments": (C.c_int, [vp, C.c_int, vp, vp]),
     "fwn_front": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "fwn_gate": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "fwn_tail_can_chain": (C.c_int, [C.POINTER(FlowDesc), C.c_int, C.c_int]),
+    "fwn_tail_partials_chained": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "fwn_tail_chained": (C.c_int, [C.POINTER(FlowDesc), C.POINTER(FlowDesc), vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "fwn_gate_stream_bytes": (i64, [C.c_int]),
     "fwn_pack_gate_stream": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_gate_stream_rows": (C.c_int, []),

@@ -294,6 +294,36 @@ int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float*
     return check_launch("fwn_tail");
 }
 
+int fwn_tail_can_chain(const fwn_flow_desc* d, int M, int with_front) {
+    if (!d || M <= 0 || !fwn_tail_chain_xb_out(M, d->npt)) return 0;
+    return with_front ? (fwn_tail_chain_front(M, d->Ch, d->npt) ? 1 : 0) : 1;
+}
+int fwn_tail_partials_chained(int M, int Ch, int with_front) { return M > 0 ? fwn_tail_npartials_chain(M, Ch, with_front != 0) : 0; }
+int fwn_tail_chained(const fwn_flow_desc* d, const fwn_flow_desc* next, const void* o, float* xa, const float* xb, float* xb_out,
+                     void* h0_next, float* partial, int M, int Ti, int inverse, void* scratch, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    if (next && (rc = check_desc(next))) return rc;
+    REQUIRE(o && xa && xb && xb_out && xb_out != xb && M > 0 && Ti > 0 && M % Ti == 0, "fwn_tail_chained: bad argument");
+    REQUIRE(fwn_tail_can_chain(d, M, next != nullptr), "fwn_tail_chained: the tail at M=%d, Ch=%d cannot chain%s", M, d->Ch, next ? " a front conv" : "");
+    REQUIRE(!next || (h0_next && ALIGNED16(h0_next) && next->Wfront3 && next->kf3 > 0 && next->Ch == d->Ch),
+            "fwn_tail_chained: next needs Wfront3 / kf3, the same Ch, and h0_next");
+    REQUIRE(!fwn_tail_is_split(M) || scratch, "fwn_tail_chained: M=%d runs the N-split tail: pass scratch [2][M][256] bf16", M);
+    fwn_tail_chain tc;
+    memset(&tc, 0, sizeof(tc));
+    tc.xb_out = xb_out;
+    if (next) {
+        tc.h0_next = h0_next;
+        tc.Wfn = next->Wfront3; tc.bfn = next->bfront; tc.an_next = inverse ? nullptr : next->an; tc.kfn = next->kf3;
+    }
+    tc.Ti = Ti;
+    // (xb is read only; the launcher's xb parameter is not written when xb_out is given)
+    fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero, d->ezero, d->an, xa,
+                    const_cast<float*>(xb), inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, scratch,
+                    scratch ? (char*)scratch + (size_t)M * 512 : nullptr, &tc, (hipStream_t)stream);
+    return check_launch("fwn_tail_chained");
+}
+
 int fwn_tail_train(const fwn_flow_desc* d, const void* o, int64_t o_stride, float* xa, float* xb, float* partial, int M,
                    void* save_s, void* save_u, float* save_z, void* stream) {
     int rc = check_desc(d);

@@ -386,6 +386,8 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 const long o_stride = L > 1 ? (long)(((const char*)s.o[1] - (const char*)s.o[0]) / 2) : 0;
                 for (int l = 1; l < L; ++l)
                     TREQUIRE((const char*)s.o[l] == (const char*)s.o[0] + (size_t)l * o_stride * 2, "fwn_train_loss_and_grads: o buffers not evenly spaced");
+                // the tail addresses o through ONE 32-bit buffer descriptor (byte span of all L layers, as fwn_tail_train checks)
+                TREQUIRE(((long)(L - 1) * o_stride + m * 256) * 2 < (1L << 31), "fwn_train_loss_and_grads: o rows of a flow span %ld bytes: beyond the tail's 32-bit buffer offsets", ((long)(L - 1) * o_stride + m * 256) * 2);
                 fwn_tail_chain tc;
                 memset(&tc, 0, sizeof(tc));
                 tc.save_s = s.s_act; tc.save_u = s.u_act; tc.save_z = s.z;

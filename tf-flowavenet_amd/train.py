@@ -98,14 +98,11 @@ class Dataset:
         self._lru[m[0]] = None
         while len(self._lru) > self.MAX_OPEN:
             old, _ = self._lru.popitem(last=False)
-            gone = self._cache.pop(old)
-            for arr in gone:            # release the descriptor now, not when the garbage collector gets to it
-                mm = getattr(arr, "_mmap", None)
-                if mm is not None:
-                    try:
-                        mm.close()
-                    except (BufferError, ValueError):
-                        pass            # a caller still holds a view: the map goes with its last reference
+            # Dropping the pair releases the descriptors: a np.memmap holds a buffer export on its mmap object (an explicit
+            # mmap.close() raises BufferError while the array exists), so the map and its file descriptor go when CPython
+            # drops the LAST reference to the arrays - here, unless a caller kept a view.  _batch() copies its crops out
+            # (np.empty + slice assignment) and keeps none; tests/test_train_cli.py bounds the open descriptors.
+            del self._cache[old]
         return pair
 
     def _batch(self, metas):
