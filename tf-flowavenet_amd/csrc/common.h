@@ -38,6 +38,15 @@ __device__ __forceinline__ srd_t make_srd(const void* p, uint32_t bytes) {
 __device__ __forceinline__ void buf_load16_lds(srd_t s, uint32_t voff, unsigned char* dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(s, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
 }
+// The same with the non-temporal cache policy (aux = 2: nt).  For weight streams that ONE workgroup (or a handful) reads
+// once per pass - the small tiles of the late blocks: the guide's nt-weights row (issue -> landed -18 % from cold caches);
+// never for slices every CU re-reads from L2 (the big tiles).  FWN_NT_SMALL (developer switch) turns it on.
+#ifndef FWN_NT_SMALL
+#define FWN_NT_SMALL 0
+#endif
+__device__ __forceinline__ void buf_load16_lds_nt(srd_t s, uint32_t voff, unsigned char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s, (lds_ptr_t)dst, 16, voff, 0, 0, FWN_NT_SMALL ? 2 : 0);
+}
 
 // Epilogue stores / loads through a buffer descriptor: rows past the end of the matrix (last
 // tile) fall outside the descriptor and are dropped / read as zero by the hardware range check,

@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void front_mfma_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = 8 * (wave + 4 * j) + (lane >> 3);
-            buf_load16_lds(sw, (uint32_t)((n0 + r) * 6 * CH + q * 64 + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2u,
-                           lds + (q % D) * B_SLOT + (wave + 4 * j) * 1024);
+            buf_load16_lds_nt(sw, (uint32_t)((n0 + r) * 6 * CH + q * 64 + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2u,
+                              lds + (q % D) * B_SLOT + (wave + 4 * j) * 1024);
         }
     };
 #pragma unroll
@@ -651,6 +651,7 @@ struct ResProb {
 
 // ---- conditioning projection hoisted out of the flow chain: P = c_a @ Wc -------------------
 struct CondProb {
+    static constexpr bool NT_B = true;    // K = cin up to 10240: the weight rows are streamed once by a few row tiles (FWN_NT_SMALL)
     static constexpr bool A_DMA = true;
     static constexpr bool ALLOW_256 = false;
     const bf16* ca;       // [M][cin]

@@ -110,6 +110,9 @@ template <class P> struct prob_lds_epi<P, decltype((void)P::LDS_EPI)> { static c
 // pieces, so the first ring wait also covers them (everything of the prologue lands together); the compiler's own wait
 // sits at their first use, after the loop.  Big tiles keep their loads in the epilogue: ahead of the K loop of an HBM-bound
 // launch they compete with its LDS-DMA stream (res layer of block 0: 21.0 -> 24.7 us).
+// A problem whose B operand (weights) is a long stream that few workgroups read once declares NT_B (hoisted conditioning)
+template <class P, class = void> struct prob_nt_b { static constexpr bool value = false; };
+template <class P> struct prob_nt_b<P, decltype((void)P::NT_B)> { static constexpr bool value = P::NT_B; };
 template <class P, class = void> struct prob_prefetch { static constexpr bool value = false; };
 template <class P> struct prob_prefetch<P, decltype((void)P::PREFETCH)> { static constexpr bool value = P::PREFETCH; };
 
@@ -187,8 +190,13 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
                            la + (wave + NWV * j) * 1024);
         } else {
             const int jb = j - PA;
-            buf_load16_lds(p.b_srd(cc), p.b_voff(cc, n0 + brow[jb < PB ? jb : 0], bc[jb < PB ? jb : 0]),
-                           la + A_BYTES + (wave + NWV * jb) * 1024);
+            // small tiles (KSP > 1: a handful of workgroups per launch): the weight rows are read once -> nt (FWN_NT_SMALL)
+            if constexpr (KSP > 1 || prob_nt_b<Prob>::value)
+                buf_load16_lds_nt(p.b_srd(cc), p.b_voff(cc, n0 + brow[jb < PB ? jb : 0], bc[jb < PB ? jb : 0]),
+                                  la + A_BYTES + (wave + NWV * jb) * 1024);
+            else
+                buf_load16_lds(p.b_srd(cc), p.b_voff(cc, n0 + brow[jb < PB ? jb : 0], bc[jb < PB ? jb : 0]),
+                               la + A_BYTES + (wave + NWV * jb) * 1024);
         }
     };
     auto issue = [&](int q) {

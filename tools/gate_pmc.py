@@ -55,9 +55,10 @@ def main():
             continue
         for r in csv.DictReader(open(files[0])):
             name = r["Kernel_Name"]
-            if "gate_halo_kernel" not in name:
+            if "gate_halo_kernel" not in name and "gate_rs_kernel" not in name:
                 continue
-            key = "fp8" if "true" in name.split("gate_halo_kernel")[1].split(">")[0] or "Lb1" in name else "bf16"
+            # bf16: the register-streamed kernel (gate_rs_kernel, round 4) at this shape; fp8: the tap-sharing tile's FP8 form
+            key = "bf16" if "gate_rs_kernel" in name else ("fp8" if "true" in name.split("gate_halo_kernel")[1].split(">")[0] or "Lb1" in name else "bf16_halo")
             a = agg.setdefault(key, collections.defaultdict(lambda: [0.0, 0]))
             a[r["Counter_Name"]][0] += float(r["Counter_Value"])
             a[r["Counter_Name"]][1] += 1
@@ -66,9 +67,9 @@ def main():
     raw = []
     for key, cs in agg.items():
         means = {c: v / n for c, (v, n) in cs.items()}
-        raw.append("%s gate_halo_kernel<256,256> (M = 64512, 504 workgroups), per launch: %s" % (key, json.dumps({c: round(v) for c, v in means.items()})))
+        raw.append("%s %s (M = 64512, 504 workgroups), per launch: %s" % (key, "gate_rs_kernel<5>" if key == "bf16" else "gate_halo_kernel<256,256>", json.dumps({c: round(v) for c, v in means.items()})))
         if key == "bf16" and "FETCH_SIZE" in means and "WRITE_SIZE" in means:
-            rec = {"kernel": "gate_halo_kernel<256,256,GateProb>", "rows": 64512, "fetch_size_kb": means["FETCH_SIZE"],
+            rec = {"kernel": "gate_rs_kernel<5>", "rows": 64512, "fetch_size_kb": means["FETCH_SIZE"],
                    "write_size_kb": means["WRITE_SIZE"], "traffic_bytes": int((2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024),
                    "source_sha": bench.gate_source_hash(),
                    "source": "tools/gate_pmc.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section"}

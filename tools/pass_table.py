@@ -31,7 +31,7 @@ def block_flop(i, samples):
 def stage_of(name):
     if name.startswith("front_valu") or name.startswith("front_mfma") or name.startswith("xprep") or "FrontRingProb" in name or "FrontProb" in name:
         return "front"
-    if name.startswith("gate_halo") or "GateProb" in name:
+    if name.startswith("gate_halo") or name.startswith("gate_rs") or "GateProb" in name:
         return "gate"
     if "ResProb" in name:
         return "res"
