@@ -290,14 +290,16 @@ def test_gate_stage_kernel_matches_oracle(full_model, b, ti, layer):
     assert err.max() < 3e-2 and err.mean() < 2e-3, (err.max(), err.mean(), np.unravel_index(err.argmax(), err.shape))
 
 
-@pytest.mark.parametrize("blk,b,ti,layer", [(0, 26, 1000, 0), (0, 4, 8064, 1), (1, 8, 4032, 0), (1, 25, 1000, 1), (1, 97, 256, 1)])
+@pytest.mark.parametrize("blk,b,ti,layer", [(0, 26, 1000, 0), (0, 4, 8064, 1), (1, 8, 4032, 0), (1, 25, 1000, 1), (1, 97, 256, 1),
+                                             (2, 8, 2016, 0), (2, 13, 1000, 1), (1, 4, 4032, 1), (0, 16, 1000, 0), (2, 49, 256, 0)])
 def test_gate_stream_kernel_against_tap_sharing_kernel(full_model, blk, b, ti, layer):
     """The register-streamed gate (gate_rs.h, through fwn_gate with the flow's fragment stream Wgs) against the tap-sharing
     tile (the same call with Wgs = NULL) on the same operands: both multiply the same bf16 values and differ only in the
     order of the fp32 accumulation (the stream takes the conditioning chunks after the first slice), so the bf16 outputs
     agree except for roundings at a tie - one output ulp, on a small fraction of the elements.
-    Blocks 0 and 1 (5 and 10 conditioning k-steps), both dilations, clip edges on and off tile boundaries, Ti = 256
-    (the smallest the kernel takes), partial last tiles."""
+    Blocks 0, 1 and 2 (5, 10 and 20 conditioning k-steps), the 256-row tiles (M >= 24 576) and the 128-row tiles (from
+    12 288 rows: block 2 of the 8-clip pass, blocks 0 / 1 of smaller batches), both dilations, clip edges on and off tile
+    boundaries, Ti = 256 (the smallest the kernel takes), partial last tiles."""
     hp, model, _, _, _ = full_model
     lib = _lib.load()
     d = model._packed.flow_descs[blk * hp.n_flow + 1]
@@ -323,7 +325,7 @@ def test_gate_stream_kernel_against_tap_sharing_kernel(full_model, blk, b, ti, l
 
 
 def test_gate_stream_is_what_the_model_runs(full_model):
-    """The packed model carries fragment streams for the blocks the kernel is built for (cin = 80, 160 at num_mels = 80) and
+    """The packed model carries fragment streams for the blocks the kernel is built for (cin = 80, 160, 320 at num_mels = 80) and
     none elsewhere; fwn_pack_gate_stream refuses a cin without a kernel; a descriptor that claims a stream for such a cin
     is rejected."""
     hp, model, _, _, _ = full_model
@@ -331,7 +333,7 @@ def test_gate_stream_is_what_the_model_runs(full_model):
     for i in range(hp.n_block):
         d = model._packed.flow_descs[i * hp.n_flow]
         have = lib.fwn_gate_stream_bytes(d.cin) > 0
-        assert have == (i < 2)
+        assert have == (i < 3)
         assert all(bool(d.Wgs[l]) == have for l in range(hp.n_layer))
     d3 = _lib.FlowDesc.from_buffer_copy(model._packed.flow_descs[3 * hp.n_flow])
     buf = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")

@@ -1026,7 +1026,7 @@ void fwn_launch_front(const float* xa, const float* an_a, const void* W, const v
 }
 
 // ---- register-streamed gate (gate_rs.h): one instantiation per number of conditioning k-steps
-#define FWN_RS_CASES(X) X(5) X(10)          // cin = 80 (block 0), 160 (block 1) at num_mels = 80
+#define FWN_RS_CASES(X) X(5) X(10) X(20)    // cin = 80 (block 0), 160 (block 1), 320 (block 2) at num_mels = 80
 long fwn_gate_stream_size(int cin) {
     const int nkc = (cin + 15) / 16;
 #define X(n) if (nkc == n) return 16L * RsPlan<n>::NK * 1024;
@@ -1034,10 +1034,12 @@ long fwn_gate_stream_size(int cin) {
 #undef X
     return 0;
 }
-int fwn_gate_stream_min_rows() { return FWN_TUNE(FWN_RS_MIN_ROWS, 24576); }
+// 256-row tiles from 24 576 rows on (x 2 channel halves: the chip is full, as for the 256 x 256 tap-sharing tile); 128-row
+// tiles from 12 288 rows on (block 2 of the 8-clip pass, block 1 of a 4-clip pass: 256-row tiles would leave half the CUs empty)
+int fwn_gate_stream_min_rows() { return FWN_TUNE(FWN_RS_MIN_ROWS, 12288); }
+static int gate_stream_mt(int M) { return M >= FWN_TUNE(FWN_RS_MIN_ROWS256, 24576) ? 8 : 4; }
 int fwn_gate_stream_ok(int M, int Ti, int dil, int cin, bool fused_cond, bool aux) {
-    // 256-row tiles x 2 channel halves must fill the chip (as for the 256 x 256 tap-sharing tile); a tile may cross one
-    // clip edge only; dilations whose halo fits the slot
+    // a tile may cross one clip edge only; dilations whose halo fits the slot
     return fused_cond && !aux && dil <= FWN_HALO_MAXDIL && Ti >= 256 && M >= fwn_gate_stream_min_rows() &&
            fwn_gate_stream_size(cin) != 0 && cin % 8 == 0;
 }
@@ -1053,10 +1055,18 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
                      hipStream_t st) {
     if (Wgs && fwn_gate_stream_ok(M, Ti, dil, cin, ca != nullptr && P == nullptr, aux != nullptr)) {
         GateRsArgs a{(const bf16*)h, (const bf16*)ca, (const bf16*)Wgs, bias, (bf16*)o, M, Ti, dil, cin};
-        const int nkc = (cin + 15) / 16, grid = ((M + 255) / 256) * 2;
-#define X(n) if (nkc == n) hipLaunchKernelGGL((gate_rs_kernel<n>), dim3(grid), dim3(512), 0, st, a);
-        FWN_RS_CASES(X)
+        const int nkc = (cin + 15) / 16;
+        if (gate_stream_mt(M) == 8) {
+            const int grid = ((M + 255) / 256) * 2;
+#define X(n) if (nkc == n) hipLaunchKernelGGL((gate_rs_kernel<n, 8>), dim3(grid), dim3(512), 0, st, a);
+            FWN_RS_CASES(X)
 #undef X
+        } else {
+            const int grid = ((M + 127) / 128) * 2;
+#define X(n) if (nkc == n) hipLaunchKernelGGL((gate_rs_kernel<n, 4>), dim3(grid), dim3(512), 0, st, a);
+            FWN_RS_CASES(X)
+#undef X
+        }
         return;
     }
     GateProb p{(const bf16*)h, (const bf16*)ca, P, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o,

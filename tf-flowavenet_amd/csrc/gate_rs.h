@@ -29,8 +29,10 @@
 #include "gemm_ring.h"
 #include <type_traits>
 
-#define FWN_RS_ZROW 280          // a slot row no item ever stages
-#define FWN_RS_PP 5              // DMA pieces per wave and item (8 waves x 5 x 8 rows = 320-row slots)
+// MT: 32-row time tiles per wave (8: 256-row workgroup tiles; 4: 128-row tiles for row counts at which 256-row tiles would
+// leave CUs empty).  DMA pieces per wave and item: 8 waves x PP x 8 rows must hold the tile, its halo and a zero row.
+__host__ __device__ constexpr int rs_pp(int mt) { return mt == 8 ? 5 : 3; }      // 320- / 192-row slots
+__host__ __device__ constexpr int rs_zrow(int mt) { return 32 * mt + 24; }       // a slot row no item ever stages
 
 #ifndef FWN_RABL
 #define FWN_RABL 0               // developer ablation (wrong results): 1 no weight loads after the prologue, 2 no epilogue, 3 no item barriers,
@@ -130,10 +132,11 @@ struct RsPlan {
 // k-step 0 those of item 1 in front of them), under every k-step g the load of W[g + R - 1] (slot 1, behind that slot's
 // pieces).  Laggers: [barrier 0], pieces of items 1 and 2, ring loads, [barrier 1]; under the first k-step of item i the
 // pieces of item i + 3.
-template <int NKC, int R, bool LAG>
+template <int NKC, int R, bool LAG, int MT>
 struct RsCount {
     using P = RsPlan<NKC>;
-    static constexpr int PP = FWN_RS_PP;
+    static constexpr int PP = rs_pp(MT);
+    static_assert(PP <= MT, "one piece per MFMA slot");
     // target: weight k-step tw (or -1) / last piece of item ti (or -1); query: the wait in front of k-step qg (or -1) /
     // the arrival at barrier qb (or -1)
     static constexpr int walk(int tw, int ti, int qg, int qb) {
@@ -154,7 +157,7 @@ struct RsCount {
                 const int g = P::item_first(i) + l;
                 if (!done && g == qg) { result = count; done = true; }
                 const bool pieces = l == 0 && i + ahead < P::NI;
-                for (int slot = 0; slot < 8; ++slot) {
+                for (int slot = 0; slot < MT; ++slot) {
                     if (!LAG && g == 0 && slot < PP) { if (count >= 0) ++count; if (1 == ti && slot == PP - 1) count = 0; }
                     if (pieces && slot < PP) { if (count >= 0) ++count; if (i + ahead == ti && slot == PP - 1) count = 0; }
                     if (slot == 1 && g + R - 1 < P::NK) { if (count >= 0) ++count; if (g + R - 1 == tw) count = 0; }
@@ -168,18 +171,18 @@ struct RsCount {
     static constexpr int wait_barrier(int b) { return walk(-1, b, -1, b); }   // own pieces of item b (b < NI)
 };
 
-template <int NKC, int R, bool LAG, class Stamp>
+template <int NKC, int R, bool LAG, int MT, class Stamp>
 __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char* lds, int wave, int lane, int m0, int grp, Stamp&& stamp) {
     using P = RsPlan<NKC>;
-    using C = RsCount<NKC, R, LAG>;
-    constexpr int NK = P::NK, NI = P::NI, PP = FWN_RS_PP;
+    using C = RsCount<NKC, R, LAG, MT>;
+    constexpr int NK = P::NK, NI = P::NI, PP = rs_pp(MT), BM = 32 * MT, ZROW = rs_zrow(MT);
     constexpr int SLOT = 8 * PP * 1024;
     const int lr = lane & 31, lh = lane >> 5;
     const int dil = p.dil, M = p.M, cin = p.cin;
 
     // bias -> accumulators, through the scalar cache (uniform addresses; a vector load here would make hipcc wait for
     // the whole prologue queue at its first use): register r is row (r & 3) + 8 (r >> 2) + 4 lh of the fragment
-    f32x16 acc[8];
+    f32x16 acc[MT];
     {
         const float* __restrict__ bias = p.bias;
 #pragma unroll
@@ -188,7 +191,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
             const float b1 = bias[rs_packed_row(grp, acc_row_c(r) + 4)];
             const float b = lh ? b1 : b0;
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) acc[mi][r] = b;
+            for (int mi = 0; mi < MT; ++mi) acc[mi][r] = b;
         }
     }
 
@@ -205,11 +208,11 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
         const int c = (lane & 7) ^ ((jrow >> 1) & 7);
         if constexpr (P::is_slice(item)) {
             const int g = m0 - dil + jrow;
-            const bool ok = (jrow < 256 + 2 * dil) & ((unsigned)g < (unsigned)M);
+            const bool ok = (jrow < BM + 2 * dil) & ((unsigned)g < (unsigned)M);
             buf_load16_lds(make_srd(p.h, hbytes), ok ? (uint32_t)(g * (FWN_HID * 2) + c * 16 + P::slice_of(item) * 128) : FWN_OOB, dst);
         } else {
             const int col = P::chunk_of(item) * 64 + c * 8;
-            const bool ok = (jrow < 256) & (m0 + jrow < M) & (col < cin);
+            const bool ok = (jrow < BM) & (m0 + jrow < M) & (col < cin);
             buf_load16_lds(make_srd(p.ca, cbytes), ok ? (uint32_t)((m0 + jrow) * cin + col) * 2u : FWN_OOB, dst);
         }
     };
@@ -232,7 +235,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
     // ---- activation fragment addresses: view v = tap 0..2 (slot row i + tap*dil, clip mask) or 3 (conditioning: row i).
     // The centre tap never leaves its clip: one base register + immediates, like the conditioning view; one integer
     // division per lane: a tile of 256 rows crosses at most one clip edge - the launcher requires Ti >= 256.
-    int rbe[2][8], xv[4];
+    int rbe[2][MT], xv[4];
     {
         const int t0 = (m0 + lr) % p.Ti;
 #pragma unroll
@@ -242,10 +245,10 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
             xv[v] = (lh ^ ((row >> 1) & 7)) << 4;
             if (v == 0 || v == 2) {
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
+                for (int mi = 0; mi < MT; ++mi) {
                     int t = t0 + mi * 32;
                     t = (t >= p.Ti ? t - p.Ti : t) + (v - 1) * dil;
-                    rbe[v >> 1][mi] = ((unsigned)t < (unsigned)p.Ti ? row + mi * 32 : FWN_RS_ZROW) * 128;
+                    rbe[v >> 1][mi] = ((unsigned)t < (unsigned)p.Ti ? row + mi * 32 : ZROW) * 128;
                 }
             }
         }
@@ -254,7 +257,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
     const int rb3 = lr * 128;                         // conditioning view: row i, no mask
     // activation fragments of the running k-step, refilled tile by tile for the next one right behind the MFMA that
     // reads them (single buffer: the next use of hf[mi] is a whole k-step away)
-    bf16x8 hf[8];
+    bf16x8 hf[MT];
     // (ko: the k-step's column offset, made opaque once per k-step - left to itself hipcc keeps every (view, ki, tile)
     // address of the whole unrolled loop in registers and spills)
     auto kofs = [&](int v, int ki) {
@@ -304,7 +307,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
             if (FWN_RABL != 5 || g == 0) {
                 const int ko = kofs(view, ki);
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) ldfrag1(la, view, ko, mi);
+                for (int mi = 0; mi < MT; ++mi) ldfrag1(la, view, ko, mi);
             }
         }
         constexpr int nview = slice ? (l + 1) >> 2 : 3, nki = slice ? (l + 1) & 3 : l + 1;
@@ -312,7 +315,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
         __builtin_amdgcn_sched_barrier(0);
         // one MFMA per slot, each followed by at most one other instruction group (an in-order wave can only fill the
         // issue cycles behind the MFMA it has just issued)
-        rs_static_for<8>([&](auto MI) {
+        rs_static_for<MT>([&](auto MI) {
             constexpr int mi = decltype(MI)::value;
             acc[mi] = mfma32(wq[g % R], hf[mi], acc[mi]);
             if constexpr (!last && FWN_RABL != 5) ldfrag1(la, nview, kon, mi);
@@ -330,7 +333,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
     if (FWN_RABL == 2) {
         float s = 0.0f;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += acc[mi][r];
         if (s != 12345.678f) return;
@@ -341,7 +344,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
     // row: ONE 16-byte store per lane and time tile instead of two 8-byte ones (the store tail is issue-bound).
     const srd_t so = make_srd(p.o, hbytes);
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
+    for (int mi = 0; mi < MT; ++mi) {
         const int row = m0 + mi * 32 + lr;
         const uint32_t voff = row < M ? (uint32_t)(row * FWN_HID + grp * 16 + 8 * lh) * 2u : FWN_OOB;
         uint32_t w[2][2];
@@ -373,24 +376,25 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
 #ifndef FWN_RS_R
 #define FWN_RS_R 6
 #endif
-template <int NKC, int R = FWN_RS_R>
+template <int NKC, int MT = 8, int R = FWN_RS_R>
 __global__ __launch_bounds__(512) void gate_rs_kernel(GateRsArgs p) {
     static_assert(R >= 3 && R <= 12, "ring depth");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * FWN_RS_PP * 1024];
+    static_assert(MT == 8 || MT == 4, "256- or 128-row tiles");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * rs_pp(MT) * 1024];
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = wg >> 1, tile_n = wg & 1;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = tile_m * 256;
+    const int m0 = tile_m * (32 * MT);
     const int grp = tile_n * 8 + wave;                // channel group: 16 channels
     RS_STAMP(0); RS_STAMP_RT(30);
 #ifdef FWN_RS_PRIO
     if (wave >= 4) __builtin_amdgcn_s_setprio(FWN_RS_PRIO);
 #endif
     auto stamp = [&](int i) { RS_STAMP(i); };
-    if (wave >= 4) gate_rs_wave<NKC, R, true>(p, lds, wave, lane, m0, grp, stamp);
-    else gate_rs_wave<NKC, R, false>(p, lds, wave, lane, m0, grp, stamp);
+    if (wave >= 4) gate_rs_wave<NKC, R, true, MT>(p, lds, wave, lane, m0, grp, stamp);
+    else gate_rs_wave<NKC, R, false, MT>(p, lds, wave, lane, m0, grp, stamp);
     RS_STAMP(21); RS_STAMP_RT(31);
 }
 

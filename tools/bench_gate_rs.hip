@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&Wg, 16ull * (48 + nkc) * 1024));
         if (nkc == 5) hipLaunchKernelGGL(gate_stream_pack_kernel<5>, dim3(256), dim3(256), 0, 0, (const bf16*)Wd, (const bf16*)Wc, kcpad, (bf16*)Wg);
         else if (nkc == 10) hipLaunchKernelGGL(gate_stream_pack_kernel<10>, dim3(256), dim3(256), 0, 0, (const bf16*)Wd, (const bf16*)Wc, kcpad, (bf16*)Wg);
+        else if (nkc == 20) hipLaunchKernelGGL(gate_stream_pack_kernel<20>, dim3(256), dim3(256), 0, 0, (const bf16*)Wd, (const bf16*)Wc, kcpad, (bf16*)Wg);
         else { printf("no instantiation for cin %d\n", cin); return 1; }
         GateProb p{(const bf16*)h, (const bf16*)ca, nullptr, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o_ref, M, Ti, dil, cin, kcpad};
         GateRsArgs a{(const bf16*)h, (const bf16*)ca, (const bf16*)Wg, bias, (bf16*)o_new, M, Ti, dil, cin};
@@ -56,10 +57,22 @@ int main(int argc, char** argv) {
         unsigned long long* stamps; CK(hipMalloc(&stamps, (size_t)t256 * 2 * RS_NW * 32 * 8)); CK(hipMemset(stamps, 0, (size_t)t256 * 2 * RS_NW * 32 * 8));
         a.stamps = stamps;
 #endif
-        auto run_ref = [&] { hipLaunchKernelGGL((gate_halo_kernel<256, 256, GateProb>), dim3(t256 * 2), dim3(1024), 0, 0, p, 2); };
+        const bool big = t256 * 2 >= 192;         // the library's choice: 256 x 256 tap-sharing tile / 256-row stream tile
+        const int t128 = (M + 127) / 128;
+        auto run_ref = [&] {
+            if (big) hipLaunchKernelGGL((gate_halo_kernel<256, 256, GateProb>), dim3(t256 * 2), dim3(1024), 0, 0, p, 2);
+            else hipLaunchKernelGGL((gate_halo_kernel<256, 128, GateProb>), dim3(t256 * 4), dim3(1024), 0, 0, p, 4);
+        };
         auto run_new = [&] {
-            if (cin == 80) hipLaunchKernelGGL((gate_rs_kernel<5>), dim3(t256 * 2), dim3(512), 0, 0, a);
-            else hipLaunchKernelGGL((gate_rs_kernel<10>), dim3(t256 * 2), dim3(512), 0, 0, a);
+            if (big) {
+                if (nkc == 5) hipLaunchKernelGGL((gate_rs_kernel<5, 8>), dim3(t256 * 2), dim3(512), 0, 0, a);
+                else if (nkc == 10) hipLaunchKernelGGL((gate_rs_kernel<10, 8>), dim3(t256 * 2), dim3(512), 0, 0, a);
+                else hipLaunchKernelGGL((gate_rs_kernel<20, 8>), dim3(t256 * 2), dim3(512), 0, 0, a);
+            } else {
+                if (nkc == 5) hipLaunchKernelGGL((gate_rs_kernel<5, 4>), dim3(t128 * 2), dim3(512), 0, 0, a);
+                else if (nkc == 10) hipLaunchKernelGGL((gate_rs_kernel<10, 4>), dim3(t128 * 2), dim3(512), 0, 0, a);
+                else hipLaunchKernelGGL((gate_rs_kernel<20, 4>), dim3(t128 * 2), dim3(512), 0, 0, a);
+            }
         };
         run_ref(); run_new();
         CK(hipDeviceSynchronize());
@@ -95,8 +108,8 @@ int main(int argc, char** argv) {
             }
         }
         std::sort(tr.begin(), tr.end()); std::sort(tn.begin(), tn.end());
-        printf("  halo 256x256 : median %.2f us (min %.2f)  %.1f TFLOP/s\n", tr[3], tr[0], flops / (tr[3] * 1e-6) / 1e12);
-        printf("  rs   %d waves   : median %.2f us (min %.2f)  %.1f TFLOP/s\n", RS_NW, tn[3], tn[0], flops / (tn[3] * 1e-6) / 1e12);
+        printf("  tap-sharing  : median %.2f us (min %.2f)  %.1f TFLOP/s\n", tr[3], tr[0], flops / (tr[3] * 1e-6) / 1e12);
+        printf("  reg-streamed : median %.2f us (min %.2f)  %.1f TFLOP/s\n", tn[3], tn[0], flops / (tn[3] * 1e-6) / 1e12);
 #ifdef FWN_RS_STAMP
         {
             std::vector<unsigned long long> st((size_t)t256 * 2 * RS_NW * 32);
