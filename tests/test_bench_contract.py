@@ -70,8 +70,9 @@ def test_traffic_is_only_reported_for_the_current_kernel_sources(tmp_path, monke
 
 
 def test_path_roofline_quotes_committed_profiles_only_for_the_current_kernel_sources(tmp_path, monkeypatch):
-    """the bench line carries the PATH's fractions.  The live part needs only the timings; the per-block
-    table and the whole-pass HBM bytes come from profiles/ and must be dropped once a kernel source changed."""
+    """the bench line carries the PATH's fractions.  The whole-pass fractions and (round 4)
+    the per-block table are measured live (the table is handed in: bench.block_table); the launch counts attached to it
+    and the whole-pass HBM bytes come from profiles/ and must be dropped once a kernel source changed."""
     import json
     import bench
     from tf_flowavenet_amd.hparams import default_hparams
@@ -88,13 +89,17 @@ def test_path_roofline_quotes_committed_profiles_only_for_the_current_kernel_sou
     (tmp_path / "profiles" / "r03_pass_traffic.json").write_text(json.dumps(
         {"source_sha": sha, "algorithmic_bytes": 882.5e6, "fwd": {"traffic_bytes": 4000000000, "ratio_to_algorithmic": 4.53},
          "inv": {"traffic_bytes": 3900000000, "ratio_to_algorithmic": 4.42}}))
-    r = bench.path_roofline(hp, 8, 16128, 4.0e-3, 4.1e-3)
+    live = lambda: {d: [{"block": i, "rows": 64512 >> i, "us": 90.0 + i, "gflop": 10.0, "mfma_frac": 0.04} for i in range(8)] for d in ("fwd", "inv")}
+    r = bench.path_roofline(hp, 8, 16128, 4.0e-3, 4.1e-3, live())
     flop = 16527360 * 8 * 16128
     assert abs(r["fwd"]["mfma_frac"] - flop / 4.0e-3 / 2.5e15) < 1e-12 and abs(r["fwd"]["frac_of_survey_bound"] - 853e-6 / 4.0e-3) < 1e-12
     assert abs(r["serial_pair_ms"] - 8.1) < 1e-9
-    assert len(r["blocks"]["fwd"]) == 8 and r["blocks"]["inv"][3]["us"] == 103.0
+    assert len(r["blocks"]["fwd"]) == 8 and r["blocks"]["inv"][3]["us"] == 93.0 and r["blocks"]["inv"][3]["launches"] == 30
+    assert r["blocks_source"].startswith("live")
     assert abs(r["hbm"]["fwd"]["gbs_at_this_pass"] - 1000.0) < 1e-6 and abs(r["hbm"]["fwd"]["hbm_frac"] - 0.125) < 1e-9
     (src / "b.h").write_text("// edited")
-    r = bench.path_roofline(hp, 8, 16128, 4.0e-3, 4.1e-3)
-    assert r["blocks"] is None and r["hbm"] is None and "no profile of the current kernel sources" in r["blocks_source"]
+    r = bench.path_roofline(hp, 8, 16128, 4.0e-3, 4.1e-3, live())
+    assert "launches" not in r["blocks"]["fwd"][0] and r["hbm"] is None
+    assert "no profile of the current kernel sources" in r["blocks_launch_counts_source"] and "no profile" in r["hbm_source"]
+    assert bench.path_roofline(hp, 8, 16128, 4.0e-3, 4.1e-3)["blocks"] is None
     assert bench.path_roofline(hp, 3, 999 * 256, 1e-3, 1e-3)["survey_bound_us"] is None      # no SURVEY bound for other shapes

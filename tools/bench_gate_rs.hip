@@ -29,6 +29,7 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 8;
     const int blk0 = argc > 2 ? atoi(argv[2]) : 0, blk1 = argc > 3 ? atoi(argv[3]) : 1;
     const int dil = argc > 4 ? atoi(argv[4]) : 1;
+    const int grid_max = argc > 5 ? atoi(argv[5]) : 1 << 30;     // e.g. 256: the experimental persistent form (one workgroup per CU)
     const int T = 16128;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -54,7 +55,7 @@ int main(int argc, char** argv) {
         GateRsArgs a{(const bf16*)h, (const bf16*)ca, (const bf16*)Wg, bias, (bf16*)o_new, M, Ti, dil, cin};
         const int t256 = (M + 255) / 256;
 #ifdef FWN_RS_STAMP
-        unsigned long long* stamps; CK(hipMalloc(&stamps, (size_t)t256 * 2 * RS_NW * 32 * 8)); CK(hipMemset(stamps, 0, (size_t)t256 * 2 * RS_NW * 32 * 8));
+        unsigned long long* stamps; CK(hipMalloc(&stamps, (size_t)1024 * RS_NW * 32 * 8)); CK(hipMemset(stamps, 0, (size_t)1024 * RS_NW * 32 * 8));
         a.stamps = stamps;
 #endif
         const bool big = t256 * 2 >= 192;         // the library's choice: 256 x 256 tap-sharing tile / 256-row stream tile
@@ -64,17 +65,20 @@ int main(int argc, char** argv) {
             else hipLaunchKernelGGL((gate_halo_kernel<256, 128, GateProb>), dim3(t256 * 4), dim3(1024), 0, 0, p, 4);
         };
         auto run_new = [&] {
+            const int nt = big ? t256 * 2 : t128 * 2, grid = nt < grid_max ? nt : grid_max;
+            // fewer workgroups than tiles: the persistent form (experimental); else one tile per workgroup (the product)
+#define RS_GO(n, mt) do { if (grid < nt) hipLaunchKernelGGL((gate_rs_kernel<n, mt, true>), dim3(grid), dim3(512), 0, 0, a, nt); \
+                          else hipLaunchKernelGGL((gate_rs_kernel<n, mt, false>), dim3(grid), dim3(512), 0, 0, a, nt); } while (0)
             if (big) {
-                if (nkc == 5) hipLaunchKernelGGL((gate_rs_kernel<5, 8>), dim3(t256 * 2), dim3(512), 0, 0, a);
-                else if (nkc == 10) hipLaunchKernelGGL((gate_rs_kernel<10, 8>), dim3(t256 * 2), dim3(512), 0, 0, a);
-                else hipLaunchKernelGGL((gate_rs_kernel<20, 8>), dim3(t256 * 2), dim3(512), 0, 0, a);
+                if (nkc == 5) RS_GO(5, 8); else if (nkc == 10) RS_GO(10, 8); else RS_GO(20, 8);
             } else {
-                if (nkc == 5) hipLaunchKernelGGL((gate_rs_kernel<5, 4>), dim3(t128 * 2), dim3(512), 0, 0, a);
-                else if (nkc == 10) hipLaunchKernelGGL((gate_rs_kernel<10, 4>), dim3(t128 * 2), dim3(512), 0, 0, a);
-                else hipLaunchKernelGGL((gate_rs_kernel<20, 4>), dim3(t128 * 2), dim3(512), 0, 0, a);
+                if (nkc == 5) RS_GO(5, 4); else if (nkc == 10) RS_GO(10, 4); else RS_GO(20, 4);
             }
         };
-        run_ref(); run_new();
+        if (getenv("RS_DEBUG")) printf("h %p ca %p Wd %p Wc %p Wg %p bias %p o_ref %p o_new %p\n", h, ca, Wd, Wc, Wg, (void*)bias, o_ref, o_new);
+        if (!getenv("RS_SKIP_REF")) run_ref();
+        CK(hipDeviceSynchronize());
+        run_new();
         CK(hipDeviceSynchronize());
         std::vector<unsigned short> r((size_t)M * 256), n((size_t)M * 256);
         CK(hipMemcpy(r.data(), o_ref, r.size() * 2, hipMemcpyDeviceToHost));
@@ -93,6 +97,34 @@ int main(int argc, char** argv) {
         printf("block %d  M=%d K=%d dil=%d: %zu of %zu outputs differ, %zu by more than one bf16 ulp (max |d| %.3g)", blk, M, 768 + cin, dil, bad, r.size(), bad2, maxd);
         if (bad2) printf(", first at row %zu ch %zu: ref %04x new %04x", first / 256, first % 256, r[first], n[first]);
         printf("\n");
+        if (getenv("RS_CONTEND")) {
+            // contention soak: the kernel beside a bandwidth hog on a second stream, every output against the quiet run
+            hipStream_t s2; CK(hipStreamCreate(&s2));
+            void *big1, *big2; CK(hipMalloc(&big1, 1u << 30)); CK(hipMalloc(&big2, 1u << 30));
+            std::vector<unsigned short> quiet((size_t)M * 256), cur((size_t)M * 256);
+            run_new(); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(quiet.data(), o_new, quiet.size() * 2, hipMemcpyDeviceToHost));
+            int badruns = 0;
+            for (int it = 0; it < 40; ++it) {
+                if (atoi(getenv("RS_CONTEND")) == 2) {     // the same kernel on a second stream (its own output): two launches share the chip
+                    GateRsArgs a2 = a; a2.o = (bf16*)big2;
+                    const int nt2 = big ? t256 * 2 : t128 * 2, grid2 = nt2 < grid_max ? nt2 : grid_max;
+                    for (int k = 0; k < 6; ++k) {
+                        if (big && nkc == 5 && grid2 < nt2) hipLaunchKernelGGL((gate_rs_kernel<5, 8, true>), dim3(grid2), dim3(512), 0, s2, a2, nt2);
+                        else if (big && nkc == 5) hipLaunchKernelGGL((gate_rs_kernel<5, 8, false>), dim3(grid2), dim3(512), 0, s2, a2, nt2);
+                    }
+                } else
+                for (int k = 0; k < 4; ++k) CK(hipMemcpyAsync(big2, big1, 1u << 30, hipMemcpyDeviceToDevice, s2));
+                CK(hipMemsetAsync(o_new, 0xee, (size_t)M * 512, 0));
+                run_new();
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(cur.data(), o_new, cur.size() * 2, hipMemcpyDeviceToHost));
+                size_t nb = 0, firstb = 0; int rmin = 1 << 30, rmax = -1, cmin = 999, cmax = -1;
+                for (size_t i = 0; i < cur.size(); ++i) if (cur[i] != quiet[i]) { if (!nb) firstb = i; ++nb; int r_ = (int)(i / 256), c_ = (int)(i % 256); rmin = std::min(rmin, r_); rmax = std::max(rmax, r_); cmin = std::min(cmin, c_); cmax = std::max(cmax, c_); }
+                if (nb) { ++badruns; if (badruns <= 8) printf("  contended run %d: %zu outputs differ; rows %d..%d (tiles %d..%d), channels %d..%d; first row %zu ch %zu\n", it, nb, rmin, rmax, rmin / 256, rmax / 256, cmin, cmax, firstb / 256, firstb % 256); }
+            }
+            printf("  contention soak: %d of 40 runs differ from the quiet run\n", badruns);
+        }
         const double flops = 2.0 * M * (768.0 + cin) * 512;
         std::vector<float> tr, tn;
         for (int round = 0; round < 7; ++round) {
@@ -110,14 +142,24 @@ int main(int argc, char** argv) {
         std::sort(tr.begin(), tr.end()); std::sort(tn.begin(), tn.end());
         printf("  tap-sharing  : median %.2f us (min %.2f)  %.1f TFLOP/s\n", tr[3], tr[0], flops / (tr[3] * 1e-6) / 1e12);
         printf("  reg-streamed : median %.2f us (min %.2f)  %.1f TFLOP/s\n", tn[3], tn[0], flops / (tn[3] * 1e-6) / 1e12);
-#ifdef FWN_RS_STAMP
+#if defined(FWN_RS_CHECK)
         {
-            std::vector<unsigned long long> st((size_t)t256 * 2 * RS_NW * 32);
+            CK(hipMemset(stamps, 0, 4096));
+            run_new();
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> st(8 + 4 * 60);
+            CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+            printf("  schedule check: %llu waits with fewer younger operations than the static count\n", st[0] & 0xffffffffull);
+            for (unsigned i = 0; i < std::min<unsigned long long>(st[0] & 0xffffffffull, 60); ++i)
+                printf("    wave %llu tile/g %llu: actual %llu static %llu\n", st[8 + 4 * i], st[9 + 4 * i], st[10 + 4 * i], st[11 + 4 * i]);
+        }
+#elif defined(FWN_RS_STAMP)
+        {
+            std::vector<unsigned long long> st((size_t)1024 * RS_NW * 32);
             CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
             // earliest start over all waves = time zero; print a few workgroups' waves: prologue, items, K loop end, epilogue end
-            unsigned long long t0 = ~0ull; for (size_t w = 0; w < (size_t)t256 * 2 * RS_NW; ++w) t0 = std::min(t0, st[w * 32]);
-            for (int wgi : {0, 1, 100, 255, 256, 300, t256 * 2 - 1}) {
-                if (wgi >= t256 * 2) continue;
+            unsigned long long t0 = ~0ull; for (size_t w = 0; w < (size_t)256 * RS_NW; ++w) if (st[w * 32]) t0 = std::min(t0, st[w * 32]);
+            for (int wgi : {0, 1, 100, 251, 255}) {
                 for (int w = 0; w < RS_NW; w += RS_NW - 1) {
                     const unsigned long long* q = &st[((size_t)wgi * RS_NW + w) * 32];
                     const double clk = (double)(q[21] - q[0]) / ((double)(q[31] - q[30]) * 10.0);   // cycles per ns: memrealtime ticks at 100 MHz
