@@ -324,6 +324,39 @@ def test_gate_stream_kernel_against_tap_sharing_kernel(full_model, blk, b, ti, l
     assert (diff != 0).mean() < 1e-3, (diff != 0).mean()
 
 
+@pytest.mark.parametrize("blk,b,ti,layer", [(0, 26, 1000, 0), (0, 8, 8064, 1), (1, 8, 4032, 0), (1, 97, 256, 1), (2, 16, 2016, 1), (2, 25, 1000, 0)])
+def test_co_resident_gate_against_tap_sharing_kernel(full_model, monkeypatch, blk, b, ti, layer):
+    """The experimental co-resident gate (gate_co.h: 4-wave workgroups, two per CU; FWN_GATE_CO=1, read per call) reads the
+    same fragment stream as the 8-wave register-streamed kernel in yet another accumulation order (32-channel sub-slices,
+    conditioning after the first): same bound against the tap-sharing tile, and repeated launches are bit-identical.
+    256-row tiles only (M >= 24 576), all three conditioning widths, both dilations, partial last tiles, Ti = 256."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    d = model._packed.flow_descs[blk * hp.n_flow + 1]
+    m = b * ti
+    assert d.Wgs[layer] and m >= 24576
+    d_plain = _lib.FlowDesc.from_buffer_copy(d)
+    for l in range(_lib.FWN_MAX_LAYERS):
+        d_plain.Wgs[l] = None
+    rng = np.random.default_rng(blk * 100 + b + layer)
+    h = torch.from_numpy(rng.standard_normal((m, 256)).astype(np.float32) * 0.5).cuda().to(torch.bfloat16)
+    ca = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for desc, co in ((d, "1"), (d, "1"), (d, "0"), (d_plain, "0")):
+        monkeypatch.setenv("FWN_GATE_CO", co)
+        o = torch.full((m + 8, 256), 7.0, device="cuda", dtype=torch.bfloat16)
+        _lib.check(lib.fwn_gate(C.byref(desc), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
+        assert bool((o[m:] == 7.0).all()), "the kernel wrote past row M"
+        outs.append(o[:m].float().cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    for other in (outs[2], outs[3]):
+        diff = np.abs(outs[0] - other)
+        assert diff.max() <= 4e-3, diff.max()
+        assert (diff != 0).mean() < 1e-3, (diff != 0).mean()
+    assert not np.array_equal(outs[0], outs[2]) or blk < 0     # the switch did select another kernel (orders differ)
+
+
 def test_gate_stream_is_what_the_model_runs(full_model):
     """The packed model carries fragment streams for the blocks the kernel is built for (cin = 80, 160, 320 at num_mels = 80) and
     none elsewhere; fwn_pack_gate_stream refuses a cin without a kernel; a descriptor that claims a stream for such a cin

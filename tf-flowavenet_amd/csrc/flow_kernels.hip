@@ -527,6 +527,7 @@ struct GateProb {
 
 #include "gate_halo.h"
 #include "gate_rs.h"
+#include "gate_co.h"
 
 // ---- residual 1x1: h' = (h + res_conv(o)) * sqrt(0.5), modules.py:126-128 ------------------
 struct ResProb {
@@ -1069,6 +1070,19 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
             return n & ~1;
         }();
         const int mt = gate_stream_mt(M);
+        // 256-row tiles, experimental: the co-resident form (gate_co.h: 4-wave workgroups of 256 rows x 64 channels, two per
+        // CU) reads the same stream.  Stand-alone it is 1 - 5 % faster per launch than the 8-wave form (tools/bench_gate_co.hip),
+        // inside the overlapped passes the step is unchanged (5.82 against 5.80 ms, three interleaved rounds on one box):
+        // FWN_GATE_CO=1 selects it, the product keeps the 8-wave form.
+        const char* co_env = getenv("FWN_GATE_CO");        // read per call: tests/test_gpu_parity.py flips it inside one process
+        const bool co = co_env && co_env[0] == '1';
+        if (mt == 8 && co && !persist) {
+            const int grid4 = ((M + 255) / 256) * 4;
+#define X(n) if (nkc == n) hipLaunchKernelGGL((gate_co_kernel<n>), dim3(grid4), dim3(256), 0, st, a);
+            FWN_RS_CASES(X)
+#undef X
+            return;
+        }
         const int ntiles = ((M + 32 * mt - 1) / (32 * mt)) * 2, grid = persist && ntiles > ncu ? ncu : ntiles;
 #define X(n)                                                                                                                   \
         if (nkc == n) {                                                                                                        \

@@ -1,0 +1,276 @@
+// Gated dilated layer, co-resident form (round 4, second half): the register-streamed wave of gate_rs.h in workgroups of
+// FOUR waves and 80 KiB of LDS, so that TWO workgroups share a CU.
+//
+// gate_rs.h hides one wave's prologue / epilogue / barrier bubbles under its SIMD partner by running the partners one
+// item apart inside ONE 160 KiB workgroup - which leaves the ends of a tile exposed (prologue 3.3 k cycles, leaders alone
+// in the first interval, laggers' epilogue 3.7 k: 42-44 k cycles per tile for 27 k of matrix-pipe time, DESIGN.md
+// section 3.1c) and the CU idle between two tiles.  Here the partner of a wave is a wave of ANOTHER workgroup: the two
+// workgroups of a CU are independent (no barrier couples them, the SIMD arbitrates by age), so whatever one of them is
+// doing that is not MFMA - DMA issue, the bubble behind a barrier, the tanh / sigmoid epilogue, its exit and the launch of
+// its successor - runs under the other's K loop, across tile boundaries as well.
+//   * A wave owns 256 time rows x 16 channels exactly as in gate_rs.h (8 accumulator tiles, weights streamed to a register
+//     ring from the same fragment stream Wgs, the same epilogue); a workgroup is 4 waves = 256 rows x 64 channels, four
+//     workgroups per 256-row slab.
+//   * 80 KiB of LDS hold four 20 KiB slots; the activations go through them in 32-channel sub-slices (64-byte rows,
+//     [m0 - dil, m0 + 256 + dil) + a zero row: 17 pieces of 16 rows) and the conditioning in 32-column chunks.  Item i lives
+//     in slot i % 4; its pieces are issued under the first k-step of item i - 3, behind the barrier that proves every wave
+//     has left item i - 4.  One barrier per item (8 + NCC per tile), four waves each.
+//   * The price: every activation row is staged by four workgroups instead of two (L2 -> LDS bytes per tile pair 776 KB
+//     against 600 KB) and the items are half as long.
+#pragma once
+#include "gate_rs.h"
+
+template <int NKC>
+struct CoPlan {
+    static constexpr int NCC = (NKC + 1) / 2;                // conditioning chunks of up to 32 columns
+    static constexpr int NI = 8 + NCC;                       // items: sub-slice 0, chunks 0 .. NCC-1, sub-slices 1 .. 7
+    static constexpr int NK = 48 + NKC;
+    static constexpr bool is_slice(int i) { return i == 0 || i > NCC; }
+    static constexpr int slice_of(int i) { return i == 0 ? 0 : i - NCC; }     // 32-channel sub-slice 0 .. 7
+    static constexpr int chunk_of(int i) { return i - 1; }
+    static constexpr int item_ks(int i) { return is_slice(i) ? 6 : (chunk_of(i) < NCC - 1 ? 2 : NKC - 2 * (NCC - 1)); }
+    static constexpr int item_first(int i) { int g = 0; for (int j = 0; j < i; ++j) g += item_ks(j); return g; }
+    static constexpr int item_of(int g) { int i = 0; while (g >= item_ks(i)) { g -= item_ks(i); ++i; } return i; }
+    // position of k-step g (this plan's order) in the fragment stream, which is in RsPlan<NKC> order: slice 0 (tap-major,
+    // 4 k-steps per tap), the conditioning k-steps, slices 1 .. 3
+    static constexpr int stream_pos(int g) {
+        const int i = item_of(g), l = g - item_first(i);
+        if (!is_slice(i)) return 12 + 2 * chunk_of(i) + l;
+        const int s = slice_of(i), tap = l >> 1, ki4 = (s & 1) * 2 + (l & 1), s64 = s >> 1;
+        return (s64 == 0 ? 0 : 12 + NKC + (s64 - 1) * 12) + tap * 4 + ki4;
+    }
+};
+
+// Younger vector-memory operations of the wave at each wait (program order walked at compile time, as RsCount):
+//   prologue: pieces of items 0, 1, 2; ring loads W(0 .. R-2)
+//   item i  : [wait own pieces of item i, barrier i]; k-steps; under the first k-step the pieces of item i + 3 (MFMA slots
+//             0 .. PP-1); under every k-step g (MFMA slot WSLOT) the load W(g + R - 1)
+template <int NKC, int R>
+struct CoCount {
+    using P = CoPlan<NKC>;
+    static constexpr int PP = 5, NI = P::NI, NK = P::NK, AHEAD = 3, WSLOT = 6;
+    static constexpr int walk(int tk, int ta, int qk, int qa) {     // target: 0 = W(ta) / 1 = last piece of item ta; query: 0 = wait of k-step qa / 1 = barrier qa
+        int count = -1, result = -1;
+        bool done = false;
+#define CO_W(k) do { if (count >= 0) ++count; if (tk == 0 && ta == (k)) count = 0; } while (0)
+#define CO_P(J) do { for (int j_ = 0; j_ < PP; ++j_) { if (count >= 0) ++count; if (tk == 1 && ta == (J) && j_ == PP - 1) count = 0; } } while (0)
+#define CO_P1(J, j_) do { if (count >= 0) ++count; if (tk == 1 && ta == (J) && (j_) == PP - 1) count = 0; } while (0)
+        for (int i = 0; i < AHEAD && i < NI; ++i) CO_P(i);
+        for (int k = 0; k < R - 1; ++k) CO_W(k);
+        for (int i = 0; i < NI; ++i) {
+            if (!done && qk == 1 && qa == i) { result = count; done = true; }
+            for (int l = 0; l < P::item_ks(i); ++l) {
+                const int g = P::item_first(i) + l;
+                if (!done && qk == 0 && qa == g) { result = count; done = true; }
+                for (int slot = 0; slot < 8; ++slot) {
+                    if (l == 0 && slot < PP && i + AHEAD < NI) CO_P1(i + AHEAD, slot);
+                    if (slot == WSLOT && g + R - 1 < NK) CO_W(g + R - 1);
+                }
+            }
+        }
+#undef CO_W
+#undef CO_P
+#undef CO_P1
+        return result;
+    }
+    static constexpr int wait_kstep(int g) { return walk(0, g, 0, g); }
+    static constexpr int wait_barrier(int i) { return walk(1, i, 1, i); }
+};
+
+#ifndef FWN_CO_R
+#define FWN_CO_R 6
+#endif
+#ifndef FWN_CABL
+#define FWN_CABL 0               // developer ablation (wrong results): 1 no weight loads after the prologue, 2 no epilogue, 3 no item barriers,
+                                 // 4 no DMA pieces after the prologue, 5 no fragment reads after an item's first
+#endif
+
+// NKC: conditioning k-steps of 16 (cin / 16 rounded up); R: ring stages of weight fragments per wave.
+// Grid: 4 ceil(M / 256) workgroups of 256 threads; workgroup w: rows 256 (w >> 2) .., channels 64 (w & 3) ..
+template <int NKC, int R = FWN_CO_R>
+__global__ __launch_bounds__(256, 2) void gate_co_kernel(GateRsArgs p) {
+    using P = CoPlan<NKC>;
+    using C = CoCount<NKC, R>;
+    constexpr int NK = P::NK, NI = P::NI, PP = C::PP, BM = 256, MT = 8, ZROW = 270, AHEAD = C::AHEAD;
+    constexpr int SLOT = 4 * PP * 1024;               // 20 pieces of 16 rows x 64 bytes
+    static_assert(R >= 3 && R <= 12, "ring depth");
+    static_assert(NI >= AHEAD, "the prologue stages three items");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * SLOT];
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int dil = p.dil, M = p.M, cin = p.cin;
+    const int grp = (wg & 3) * 4 + wave;              // channel group: 16 channels
+    const int m0 = (wg >> 2) * BM;
+#if defined(FWN_RS_STAMP) && !defined(FWN_RS_CHECK)
+#define CO_STAMP(i) do { if (lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CO_STAMP_RT(i) do { if (lane == 0) p.stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CO_STAMP(i) do { } while (0)
+#define CO_STAMP_RT(i) do { } while (0)
+#endif
+    CO_STAMP(0); CO_STAMP_RT(30);
+
+    // ---- DMA pieces: piece j of this wave = slot rows 16 (wave + 4 j) .. + 15, four 16-byte granules per row; the granule
+    // a lane fetches for its lane-linear LDS position is XOR-ed with (row >> 2) & 3 = (lane >> 4) & 3
+    const uint32_t hbytes = (uint32_t)((size_t)M * FWN_HID * 2);
+    const uint32_t cbytes = (uint32_t)((size_t)M * cin * 2);
+    const int prow = 16 * wave + (lane >> 2);
+    const int pc = (lane & 3) ^ ((lane >> 4) & 3);
+    auto issue_piece = [&](auto ITEM, int j) {
+        constexpr int item = decltype(ITEM)::value;
+        static_assert(item < NI, "no such item");
+        unsigned char* dst = lds + (item & 3) * SLOT + (wave + 4 * j) * 1024;
+        const int jrow = prow + 64 * j;
+        if constexpr (P::is_slice(item)) {
+            const int g = m0 - dil + jrow;
+            const bool ok = (jrow < BM + 2 * dil) & ((unsigned)g < (unsigned)M);
+            buf_load16_lds(make_srd(p.h, hbytes), ok ? (uint32_t)(g * (FWN_HID * 2) + P::slice_of(item) * 64 + pc * 16) : FWN_OOB, dst);
+        } else {
+            const int col = P::chunk_of(item) * 32 + pc * 8;
+            const bool ok = (jrow < BM) & (m0 + jrow < M) & (col < cin);
+            buf_load16_lds(make_srd(p.ca, cbytes), ok ? (uint32_t)((m0 + jrow) * cin + col) * 2u : FWN_OOB, dst);
+        }
+    };
+
+    // ---- weight stream of this wave: k-step g (this plan's order) -> ring stage g % R, read at its RsPlan position
+    const unsigned long long wbase = (unsigned long long)(uintptr_t)p.Wg + (unsigned long long)grp * NK * 1024;
+    const u32x4 wsrd = {(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wbase),
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wbase >> 32)) & 0xffffu,      // stride 0
+                        (uint32_t)(NK * 1024), 0x00020000u};
+    const uint32_t wl = (uint32_t)lane * 16u;
+    bf16x8 wq[R];
+    auto issue_w = [&](auto G) {
+        constexpr int g = decltype(G)::value, sp = P::stream_pos(g);
+        rs_wload<(sp * 1024) % 4096>(wq[g % R], wsrd, (uint32_t)(((sp * 1024) / 4096) * 4096), wl);
+    };
+
+    // bias -> accumulators, BEFORE the first asm statement with a memory clobber (behind one hipcc no longer proves the
+    // bias read-only, loads it with vector loads and drains the whole prologue queue - DMA pieces and ring loads - at their
+    // first use); register r is row (r & 3) + 8 (r >> 2) + 4 lh of the fragment
+    f32x16 acc[MT];
+    {
+        const float* __restrict__ bias = p.bias;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float b0 = bias[rs_packed_row(grp, acc_row_c(r))];
+            const float b1 = bias[rs_packed_row(grp, acc_row_c(r) + 4)];
+            const float b = lh ? b1 : b0;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][r] = b;
+        }
+    }
+
+    // ---- prologue (order = CoCount::walk)
+    rs_static_for<AHEAD>([&](auto I) {
+#pragma unroll
+        for (int j = 0; j < PP; ++j) issue_piece(I, j);
+    });
+    rs_static_for<R - 1>([&](auto G) { issue_w(G); });
+
+    // ---- activation fragment addresses: view v = tap 0..2 (slot row i + tap*dil, clip mask) or 3 (conditioning: row i)
+    int rbe[2][MT], xv[4];
+    {
+        const int t0r = (m0 + lr) % p.Ti;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int sh = v < 3 ? v * dil : 0;
+            const int row = lr + sh;
+            xv[v] = (lh ^ ((row >> 2) & 3)) << 4;
+            if (v == 0 || v == 2) {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    int tt = t0r + mi * 32;
+                    tt = (tt >= p.Ti ? tt - p.Ti : tt) + (v - 1) * dil;
+                    rbe[v >> 1][mi] = ((unsigned)tt < (unsigned)p.Ti ? row + mi * 32 : ZROW) * 64;
+                }
+            }
+        }
+    }
+    const int rb1 = (lr + dil) * 64;                  // centre tap: slot row i + dil, tile mi at + mi * 2048 (immediate)
+    const int rb3 = lr * 64;                          // conditioning view: row i, no mask
+    bf16x8 hf[MT];
+    auto kofs = [&](int v, int ki) {
+        int x = xv[v];
+        asm volatile("" : "+v"(x));
+        return (ki * 32) ^ x;
+    };
+    auto ldfrag1 = [&](const unsigned char* la, int v, int ko, int mi) {
+        hf[mi] = *(const bf16x8*)(la + (v == 1 ? rb1 + mi * 2048 : v == 3 ? rb3 + mi * 2048 : rbe[(v >> 1) & 1][mi]) + ko);
+    };
+
+    // ---- the K loop, every position a compile-time constant
+    rs_static_for<NK>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        constexpr int item = P::item_of(g), l = g - P::item_first(item);
+        constexpr bool slice = P::is_slice(item);
+        constexpr int view = slice ? l >> 1 : 3, ki = slice ? l & 1 : l;
+        constexpr bool firstk = l == 0, last = l + 1 == P::item_ks(item);
+        const unsigned char* la = lds + (item & 3) * SLOT;
+        rs_wwait<C::wait_kstep(g)>(wq[g % R]);
+        if constexpr (firstk) {
+            rs_vmwait<C::wait_barrier(item)>();
+            CO_STAMP(1 + item);
+            if (FWN_CABL != 3) FWN_RING_BARRIER();
+            const int ko = kofs(view, ki);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) ldfrag1(la, view, ko, mi);
+        }
+        constexpr int nview = slice ? (l + 1) >> 1 : 3, nki = slice ? (l + 1) & 1 : l + 1;
+        const int kon = last ? 0 : kofs(nview, nki);
+        __builtin_amdgcn_sched_barrier(0);
+        rs_static_for<MT>([&](auto MI) {
+            constexpr int mi = decltype(MI)::value;
+            acc[mi] = mfma32(wq[g % R], hf[mi], acc[mi]);
+            if constexpr (!last && FWN_CABL != 5) ldfrag1(la, nview, kon, mi);
+            if constexpr (firstk && mi < PP && item + AHEAD < NI && FWN_CABL != 4)
+                issue_piece(std::integral_constant<int, (item + AHEAD < NI ? item + AHEAD : 0)>{}, mi);
+            if constexpr (mi == C::WSLOT && g + R - 1 < NK && FWN_CABL != 1) issue_w(std::integral_constant<int, (g + R - 1 < NK ? g + R - 1 : 0)>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+    CO_STAMP(20);
+
+    bool skip_epilogue = false;
+    if (FWN_CABL == 2) {
+        float s = 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[mi][r];
+        skip_epilogue = s != 12345.678f;
+    }
+    // ---- epilogue: as gate_rs.h (one 16-byte store per lane and time tile)
+    if (!skip_epilogue) {
+        const srd_t so = make_srd(p.o, hbytes);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int row = m0 + mi * 32 + lr;
+            const uint32_t voff = row < M ? (uint32_t)(row * FWN_HID + grp * 16 + 8 * lh) * 2u : FWN_OOB;
+            uint32_t w[2][2];
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x16& a = acc[mi];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const f32x2 y = {rs_gated1(a[8 * q + 2 * d], a[8 * q + 4 + 2 * d]), rs_gated1(a[8 * q + 2 * d + 1], a[8 * q + 4 + 2 * d + 1])};
+                    w[q][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(y, bf16x2));
+                }
+            }
+            u32x4 out;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(w[0][d], w[1][d], false, false);
+                out[d] = sw[0];
+                out[2 + d] = sw[1];
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(out, so, voff, 0, 0);
+        }
+    }
+    CO_STAMP(21); CO_STAMP_RT(31);
+#undef CO_STAMP
+#undef CO_STAMP_RT
+}

@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
             if (big) hipLaunchKernelGGL((gate_halo_kernel<256, 256, GateProb>), dim3(t256 * 2), dim3(1024), 0, 0, p, 2);
             else hipLaunchKernelGGL((gate_halo_kernel<256, 128, GateProb>), dim3(t256 * 4), dim3(1024), 0, 0, p, 4);
         };
-        auto run_new = [&] {
+        auto run_rs = [&] {
             const int nt = big ? t256 * 2 : t128 * 2, grid = nt < grid_max ? nt : grid_max;
             // fewer workgroups than tiles: the persistent form (experimental); else one tile per workgroup (the product)
 #define RS_GO(n, mt) do { if (grid < nt) hipLaunchKernelGGL((gate_rs_kernel<n, mt, true>), dim3(grid), dim3(512), 0, 0, a, nt); \
@@ -75,6 +75,14 @@ int main(int argc, char** argv) {
                 if (nkc == 5) RS_GO(5, 4); else if (nkc == 10) RS_GO(10, 4); else RS_GO(20, 4);
             }
         };
+        auto run_co = [&] {
+            const int grid = t256 * 4;
+            if (nkc == 5) hipLaunchKernelGGL((gate_co_kernel<5>), dim3(grid), dim3(256), 0, 0, a);
+            else if (nkc == 10) hipLaunchKernelGGL((gate_co_kernel<10>), dim3(grid), dim3(256), 0, 0, a);
+            else hipLaunchKernelGGL((gate_co_kernel<20>), dim3(grid), dim3(256), 0, 0, a);
+        };
+        const bool use_co = getenv("RS_CO") != nullptr;     // the co-resident form (csrc/gate_co.h) as the "new" contender
+        auto run_new = [&] { if (use_co) run_co(); else run_rs(); };
         if (getenv("RS_DEBUG")) printf("h %p ca %p Wd %p Wc %p Wg %p bias %p o_ref %p o_new %p\n", h, ca, Wd, Wc, Wg, (void*)bias, o_ref, o_new);
         if (!getenv("RS_SKIP_REF")) run_ref();
         CK(hipDeviceSynchronize());
