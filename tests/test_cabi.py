@@ -168,3 +168,11 @@ def test_build_keeps_slp_vectorisation_off_and_the_valu_front_conv_free_of_swizz
     assert front, "front_valu_kernel not found in the code object"
     for b in front:
         assert "v_pk_mul_f32" not in b and "v_pk_add_f32" not in b and "v_pk_fma_f32" not in b
+
+
+def test_graft_entry_build_runs_and_checks_the_header_version():
+    """__graft_entry__.build() (the driver's "does it build" check): make is a no-op on an up-to-date tree, every symbol
+    binds, and the version assertion follows include/fwn.h (it once pinned a stale literal and failed after a bump)."""
+    import importlib
+    g = importlib.import_module("__graft_entry__")
+    g.build()
