@@ -145,6 +145,22 @@ def gate_roofline(model, hp, b, t, iters=200):
     sec = float(np.median(us)) * 1e-6
     flops = 2.0 * m * (768 + d.cin) * 512
     ach = flops / sec / 1e12
+    # the clock the chip holds inside this kernel: a diagnostic instantiation of the same kernel (fwn_gate_clock) stamps
+    # s_memtime / s_memrealtime at the start and end of every wave; launched right behind the timed launches (the chip is
+    # warm), median over waves.  The product kernel executes no stamp.
+    clock_ghz = None
+    if bool(d.Wgs[0]) and m >= 24576:
+        nwg = 2 * ((m + 255) // 256)
+        stamps = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device=dev)
+        for _ in range(group):
+            launch()
+        n = lib.fwn_gate_clock(C.byref(d), 0, h.data_ptr(), ca.data_ptr(), o.data_ptr(), m, ti, stamps.data_ptr(), st)
+        torch.cuda.synchronize()
+        if n == nwg:
+            sv = stamps.cpu().numpy().reshape(-1, 4).astype(np.float64)
+            ok = (sv[:, 3] > sv[:, 2]) & (sv[:, 1] > sv[:, 0])
+            if ok.any():
+                clock_ghz = float(np.median((sv[ok, 1] - sv[ok, 0]) / (sv[ok, 3] - sv[ok, 2]))) * 0.1     # reference ticks at 100 MHz
     traffic, traffic_source = gate_traffic(m)
     streamed = bool(d.Wgs[0]) and m >= lib.fwn_gate_stream_rows()
     kernel = ("gate_rs_kernel<5> (register-streamed weights, csrc/gate_rs.h)" if streamed
@@ -153,7 +169,9 @@ def gate_roofline(model, hp, b, t, iters=200):
             "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
             "traffic": traffic, "traffic_source": traffic_source, "launch_us": sec * 1e6, "flop_per_launch": flops,
             "rows": m, "timing": "median over %d groups of %d back-to-back launches, one HIP event pair per group" % (ngroups, group),
-            "launch_us_min": float(us[0]), "launch_us_max": float(us[-1]), "launch_us_single_event_pair": single_us}
+            "launch_us_min": float(us[0]), "launch_us_max": float(us[-1]), "launch_us_single_event_pair": single_us,
+            # in-kernel shader clock (fwn_gate_clock) and the fraction of the peak AT THAT CLOCK (datasheet peak x clock / 2.4 GHz)
+            "clock_ghz": clock_ghz, "frac_at_clock": (ach / (MFMA_PEAK_TFLOPS * clock_ghz / 2.4)) if clock_ghz else None}
 
 
 GATE_SOURCES = ("gate_rs.h", "gate_halo.h", "gemm_ring.h", "common.h", "flow_kernels.hip")

@@ -151,6 +151,14 @@ typedef struct fwn_flow_desc {
 int64_t fwn_gate_stream_bytes(int cin);
 int fwn_pack_gate_stream(const void* Wd, const void* Wc, int cin, int kcpad, void* out, void* stream);
 int fwn_gate_stream_rows(void);
+/* Diagnostic (bench.py's roofline.clock_ghz): ONE launch of the register-streamed gate of `layer` exactly as fwn_gate would
+ * run it at this shape (256-row tiles: M >= 24 576 rows, Wgs set), from an instantiation that also stamps the shader clock
+ * (s_memtime) and the 100 MHz reference (s_memrealtime) at the start and end of every wave:
+ * stamps[(workgroup * 8 + wave) * 4 + {0, 1, 2, 3}] = {cycles at start, at end, reference at start, at end}; returns the
+ * number of workgroups (stamps holds 32 * that many uint64_t) or a negative error code if the shape has no such kernel.
+ * In-kernel clock of a wave = (s[1] - s[0]) / (s[3] - s[2]) x 100 MHz; take it after seconds of back-to-back launches. */
+int fwn_gate_clock(const fwn_flow_desc* d, int layer, const void* h, const void* ca, void* o, int M, int Ti, uint64_t* stamps,
+                   void* stream);
 
 /* ---- stage entry points (K4..K8), exposed so each kernel can be parity-tested alone ---- */
 /* K4 front conv k=3 + ReLU over in_a (modules.py:144,164-165); apply_an: ActNorm on load.

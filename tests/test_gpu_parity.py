@@ -357,6 +357,36 @@ def test_co_resident_gate_against_tap_sharing_kernel(full_model, monkeypatch, bl
     assert not np.array_equal(outs[0], outs[2]) or blk < 0     # the switch did select another kernel (orders differ)
 
 
+def test_gate_clock_diagnostic_runs_the_same_kernel(full_model):
+    """fwn_gate_clock (bench.py's roofline.clock_ghz): the stamping instantiation of the 256-row register-streamed gate writes
+    the same output bits as fwn_gate, one record of four stamps per wave (start < end on both clocks), a shader clock between
+    1 and 2.6 GHz; shapes without that kernel are refused."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    d = model._packed.flow_descs[1]
+    ti, b = 8064, 4
+    m = b * ti
+    rng = np.random.default_rng(3)
+    h = torch.from_numpy(rng.standard_normal((m, 256)).astype(np.float32) * 0.5).cuda().to(torch.bfloat16)
+    ca = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    o0 = torch.zeros(m, 256, device="cuda", dtype=torch.bfloat16)
+    o1 = torch.ones(m, 256, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.fwn_gate(C.byref(d), 1, h.data_ptr(), ca.data_ptr(), None, o0.data_ptr(), m, ti, st), "fwn_gate")
+    nwg = 2 * ((m + 255) // 256)
+    stamps = torch.zeros(nwg * 8 * 4, dtype=torch.int64, device="cuda")
+    n = lib.fwn_gate_clock(C.byref(d), 1, h.data_ptr(), ca.data_ptr(), o1.data_ptr(), m, ti, stamps.data_ptr(), st)
+    assert n == nwg, (n, lib.fwn_last_error())
+    assert torch.equal(o0, o1)
+    sv = stamps.cpu().numpy().reshape(-1, 4).astype(np.float64)
+    assert (sv[:, 1] > sv[:, 0]).all() and (sv[:, 3] > sv[:, 2]).all()
+    ghz = np.median((sv[:, 1] - sv[:, 0]) / (sv[:, 3] - sv[:, 2])) * 0.1
+    assert 1.0 < ghz < 2.6, ghz
+    assert lib.fwn_gate_clock(C.byref(d), 1, h.data_ptr(), ca.data_ptr(), o1.data_ptr(), 2 * ti, ti, stamps.data_ptr(), st) == -1
+    d3 = model._packed.flow_descs[3 * hp.n_flow]
+    assert lib.fwn_gate_clock(C.byref(d3), 0, h.data_ptr(), ca.data_ptr(), o1.data_ptr(), m, ti, stamps.data_ptr(), st) == -1
+
+
 def test_gate_stream_is_what_the_model_runs(full_model):
     """The packed model carries fragment streams for the blocks the kernel is built for (cin = 80, 160, 320 at num_mels = 80) and
     none elsewhere; fwn_pack_gate_stream refuses a cin without a kernel; a descriptor that claims a stream for such a cin

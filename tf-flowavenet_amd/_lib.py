@@ -155,6 +155,7 @@ SIGNATURES = {
     "fwn_gate_stream_bytes": (i64, [C.c_int]),
     "fwn_pack_gate_stream": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_gate_stream_rows": (C.c_int, []),
+    "fwn_gate_clock": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_gate_fp8_supported": (C.c_int, [C.c_int, C.c_int]),
     "fwn_gate_fp8": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),
     "fwn_cast_e4m3": (C.c_int, [vp, vp, i64, vp]),

@@ -197,6 +197,20 @@ int fwn_gate_train(const fwn_flow_desc* d, int layer, const void* h, const void*
     return check_launch("fwn_gate_train");
 }
 
+int fwn_gate_clock(const fwn_flow_desc* d, int layer, const void* h, const void* ca, void* o, int M, int Ti, uint64_t* stamps,
+                   void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    REQUIRE(layer >= 0 && layer < d->L && h && ca && o && stamps && M > 0 && Ti > 0 && M % Ti == 0, "fwn_gate_clock: bad argument");
+    REQUIRE(ALIGNED16(h) && ALIGNED16(ca) && ALIGNED16(o) && (((uintptr_t)stamps) & 7) == 0, "fwn_gate_clock: misaligned buffer");
+    const int n = fwn_launch_gate_clock(h, ca, d->Wgs[layer], d->bgate[layer], o, M, Ti, dilation_of(layer), d->cin,
+                                        (unsigned long long*)stamps, (hipStream_t)stream);
+    REQUIRE(n > 0, "fwn_gate_clock: no 256-row register-streamed gate for this shape (M = %d, cin = %d, Wgs %s)", M, d->cin,
+            d->Wgs[layer] ? "set" : "NULL");
+    rc = check_launch("fwn_gate_clock");
+    return rc ? rc : n;
+}
+
 int64_t fwn_gate_stream_bytes(int cin) { return cin > 0 ? (int64_t)fwn_gate_stream_size(cin) : 0; }
 int fwn_gate_stream_rows(void) { return fwn_gate_stream_min_rows(); }
 int fwn_pack_gate_stream(const void* Wd, const void* Wc, int cin, int kcpad, void* out, void* stream) {

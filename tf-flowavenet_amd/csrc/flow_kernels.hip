@@ -1119,6 +1119,20 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
     launch_ring(p, M, 512, (768 + (ca ? kcpad : 0)) / 16, st);
 }
 
+// Diagnostic launch of the dominant kernel with two clock stamps per wave (fwn_gate_clock): the 256-row register-streamed
+// gate, same code otherwise.  Returns the number of workgroups (8 stamp records each) or 0 if the shape has no such kernel.
+int fwn_launch_gate_clock(const void* h, const void* ca, const void* Wgs, const float* bias, void* o, int M, int Ti, int dil, int cin,
+                          unsigned long long* clk, hipStream_t st) {
+    if (!Wgs || !fwn_gate_stream_ok(M, Ti, dil, cin, ca != nullptr, false) || gate_stream_mt(M) != 8) return 0;
+    GateRsArgs a{(const bf16*)h, (const bf16*)ca, (const bf16*)Wgs, bias, (bf16*)o, M, Ti, dil, cin};
+    a.clk = clk;
+    const int nkc = (cin + 15) / 16, ntiles = ((M + 255) / 256) * 2;
+#define X(n) if (nkc == n) hipLaunchKernelGGL((gate_rs_kernel<n, 8, false, FWN_RS_R, true>), dim3(ntiles), dim3(512), 0, st, a, ntiles);
+    FWN_RS_CASES(X)
+#undef X
+    return ntiles;
+}
+
 int fwn_gate_fp8_ok(int M, int dil) { return dil <= FWN_HALO_MAXDIL && ((M + 255) / 256) * 4 >= 192; }
 
 void fwn_launch_gate_fp8(const void* h8, const void* ca, const void* Wd8, int wexp, const void* Wc, const float* bias, void* o,

@@ -17,6 +17,8 @@ void fwn_launch_front(const float* xa, const float* an_a, const void* W, const v
                       void* hout, void* scratch, int M, int Ti, int Ch, int kpad, int apply_an, void* h8out, hipStream_t st);
 // Wgs: the same weights in fragment order (fwn_launch_gate_stream_pack) or nullptr; used instead of Wd / Wc where
 // fwn_gate_stream_ok says so
+int fwn_launch_gate_clock(const void* h, const void* ca, const void* Wgs, const float* bias, void* o, int M, int Ti, int dil, int cin,
+                          unsigned long long* clk, hipStream_t st);
 void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc, const void* Wgs,
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, void* aux,
                      hipStream_t st);

@@ -49,6 +49,9 @@ struct GateRsArgs {
 #ifdef FWN_RS_STAMP
     unsigned long long* stamps;   // diagnostic build (tools/bench_gate_rs.hip): [workgroup][wave][32] s_memtime / s_memrealtime
 #endif
+    // fwn_gate_clock (the CLK = true instantiation; the product launches never read it): [workgroup][8 waves][4] =
+    // s_memtime at wave start / end, s_memrealtime at wave start / end.  Nothing else reads these words.
+    unsigned long long* clk = nullptr;
 };
 #if defined(FWN_RS_STAMP) && !defined(FWN_RS_CHECK)
 #define RS_STAMP(i) do { if (lane == 0) p.stamps[((size_t)blockIdx.x * 8 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -504,7 +507,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
 #ifndef FWN_RS_R
 #define FWN_RS_R 6
 #endif
-template <int NKC, int MT = 8, bool PERSIST = false, int R = FWN_RS_R>
+template <int NKC, int MT = 8, bool PERSIST = false, int R = FWN_RS_R, bool CLK = false>
 __global__ __launch_bounds__(512) void gate_rs_kernel(GateRsArgs p, int ntiles) {
     static_assert(R >= 3 && R <= 12, "ring depth");
     static_assert(MT == 8 || MT == 4, "256- or 128-row tiles");
@@ -514,6 +517,8 @@ __global__ __launch_bounds__(512) void gate_rs_kernel(GateRsArgs p, int ntiles) 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     RS_STAMP(0); RS_STAMP_RT(30);
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if constexpr (CLK) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
 #ifdef FWN_RS_PRIO
     if (wave >= 4) __builtin_amdgcn_s_setprio(FWN_RS_PRIO);
 #endif
@@ -521,6 +526,13 @@ __global__ __launch_bounds__(512) void gate_rs_kernel(GateRsArgs p, int ntiles) 
     if (wave >= 4) gate_rs_wave<NKC, R, true, MT, PERSIST>(p, lds, wave, lane, wg, (int)gridDim.x, ntiles, stamp);
     else gate_rs_wave<NKC, R, false, MT, PERSIST>(p, lds, wave, lane, wg, (int)gridDim.x, ntiles, stamp);
     RS_STAMP(21); RS_STAMP_RT(31);
+    if constexpr (CLK) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* q = p.clk + ((size_t)blockIdx.x * 8 + wave) * 4;
+            q[0] = clk_c0; q[1] = c1; q[2] = clk_r0; q[3] = r1;
+        }
+    }
 }
 
 // Packed gate weights -> fragment stream of gate_rs_kernel<NKC>: out[grp][g][lane][8], k-step g in plan order (RsPlan).
