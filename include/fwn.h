@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FWN_VERSION 300            /* 0.3.0: fwn_flow_desc gained Wfront3 / kf3 (round 3) and Wgs (round 4), fwn_model_desc
+#define FWN_VERSION 301            /* 0.3.1: + fwn_gate_clock (additive: a 0.3.0 host keeps working).  0.3.0: fwn_flow_desc gained Wfront3 / kf3 (round 3) and Wgs (round 4), fwn_model_desc
                                     * chain_mode, fwn_block_done_fn returns int; Wskip / Wfinal rows and biases are in
                                     * acc_k_perm order, Wzero's K axis is natural.  A host built against 0.2.0 must be
                                     * rebuilt and repack its weights. */
