@@ -1152,6 +1152,18 @@ void fwn_launch_res(const void* o, const void* hin, const void* W, const float* 
                     hipStream_t st) {
     ResProb p{(const bf16*)o, (const bf16*)hin, (const bf16*)W, bias, (bf16*)hout, M};
     p.h8out = (unsigned char*)h8out;
+    // The large launches are HBM-bound (o read, h read, h write: 99 MB at block 0 of the 8-clip pass) and a workgroup runs its
+    // phases one after the other - K loop (o chunks), residual loads, stores.  Two 64 KB workgroups per CU (128 x 128 tiles,
+    // ring depth 2) put one workgroup's epilogue beside the other's K loop where ONE 147 KB workgroup per CU (256 x 128 tiles,
+    // depth 3) left the memory pipe idle between phases: block 0 19.4 -> 17.6 us per launch, block 1 9.4 -> 9.3
+    // (tools/probe/res_tiles.py, bit-identical; 128 x 128 at depth 3 / 4 x 32-wide chunks, 64 x 128 at depth 2 / 3 and
+    // 256 x 128 at depth 2 are all slower than the old tile).
+    if (((M + 255) / 256) * 2 >= 192 && FWN_TUNE(FWN_RES_TWO_PER_CU, 1)) {
+        const int N = 256;
+        typedef ResProb Prob;
+        RING_LAUNCH(128, 128, 4, 2, 64, 2);
+        return;
+    }
     launch_ring(p, M, 256, 16, st);
 }
 
