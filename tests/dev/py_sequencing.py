@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from tf_flowavenet_amd import weights
-from tf_flowavenet_amd.training import (SQH, gemm, tn_weight_grad_group, transpose_shift, weight_grad_partials,
+from tf_flowavenet_amd.training import (SQH, gemm, tn_block_splits, tn_weight_grad_group, transpose_shift, weight_grad_partials,
                                         wn_backward_group)
 
 
@@ -222,7 +222,8 @@ def loss_and_grads(self, tp, params, x, c):
             ya8[:, :ch] = ya_bf
             ya_bf = ya8
         wn(wp + "/Conv_front", wgrad(ya_bf, dh_next, kxp, 256, (-1, 0, 1)), 3 * ch, 0, (3, ch, 256), row_src=tp.front_rows[i])
-        parts = tn_weight_grad_group(tnj, m, ti)
+        # the split count the C sequencing plans for the flow's block (one launch for the weight gradients of all its flows)
+        parts = tn_weight_grad_group(tnj, m, ti, nsplit=tn_block_splits([(kx, n, len(sh)) for _, _, kx, n, sh in tnj], hp.n_flow, m))
         _wn_group(self, grads, [(nm, parts[jb] if isinstance(jb, int) else jb, k_, c0_, shp_, sc_, rs_, cs_)
                                for nm, jb, k_, c0_, shp_, sc_, rs_, cs_ in wnj])
         segs = [(dh_next, 256, -(tap - 1), tap * 256) for tap in range(3)]

@@ -141,4 +141,7 @@ void fwn_launch_pack_jobs(const fwn_scale_job* sjobs, int nsjobs, const fwn_pack
                           int scale_ld, hipStream_t st);
 int fwn_tn_tile(int M);
 void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipStream_t st);
+size_t fwn_tn_table_bytes(void);
+int fwn_tn_multi_max(void);
+void fwn_tn_multi_launch(const fwn_tn_job* const* jobs, const int* njobs, int ngroups, int M, int Ti, void* table, hipStream_t st);
 void fwn_colsum_bf16_launch(const void* dy, long M, int C, int ld, float scale, float* partial, float* out, hipStream_t st);

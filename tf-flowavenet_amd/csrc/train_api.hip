@@ -111,6 +111,20 @@ inline int tn_group_splits(const TnSpec* sp, int n, int m) {          // trainin
     return (int)(r < 1 ? 1 : r);
 }
 
+// Round 4: the split count of a flow's weight-gradient GEMMs is planned for its BLOCK - with a side stream the groups of all
+// n_flow flows of a block run as one launch (fwn_tn_multi_launch), and the one-stream path uses the same count so that both
+// sum the same partials in the same order (bit-identical results).  `sp`: the jobs of ONE flow.
+inline int tn_plan_flows(int n_flow) { return FWN_TUNE(FWN_TN_BLOCK, 1) ? n_flow : 1; }     // developer switch (tunable build): 0 = every flow on its own, as before
+inline int tn_block_splits(const TnSpec* sp, int n, int n_flow, int m) {
+    const int e = fwn_tn_tile(m);
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (long)sp[i].ntap * ((sp[i].kx + e - 1) / e) * ((sp[i].n + e - 1) / e);
+    tiles *= n_flow;
+    const long a = (m + 63) / 64, b = 256 / (tiles > 1 ? tiles : 1);
+    const long r = a < b ? a : b;
+    return (int)(r < 1 ? 1 : r);
+}
+
 struct FlowSaved {          // what the training forward keeps of one flow
     void* h[FWN_MAX_LAYERS]; void* o[FWN_MAX_LAYERS]; void* aux[FWN_MAX_LAYERS];
     void* s_act; void* u_act; float* z; float* part; int nb, p;
@@ -122,7 +136,7 @@ struct Plan {               // every buffer of one call
     float* partial_all; float* out2; float* an_dummy;
     FlowSaved* saved;       // host array, owned by the caller of plan()
     // backward temporaries, sized for the largest block and reused flow after flow
-    void* xhl; float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; double* wn_scratch; double* up_wn;
+    void* xhl; float* dzz; void* d_all; void* d_o[FWN_MAX_LAYERS]; float* tn_part; void* tn_table; double* wn_scratch; double* up_wn;
     // the ones the weight-gradient GEMMs read.  One set without a side stream; with one, a set per flow: its weight
     // gradients run on the side stream while the main stream goes on differentiating
     std::vector<BwdSet> sets;
@@ -131,7 +145,7 @@ struct Plan {               // every buffer of one call
     int npart;
 };
 
-// Number of fp32 elements of the grouped weight-gradient partials of one flow at block i (both groups of > 16 jobs included).
+// Number of fp32 elements of the grouped weight-gradient partials of ALL flows of block i (they coexist: one launch per block).
 long tn_partial_floats(const fwn_model_desc* md, int i, long m) {
     const int ch = 1 << i, L = md->n_layer, half = md->num_mels / 2, cin = half * (2 << i);
     const int ldz = 2 * ch > 8 ? 2 * ch : 8;
@@ -147,12 +161,9 @@ long tn_partial_floats(const fwn_model_desc* md, int i, long m) {
     }
     sp[n++] = {ch < 8 ? 8 : ch, 256, 3};
     long tot = 0;
-    for (int g0 = 0; g0 < n; g0 += FWN_MAX_GROUP) {
-        const int cnt = n - g0 < FWN_MAX_GROUP ? n - g0 : FWN_MAX_GROUP;
-        const int ns = tn_group_splits(sp + g0, cnt, (int)m);
-        for (int j = g0; j < g0 + cnt; ++j) tot += (long)ns * ((long)sp[j].ntap * sp[j].kx + 1) * sp[j].n;
-    }
-    return tot;
+    const int ns = tn_block_splits(sp, n, tn_plan_flows(md->n_flow), (int)m);
+    for (int j = 0; j < n; ++j) tot += (long)ns * ((long)sp[j].ntap * sp[j].kx + 1) * sp[j].n;
+    return tot * md->n_flow;
 }
 
 void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
@@ -244,6 +255,7 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
         w.sg = (double*)b.take(sg_b);          // row-range partials of the flow's small gradients (totalled on the side stream)
     }
     pl.tn_part = (float*)b.take(tn_b);
+    pl.tn_table = b.take(fwn_tn_table_bytes());       // group tables of the block-wide weight-gradient launch
     pl.wn_scratch = (double*)b.take(wn_b);
     pl.up_wn = (double*)b.take(1024 * 8);
     // up-sampling backward
@@ -427,29 +439,31 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     // a hook that returns non-zero stops the sequencing where it stands (the side stream is joined at that point)
     bool hook_failed = false;
     auto hook_stop = [&]() -> int { return fwn_set_error(FWN_ERR_CALLBACK, "fwn_train_loss_and_grads: the on_block_done callback asked to stop"); };
-    auto weight_grads = [&](Deferred& D, hipStream_t s_) -> int {
-        const long m = D.m, ti = D.ti;
-        const int ch = D.ch;
-        TnList& tn = D.tn;
+    // The weight gradients of a flow in three stages: (1) totals of the small gradients + the conditioning-gradient GEMMs,
+    // (2) the grouped TN GEMM(s) into fp32 partials, (3) the grouped weight-norm backward(s) that total them.  One stream:
+    // (1)-(3) behind the flow's chain.  Side stream: (1) of every flow of the block, then (2) of ALL its flows as ONE launch
+    // (fwn_tn_multi_launch: the block fills the chip with a sixth of the splits a flow on its own would need - a sixth of the
+    // partials to write and to read back), then (3) flow by flow.  `part`: where the flow's partials go (advanced).
+    auto wg_small = [&](Deferred& D, hipStream_t s_) {
         if (side)       // (one stream: totalled right behind their first pass, on the chain)
-            fwn_small_grads_final(D.an, m, ch, (const long long*)t->br[D.i], (const long long*)t->zcol[D.i], D.w->sg, D.td->d_an_b, D.td->d_an_logs,
+            fwn_small_grads_final(D.an, D.m, D.ch, (const long long*)t->br[D.i], (const long long*)t->zcol[D.i], D.w->sg, D.td->d_an_b, D.td->d_an_logs,
                                   D.td->d_zscale, s_);
         for (int k = 0; k < D.ndca; ++k) fwn_gemm_launch(&D.dca[k], s_);
-        // all weight gradients of the flow: grouped TN GEMM(s), then the grouped weight-norm backward(s)
-        float* part = pl.tn_part;
-        for (int g0 = 0; g0 < tn.n; g0 += FWN_MAX_GROUP) {
-            const int cnt = tn.n - g0 < FWN_MAX_GROUP ? tn.n - g0 : FWN_MAX_GROUP;
-            TnSpec sp[FWN_MAX_GROUP];
-            for (int k = 0; k < cnt; ++k) sp[k] = {tn.job[g0 + k].Kx, tn.job[g0 + k].N, tn.job[g0 + k].ntap};
-            const int ns = tn_group_splits(sp, cnt, (int)m);
-            for (int k = 0; k < cnt; ++k) {
-                fwn_tn_job& q = tn.job[g0 + k];
-                const long size = ((long)q.ntap * q.Kx + 1) * q.N;
-                q.part = part; q.split_stride = size; q.nsplit = ns;
-                part += (size_t)ns * size;
-            }
-            fwn_tn_group_launch(tn.job + g0, cnt, (int)m, (int)ti, s_);
+    };
+    auto wg_place = [&](Deferred& D, float*& part) {          // split count of the block, partial regions of this flow's jobs
+        TnList& tn = D.tn;
+        TnSpec sp[4 + 5 * FWN_MAX_LAYERS];
+        for (int k = 0; k < tn.n; ++k) sp[k] = {tn.job[k].Kx, tn.job[k].N, tn.job[k].ntap};
+        const int ns = tn_block_splits(sp, tn.n, tn_plan_flows(NF), (int)D.m);
+        for (int k = 0; k < tn.n; ++k) {
+            fwn_tn_job& q = tn.job[k];
+            const long size = ((long)q.ntap * q.Kx + 1) * q.N;
+            q.part = part; q.split_stride = size; q.nsplit = ns;
+            part += (size_t)ns * size;
         }
+    };
+    auto wg_wn = [&](Deferred& D, hipStream_t s_) -> int {
+        TnList& tn = D.tn;
         for (int w0 = 0; w0 < D.nwn; w0 += FWN_MAX_GROUP) {
             const int cnt = D.nwn - w0 < FWN_MAX_GROUP ? D.nwn - w0 : FWN_MAX_GROUP;
             fwn_wn_job jobs[FWN_MAX_GROUP];
@@ -470,6 +484,49 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 TREQUIRE(q.dV && (!q.g || (q.V && q.dg)), "fwn_train_loss_and_grads: block %d: missing gradient / master pointer", D.i);
             }
             fwn_wn_group_launch(jobs, cnt, pl.wn_scratch, s_);
+        }
+        return FWN_OK;
+    };
+    auto weight_grads = [&](Deferred& D, hipStream_t s_) -> int {        // one flow, start to end (the one-stream path)
+        wg_small(D, s_);
+        float* part = pl.tn_part;
+        wg_place(D, part);
+        for (int g0 = 0; g0 < D.tn.n; g0 += FWN_MAX_GROUP)
+            fwn_tn_group_launch(D.tn.job + g0, D.tn.n - g0 < FWN_MAX_GROUP ? D.tn.n - g0 : FWN_MAX_GROUP, (int)D.m, (int)D.ti, s_);
+        return wg_wn(D, s_);
+    };
+    auto weight_grads_block = [&](std::vector<Deferred>& flows, hipStream_t s_) -> int {      // all flows of a block (side stream)
+        if (flows.empty()) return FWN_OK;
+        const fwn_tn_job* gj[FWN_MAX_GROUP * 2];
+        int gn[FWN_MAX_GROUP * 2], ng = 0;
+        bool fits = true;
+        for (size_t k = 0; k < flows.size(); ++k) ng += (flows[k].tn.n + FWN_MAX_GROUP - 1) / FWN_MAX_GROUP;
+        if (ng > fwn_tn_multi_max() || ng > (int)(sizeof(gn) / sizeof(gn[0])) || !FWN_TUNE(FWN_TN_BLOCK, 1)) fits = false;
+        float* part = pl.tn_part;
+        for (size_t k = 0; k < flows.size(); ++k) {
+            wg_small(flows[k], s_);
+            wg_place(flows[k], part);
+        }
+        TREQUIRE(part - pl.tn_part <= tn_partial_floats(md, flows[0].i, flows[0].m),
+                 "fwn_train_loss_and_grads: block %d: weight-gradient partials need %ld floats, planned %ld", flows[0].i,
+                 (long)(part - pl.tn_part), tn_partial_floats(md, flows[0].i, flows[0].m));
+        if (fits) {
+            ng = 0;
+            for (size_t k = 0; k < flows.size(); ++k)
+                for (int g0 = 0; g0 < flows[k].tn.n; g0 += FWN_MAX_GROUP) {
+                    gj[ng] = flows[k].tn.job + g0;
+                    gn[ng++] = flows[k].tn.n - g0 < FWN_MAX_GROUP ? flows[k].tn.n - g0 : FWN_MAX_GROUP;
+                }
+            fwn_tn_multi_launch(gj, gn, ng, (int)flows[0].m, (int)flows[0].ti, pl.tn_table, s_);
+        } else {
+            for (size_t k = 0; k < flows.size(); ++k)
+                for (int g0 = 0; g0 < flows[k].tn.n; g0 += FWN_MAX_GROUP)
+                    fwn_tn_group_launch(flows[k].tn.job + g0, flows[k].tn.n - g0 < FWN_MAX_GROUP ? flows[k].tn.n - g0 : FWN_MAX_GROUP,
+                                        (int)flows[k].m, (int)flows[k].ti, s_);
+        }
+        for (size_t k = 0; k < flows.size(); ++k) {
+            const int rc = wg_wn(flows[k], s_);
+            if (rc != FWN_OK) return rc;
         }
         return FWN_OK;
     };
@@ -499,8 +556,8 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     auto hand_over = [&]() -> int {          // fork, then everything in `pending` to the side stream
         if (!fork_side()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: forking the side stream failed");
         // (FWN_SKIP_WG: developer builds only - times the data-gradient chain alone; the gradients are then wrong)
-        for (size_t k = 0; k < pending.size() && !FWN_TUNE(FWN_SKIP_WG, 0); ++k) {
-            const int rc = weight_grads(pending[k], side);
+        if (!FWN_TUNE(FWN_SKIP_WG, 0)) {
+            const int rc = weight_grads_block(pending, side);
             if (rc != FWN_OK) return rc;
         }
         pending.clear();

@@ -4,6 +4,7 @@
 // workgroups into fp32 partials that a second pass sums in a fixed order).
 #include "common.h"
 #include "gemm_ring.h"
+#include <string.h>
 #include "fwn_internal.h"
 #include "../../include/fwn.h"
 
@@ -948,8 +949,20 @@ struct TnGroup {
 // WI x WJ waves of 64 x 64 each: <2,2,3> = 128 x 128 tile, 96 KB of LDS; <4,4,2> = 256 x 256 tile (half the
 // L2 -> LDS bytes per flop: the long contractions of the first blocks are bound by exactly that), 128 KB.
 // X and dY chunks are stored as panels of 128 columns (16 KB images).
+// Several groups in ONE launch (round 4: the weight gradients of all flows of a block - their operands exist together once
+// the block's chain has run): the group tables live in device memory (tn_table_put_kernel writes one from its kernel
+// arguments), the launch carries only the workgroup prefix of every group.  With the whole block in one grid a handful of
+// splits fills the chip where every flow on its own needed a dozen - a sixth of the fp32 partials written and read back.
+#define FWN_TN_MAXGROUPS 16
+struct TnMulti {
+    int gfirst[FWN_TN_MAXGROUPS + 1];
+    int ngroups;
+};
+__global__ void tn_table_put_kernel(const TnGroup g, TnGroup* __restrict__ dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = g;
+}
 template <int WI, int WJ, int D>
-__global__ __launch_bounds__(64 * WI * WJ) void tn_gemm_kernel(const TnGroup grp) {
+__device__ __forceinline__ void tn_gemm_body(const TnGroup& grp, const int bid) {
     constexpr int TILE = 64 * 256, XP = WI / 2, YP = WJ / 2, SLOT = (XP + YP) * TILE, NW = WI * WJ;
     constexpr int BMX = 64 * WI, BNY = 64 * WJ;
     constexpr int PX = 16 * XP / NW, PY = 16 * YP / NW;          // DMA pieces per wave per chunk
@@ -958,12 +971,19 @@ __global__ __launch_bounds__(64 * WI * WJ) void tn_gemm_kernel(const TnGroup grp
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave / WJ, wj = wave % WJ;
+    int first[FWN_MAX_GROUP + 1];                                  // (all at once: the table may live in device memory)
+#pragma unroll
+    for (int j = 0; j <= FWN_MAX_GROUP; ++j) first[j] = grp.first[j];
     int jn = 0;
-    while (jn + 1 < grp.njobs && (int)blockIdx.x >= grp.first[jn + 1]) ++jn;
+#pragma unroll
+    for (int j = 1; j < FWN_MAX_GROUP; ++j) jn += (j < grp.njobs && bid >= first[j]) ? 1 : 0;
     const TnArgs a = grp.job[jn];
     const int kxt = (a.Kx + BMX - 1) / BMX;                        // row tiles per tap
     const int nbx = a.ntap * kxt, nby = (a.N + BNY - 1) / BNY;
-    const int local = (int)blockIdx.x - grp.first[jn];
+    int first_jn = 0;
+#pragma unroll
+    for (int j = 0; j < FWN_MAX_GROUP; ++j) first_jn = j == jn ? first[j] : first_jn;
+    const int local = bid - first_jn;
     const int bx = local % nbx, by = (local / nbx) % nby, bz = local / (nbx * nby);     // splits slowest: tiles of one row range run together
     const int tap = bx / kxt, kx0 = (bx % kxt) * BMX, n0 = by * BNY;
     const int shift = a.shift0 + tap * a.dshift;
@@ -1082,6 +1102,20 @@ __global__ __launch_bounds__(64 * WI * WJ) void tn_gemm_kernel(const TnGroup grp
             }
         }
 }
+template <int WI, int WJ, int D>
+__global__ __launch_bounds__(64 * WI * WJ) void tn_gemm_kernel(const TnGroup grp) {
+    tn_gemm_body<WI, WJ, D>(grp, (int)blockIdx.x);
+}
+template <int WI, int WJ, int D>
+__global__ __launch_bounds__(64 * WI * WJ) void tn_gemm_multi_kernel(const TnGroup* __restrict__ tab, const TnMulti hdr) {
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < FWN_TN_MAXGROUPS; ++k) g += (k < hdr.ngroups && (int)blockIdx.x >= hdr.gfirst[k]) ? 1 : 0;
+    int gf = 0;
+#pragma unroll
+    for (int k = 0; k < FWN_TN_MAXGROUPS; ++k) gf = k == g ? hdr.gfirst[k] : gf;
+    tn_gemm_body<WI, WJ, D>(tab[g], (int)blockIdx.x - gf);
+}
 // column sums of a bf16 matrix (bias gradients): out[c] = scale * sum_m dy[m][c]; two fixed-order passes
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ dy, long M, int C, int ld,
                                                           float* __restrict__ partial) {
@@ -1104,8 +1138,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
 #define FWN_TN256_MIN 128
 #endif
 int fwn_tn_tile(int M) { return M >= FWN_TUNE(FWN_TN256_MIN, FWN_TN256_MIN) ? 256 : 128; }     // output tile edge of the weight-gradient GEMM
-void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipStream_t st) {
-    TnGroup g;
+static int tn_fill_group(TnGroup& g, const fwn_tn_job* jobs, int njobs, int M, int Ti) {       // -> workgroups of the group
+    memset(&g, 0, sizeof(g));
     g.njobs = njobs;
     int total = 0;
     for (int j = 0; j < njobs; ++j) {
@@ -1117,8 +1151,34 @@ void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipSt
         total += q.ntap * ((q.Kx + tile - 1) / tile) * ((q.N + tile - 1) / tile) * q.nsplit;
     }
     for (int j = njobs; j <= FWN_MAX_GROUP; ++j) g.first[j] = total;
+    return total;
+}
+void fwn_tn_group_launch(const fwn_tn_job* jobs, int njobs, int M, int Ti, hipStream_t st) {
+    TnGroup g;
+    const int total = tn_fill_group(g, jobs, njobs, M, Ti);
     if (fwn_tn_tile(M) == 256) hipLaunchKernelGGL((tn_gemm_kernel<4, 4, 2>), dim3(total), dim3(1024), 0, st, g);
     else hipLaunchKernelGGL((tn_gemm_kernel<2, 2, 3>), dim3(total), dim3(256), 0, st, g);
+}
+// ngroups (<= fwn_tn_multi_max()) groups of <= FWN_MAX_GROUP jobs each, all at the same M / Ti, in ONE launch; `table`: device
+// memory of fwn_tn_table_bytes() bytes that stays untouched until the launch has run (the group tables are written into
+// it by ngroups one-thread launches in front of it).
+size_t fwn_tn_table_bytes(void) { return FWN_TN_MAXGROUPS * sizeof(TnGroup); }
+int fwn_tn_multi_max(void) { return FWN_TN_MAXGROUPS; }
+void fwn_tn_multi_launch(const fwn_tn_job* const* jobs, const int* njobs, int ngroups, int M, int Ti, void* table, hipStream_t st) {
+    TnMulti hdr;
+    memset(&hdr, 0, sizeof(hdr));
+    hdr.ngroups = ngroups;
+    TnGroup* tab = (TnGroup*)table;
+    int total = 0;
+    for (int k = 0; k < ngroups; ++k) {
+        TnGroup g;
+        hdr.gfirst[k] = total;
+        total += tn_fill_group(g, jobs[k], njobs[k], M, Ti);
+        hipLaunchKernelGGL(tn_table_put_kernel, dim3(1), dim3(64), 0, st, g, tab + k);
+    }
+    for (int k = ngroups; k <= FWN_TN_MAXGROUPS; ++k) hdr.gfirst[k] = total;
+    if (fwn_tn_tile(M) == 256) hipLaunchKernelGGL((tn_gemm_multi_kernel<4, 4, 2>), dim3(total), dim3(1024), 0, st, tab, hdr);
+    else hipLaunchKernelGGL((tn_gemm_multi_kernel<2, 2, 3>), dim3(total), dim3(256), 0, st, tab, hdr);
 }
 void fwn_colsum_bf16_launch(const void* dy, long M, int C, int ld, float scale, float* partial, float* out, hipStream_t st) {
     const int nb = fwn_colsum_blocks(M, C);

@@ -136,6 +136,15 @@ def tn_group_splits(specs, m):
     return max(1, min((m + 63) // 64, 256 // max(1, tiles)))
 
 
+def tn_block_splits(specs, n_flow, m):
+    """The split count ``fwn_train_loss_and_grads`` uses for the weight-gradient GEMMs ``specs`` of ONE flow: planned for the
+    flow's block (csrc/train_api.hip ``tn_block_splits``) - the groups of all ``n_flow`` flows of a block run as one launch
+    on the side stream, so a handful of splits fills the chip."""
+    e = int(_lib.load().fwn_tn_gemm_tile(int(m)))
+    tiles = n_flow * sum(ntap * ((kx + e - 1) // e) * ((n + e - 1) // e) for kx, n, ntap in specs)
+    return max(1, min((m + 63) // 64, 256 // max(1, tiles)))
+
+
 def tn_weight_grad_group(jobs, m, ti=0, nsplit=None):
     """``jobs``: list of ``(x, dy, kx, n, shifts)`` sharing m and ti.  One launch (``fwn_tn_gemm_group``); returns the
     fp32 partials ``[S, len(shifts)*kx + 1, n]`` of every job (views of one buffer; last row = bias gradient)."""
