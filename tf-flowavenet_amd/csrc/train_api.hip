@@ -120,9 +120,20 @@ inline int tn_block_splits(const TnSpec* sp, int n, int n_flow, int m) {
     long tiles = 0;
     for (int i = 0; i < n; ++i) tiles += (long)sp[i].ntap * ((sp[i].kx + e - 1) / e) * ((sp[i].n + e - 1) / e);
     tiles *= n_flow;
-    const long a = (m + 63) / 64, b = 256 / (tiles > 1 ? tiles : 1);
-    const long r = a < b ? a : b;
-    return (int)(r < 1 ? 1 : r);
+    // the fewest splits that fill the rounds of workgroups the launch needs to 85 % (256 CUs, one 256 x 256 tile each): the
+    // six flows of block 0 are 144 tiles - one split would leave 112 CUs idle, two would run a second round for 32 of them,
+    // five make 720 workgroups = three rounds at 94 %
+    // (few rows: the launch is bound by writing its output tiles, and every extra split is another copy of them for the
+    // weight-norm backward to read - one split per tile there.  Measured per block at 8 x 6400, TN + weight-norm kernel time:
+    // blocks 0-2 fill-aware 728 / 555 / 339 us against 1030 / 653 / 371 with one split; blocks 3-7 one split 261 / 239 / 283 /
+    // 376 / 562 us against 287 / 236 / 302 / 422 / 672 fill-aware)
+    if (m < 4096) return 1;
+    const long a = (m + 63) / 64 < 32 ? (m + 63) / 64 : 32;
+    for (long n = 1; n <= a; ++n) {
+        const long w = tiles * n, rounds = (w + 255) / 256;
+        if (100 * w >= 85 * 256 * rounds) return (int)n;
+    }
+    return (int)(a < 1 ? 1 : a);
 }
 
 struct FlowSaved {          // what the training forward keeps of one flow

@@ -142,7 +142,14 @@ def tn_block_splits(specs, n_flow, m):
     on the side stream, so a handful of splits fills the chip."""
     e = int(_lib.load().fwn_tn_gemm_tile(int(m)))
     tiles = n_flow * sum(ntap * ((kx + e - 1) // e) * ((n + e - 1) // e) for kx, n, ntap in specs)
-    return max(1, min((m + 63) // 64, 256 // max(1, tiles)))
+    if m < 4096:                            # few rows: bound by writing the output tiles - one split
+        return 1
+    a = min((m + 63) // 64, 32)
+    for n in range(1, a + 1):               # the fewest splits that fill the launch's rounds of 256 workgroups to 85 %
+        w = tiles * n
+        if 100 * w >= 85 * 256 * ((w + 255) // 256):
+            return n
+    return max(1, a)
 
 
 def tn_weight_grad_group(jobs, m, ti=0, nsplit=None):

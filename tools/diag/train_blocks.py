@@ -35,16 +35,19 @@ for b in range(nb):
         print("   %8.3f ms  %6.1f us  grid %6s  %s" % (ms(r["s"]), (r["e"] - r["s"]) / 1e3, r["Grid_Size_X"], r["n"][:80]))
 cb = [i for i, r in enumerate(step) if r["n"].startswith("coupling_bwd_kernel")]
 sg = [i for i, r in enumerate(step) if r["n"] == "flow_small_grads_kernel"]
-side_names = ("tn_gemm_kernel", "wn_group_kernel", "wn_group_mid_kernel", "flow_small_grads_final_kernel")
+side_names = ("tn_gemm_kernel", "tn_gemm_multi_kernel", "tn_table_put_kernel", "wn_group_kernel", "wn_group_mid_kernel", "flow_small_grads_final_kernel")
 chain = [r for r in step[bwd0:] if not r["n"].startswith(side_names)]
 print("backward: block  start_ms  chain_span_us  (per flow)   tn_us  wn_us  (kernel time of the block's weight-gradient launches)")
 tn = [r for r in step if r["n"].startswith("tn_gemm_kernel")]
+tnm = [r for r in step if r["n"].startswith("tn_gemm_multi_kernel")]      # round 4: ONE weight-gradient launch per block
 wn = [r for r in step if r["n"].startswith("wn_group")]
 ntn, nwn = len(tn) // nflow, len(wn) // nflow
 for b in range(nb - 1, -1, -1):
     k = nb - 1 - b
     s, e = step[cb[k * NF]]["s"], step[sg[(k + 1) * NF - 1]]["e"]
     tnb = sum(r["e"] - r["s"] for r in tn[k * NF * ntn:(k + 1) * NF * ntn]) / 1e3
+    if len(tnm) == nb:
+        tnb += (tnm[k]["e"] - tnm[k]["s"]) / 1e3
     wnb = sum(r["e"] - r["s"] for r in wn[k * NF * nwn:(k + 1) * NF * nwn]) / 1e3
     print("          %5d  %8.3f  %13.1f  %10.1f  %6.1f %6.1f" % (b, ms(s), (e - s) / 1e3, (e - s) / 1e3 / NF, tnb, wnb))
 last_sg = step[sg[-1]]["e"]
