@@ -359,6 +359,47 @@ def test_co_resident_gate_against_tap_sharing_kernel(full_model, monkeypatch, bl
     assert not np.array_equal(outs[0], outs[2]) or blk < 0     # the switch did select another kernel (orders differ)
 
 
+@pytest.mark.parametrize("blk,b,ti,layer", [(0, 8, 8064, 0), (0, 13, 8064, 1), (1, 32, 4032, 1), (0, 70, 1000, 0)])
+def test_persistent_gate_equals_the_one_tile_form_bit_for_bit(full_model, monkeypatch, blk, b, ti, layer):
+    """gate_rs_kernel<.., PERSIST = true> (one workgroup per CU loops over its tiles, the next tile's first items and weights
+    issued under the tail of the current one) multiplies in the same order as the one-tile form: identical bits, also beside
+    a second stream that keeps the memory system busy (the form's race of round 4 needed slow loads to show: a register copy
+    hipcc placed in front of a branch-dependent asm wait, fixed in gate_rs.h and found statically by
+    tools/check_async_loads.py).  Two tiles per workgroup (the bench shape), three and more (where the launcher selects the
+    form by itself), clip edges inside tiles, a partial last tile."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    d = model._packed.flow_descs[blk * hp.n_flow + 1]
+    m = b * ti
+    assert d.Wgs[layer] and m >= 24576
+    rng = np.random.default_rng(b + layer)
+    h = torch.from_numpy(rng.standard_normal((m, 256)).astype(np.float32) * 0.5).cuda().to(torch.bfloat16)
+    ca = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(flag):
+        monkeypatch.setenv("FWN_RS_PERSIST", flag)
+        o = torch.full((m + 8, 256), 7.0, device="cuda", dtype=torch.bfloat16)
+        _lib.check(lib.fwn_gate(C.byref(d), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
+        return o
+
+    want = run("0")
+    assert bool((want[m:] == 7.0).all())
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    for rep in range(12):
+        if rep >= 4:                                  # a bandwidth hog beside the launch
+            with torch.cuda.stream(side):
+                big[: 1 << 27].copy_(big[1 << 27:], non_blocking=True)
+        got = run("1")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), rep
+    monkeypatch.delenv("FWN_RS_PERSIST")           # the launcher's own choice (persistent from three tiles per workgroup on)
+    o = torch.full((m + 8, 256), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.fwn_gate(C.byref(d), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
+    assert torch.equal(o, want)
+
+
 def test_gate_clock_diagnostic_runs_the_same_kernel(full_model):
     """fwn_gate_clock (bench.py's roofline.clock_ghz): the stamping instantiation of the 256-row register-streamed gate writes
     the same output bits as fwn_gate, one record of four stamps per wave (start < end on both clocks), a shader clock between

@@ -10,18 +10,50 @@ CSRC = os.path.join(ROOT, "tf-flowavenet_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
+_ISA = {}
+
+
+def _flow_kernels_isa(tmp_path_factory):
+    """flow_kernels.hip -> gfx950 ISA, once per session (three minutes of hipcc)."""
+    if "path" not in _ISA:
+        flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off -fno-slp-vectorize -S --cuda-device-only".split()
+        out = tmp_path_factory.mktemp("isa") / "flow_kernels.s"
+        subprocess.run([HIPCC] + flags + ["-c", os.path.join(CSRC, "flow_kernels.hip"), "-o", str(out)], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _ISA["path"] = str(out)
+    return _ISA["path"]
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-def test_no_ring_barrier_is_crossed_with_lds_reads_in_flight(tmp_path):
+def test_no_register_is_touched_while_an_asm_load_into_it_is_in_flight(tmp_path_factory):
+    """tools/check_async_loads.py over the inference kernels: the register-streamed gates (gate_rs.h, gate_co.h) load weight
+    fragments from inline asm and wait for them with hand-counted s_waitcnt vmcnt(N); hipcc believes an asm output written
+    when the statement executes and may copy or reuse the register before the wait.  That was the persistent gate's race
+    (round 4: `if (first) wait<n0> else wait<n1>` made hipcc fill the merged "+v" operand with a v_mov IN FRONT of the wait -
+    a copy of a ring stage whose load was still in flight).  No kernel may touch a register with a load in flight; and the
+    checker must still see the pattern."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_async_loads as chk
+    flagged = [(name, rep[:2]) for name, body in chk.kernels(_flow_kernels_isa(tmp_path_factory)) for rep in [chk.check(name, body)] if rep]
+    assert not flagged, flagged[:3]
+    body = ["\tbuffer_load_dwordx4 v[0:3], v9, s[0:3], s4 offen offset:0\n", "\tbuffer_load_dwordx4 v[4:7], v9, s[0:3], s4 offen offset:1024\n",
+            "\ts_cbranch_vccz .LBB0_1\n", "\tv_mov_b64_e32 v[10:11], v[0:1]\n", "\ts_waitcnt vmcnt(1)\n", ".LBB0_1:\n",
+            "\ts_waitcnt vmcnt(1)\n", "\tv_add_u32_e32 v8, v1, v2\n", "\ts_endpgm\n"]
+    rep = chk.check("k", body)
+    assert len(rep) == 1 and rep[0][1].startswith("v_mov_b64") and rep[0][2] == [0, 1]
+    del body[3]
+    assert chk.check("k", body) == []
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_no_ring_barrier_is_crossed_with_lds_reads_in_flight(tmp_path, tmp_path_factory):
     """tools/check_barrier_lgkm.py over the inference kernels: no s_barrier is reached with ds_reads in flight (the
     round-3 front_mfma_kernel race, DESIGN.md section 3.5: hipcc sinks the lgkmcnt wait of a chunk's fragment reads below the
     raw barrier that licenses refilling the slot they read; FWN_RING_BARRIER retires them first).  The checker must also
     still SEE the pattern: a ring barrier without the wait is flagged."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_barrier_lgkm as chk
-    flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off -fno-slp-vectorize -S --cuda-device-only".split()
-    out = tmp_path / "flow_kernels.s"
-    subprocess.run([HIPCC] + flags + ["-c", os.path.join(CSRC, "flow_kernels.hip"), "-o", str(out)], check=True,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = _flow_kernels_isa(tmp_path_factory)
     flagged = [(name, rep) for name, body in chk.kernels(str(out)) for rep in [chk.check(name, body)] if rep]
     assert not flagged, flagged[:3]
     # the checker on a hand-made body: reads in flight at the barrier, a refill behind it

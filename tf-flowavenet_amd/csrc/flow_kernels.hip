@@ -1057,19 +1057,22 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
     if (Wgs && fwn_gate_stream_ok(M, Ti, dil, cin, ca != nullptr && P == nullptr, aux != nullptr)) {
         GateRsArgs a{(const bf16*)h, (const bf16*)ca, (const bf16*)Wgs, bias, (bf16*)o, M, Ti, dil, cin};
         const int nkc = (cin + 15) / 16;
-        // One tile per workgroup.  gate_rs_kernel<.., PERSIST = true> (one workgroup per CU loops over its tiles, the next
-        // tile's first items and weights issued under the tail of the current one: -10 % cycles per two-tile workgroup at
-        // block 0, tools/bench_gate_rs.hip) is NOT the product: inside overlapped passes about 40 % of the steps then differ
-        // from the one-stream result (tools/diag/lanes_flake.py with FWN_RS_PERSIST=1) although the stand-alone harness soaks
-        // clean under contention and every wait has its static count of younger operations in program order (FWN_RS_CHECK
-        // build) - an open race in the cross-tile hand-over.  FWN_RS_PERSIST=1: developer switch.
-        static const bool persist = [] { const char* e = getenv("FWN_RS_PERSIST"); return e && e[0] == '1'; }();
+        // gate_rs_kernel<.., PERSIST = true>: one workgroup per CU loops over its tiles, the next tile's first items and
+        // weights issued under the tail of the current one (-10 % cycles per two-tile workgroup at block 0,
+        // tools/bench_gate_rs.hip).  Its race of the first half of round 4 is root-caused and fixed (a register copy hipcc
+        // placed in front of a branch-dependent asm wait: gate_rs.h; tools/check_async_loads.py); it
+        // soaks clean inside overlapped passes at 8 / 16 / 32 clips.  Used where a workgroup gets three tiles or more (from
+        // 13 clips of 16128 samples on at block 0: 32 clips -1.9 % on the one-stream pair, -0.8 % on the overlapped step);
+        // at the bench's 8 clips (two tiles per workgroup) the overlapped step is 1.5 % slower with it: one tile per
+        // workgroup there.  FWN_RS_PERSIST=0 / 1 (read per call) forces either form.
+        const char* pe = getenv("FWN_RS_PERSIST");
         static const int ncu = [] {
             int dev = 0, n = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 2) n = 256;
             return n & ~1;
         }();
         const int mt = gate_stream_mt(M);
+        const bool persist = mt == 8 && (pe && (pe[0] == '0' || pe[0] == '1') ? pe[0] == '1' : ((M + 255) / 256) * 2 >= 3 * ncu);
         // 256-row tiles, experimental: the co-resident form (gate_co.h: 4-wave workgroups of 256 rows x 64 channels, two per
         // CU) reads the same stream.  Stand-alone it is 1 - 5 % faster per launch than the 8-wave form (tools/bench_gate_co.hip),
         // inside the overlapped passes the step is unchanged (5.82 against 5.80 ms, three interleaved rounds on one box):

@@ -400,8 +400,12 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
                 if (first) { if constexpr ((FWN_RS_SAFE & 16) != 0) rs_wwait<0>(wq[g % R]); else rs_wwait<n0>(wq[g % R]); }
                 else { if constexpr ((FWN_RS_SAFE & 8) != 0 || ((FWN_RS_SAFE & 4) != 0 && g < R - 1)) rs_wwait<0>(wq[g % R]); else rs_wwait<n1>(wq[g % R]); }
 #else
-                if constexpr (n0 == n1) rs_wwait<n1>(wq[g % R]);
-                else { if (first) rs_wwait<n0>(wq[g % R]); else rs_wwait<n1>(wq[g % R]); }
+                // ONE statement whatever the tile: under `if (first) wait<n0> else wait<n1>` hipcc merges the two arms' "+v"
+                // operand in a new register and fills it with a v_mov IN FRONT of the s_waitcnt of one arm - a copy of a ring
+                // stage whose load is still in flight (found in the ISA by tools/check_async_loads.py; it was the persistent
+                // form's race: stale weights in the k-steps whose counts differ between the first and the later tiles,
+                // whenever the load had not landed by then).  The smaller count is safe for both (it waits for more).
+                rs_wwait<(n0 < n1 ? n0 : n1)>(wq[g % R]);
 #endif
             }
             if constexpr (firstk) {
