@@ -390,15 +390,8 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
                 constexpr int n0 = C::wait_kstep(0, g), n1 = PERSIST ? C::wait_kstep(1, g) : n0;
                 static_assert(C::steady_ok(g), "the vmcnt schedule must repeat from the second tile on");
                 if (first) RS_CHK_WAIT(g % R, g, n0); else RS_CHK_WAIT(g % R, g, n1);
-#if defined(FWN_RS_SAFE) && (FWN_RS_SAFE & 1)
+#if defined(FWN_RS_SAFE) && (FWN_RS_SAFE & 1)        // developer build: drain in front of every k-step
                 rs_wwait<0>(wq[g % R]);
-#elif defined(FWN_RS_SAFE) && (FWN_RS_SAFE & 64)
-                if (!first && g == 5) rs_wwait<0>(wq[g % R]); else if (first) rs_wwait<n0>(wq[g % R]); else rs_wwait<n1>(wq[g % R]);
-#elif defined(FWN_RS_SAFE) && (FWN_RS_SAFE & 128)
-                if (!first && g >= 12) rs_wwait<0>(wq[g % R]); else if (first) rs_wwait<n0>(wq[g % R]); else rs_wwait<n1>(wq[g % R]);
-#elif defined(FWN_RS_SAFE) && (FWN_RS_SAFE & 28)
-                if (first) { if constexpr ((FWN_RS_SAFE & 16) != 0) rs_wwait<0>(wq[g % R]); else rs_wwait<n0>(wq[g % R]); }
-                else { if constexpr ((FWN_RS_SAFE & 8) != 0 || ((FWN_RS_SAFE & 4) != 0 && g < R - 1)) rs_wwait<0>(wq[g % R]); else rs_wwait<n1>(wq[g % R]); }
 #else
                 // ONE statement whatever the tile: under `if (first) wait<n0> else wait<n1>` hipcc merges the two arms' "+v"
                 // operand in a new register and fills it with a v_mov IN FRONT of the s_waitcnt of one arm - a copy of a ring
