@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define FWN_VERSION 301            /* 0.3.1: + fwn_gate_clock (additive: a 0.3.0 host keeps working).  0.3.0: fwn_flow_desc gained Wfront3 / kf3 (round 3) and Wgs (round 4), fwn_model_desc
+#define FWN_VERSION 310            /* 0.3.10 (round 5): + fwn_flow_run_persist / fwn_flow_persist_* (one launch per small-M flow), fwn_model_desc.persist_mode
+                                    * (was `reserved`: 0 keeps working), fwn_set_option.  0.3.1: + fwn_gate_clock (additive: a 0.3.0 host keeps working).  0.3.0: fwn_flow_desc gained Wfront3 / kf3 (round 3) and Wgs (round 4), fwn_model_desc
                                     * chain_mode, fwn_block_done_fn returns int; Wskip / Wfinal rows and biases are in
                                     * acc_k_perm order, Wzero's K axis is natural.  A host built against 0.2.0 must be
                                     * rebuilt and repack its weights. */
@@ -235,6 +236,26 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
                  void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
                  void* stream);
 
+/* ---- one whole flow as ONE launch (round 5, csrc/flow_persist.h): the same arithmetic as fwn_flow_run, bit for bit, for the
+ * shapes where every stage of the flow is a launch of a handful of workgroups (the dependent-launch floor of the small
+ * blocks: model.py:394-396 run one utterance at a time, synthesize.py:40-49).  Tickets (stage, 64-row tile, 64-column
+ * tile) are taken from an atomic counter by 8-wave workgroups, dependencies are per row tile, a ticket's weights are
+ * requested before it waits for its producers; hand-offs are write-through stores + agent-scope counters + sc1 loads.
+ * Preconditions (fwn_flow_persist_supported != 0): conditioning hoisted (P given, ca == NULL), n_layer <= 2,
+ * M = B * T / (2 Ch) <= 4096 rows, forward or inverse without data-dependent init, bf16 gates.
+ * sync: fwn_flow_persist_sync_bytes(M, L) bytes of device memory that the CALLER ZEROES (stream-ordered) before every call;
+ * sync[1] != 0 afterwards = a bounded spin gave up (fwn_flow_persist_status reads it back: that one synchronises). */
+int fwn_flow_persist_supported(const fwn_flow_desc* d, int64_t B, int64_t T);
+int64_t fwn_flow_persist_sync_bytes(int M, int L);
+int fwn_flow_run_persist(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, void* h0, void* h1, void* o,
+                         const float* P, float* partial, int inverse, void* sync, void* stream);
+int fwn_flow_persist_status(const void* sync, void* stream);
+
+/* ---- process-wide developer options (replaces the environment variables the launch path read in round 4) ----
+ * name: "rs_persist" (-1 auto, 0 / 1: the register-streamed gate's persistent form off / on), "gate_co" (0 / 1: the
+ * experimental co-resident gate).  Returns the previous value, or FWN_ERR_ARG for an unknown name. */
+int fwn_set_option(const char* name, int value);
+
 /* The same flow with the gated layers' dilated taps in fp8 wherever fwn_gate_fp8_supported says so (other layers /
  * shapes run the bf16 kernels): h8a / h8b are [M][256]-byte scratch buffers for the e4m3 copies of h. */
 int fwn_flow_run_fp8(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
@@ -401,7 +422,9 @@ typedef struct fwn_model_desc {
     int32_t gate_fp8;                         /* != 0: fp8 dilated taps where supported (needs flows[].Wd8) */
     int32_t chain_mode;                       /* 0: chain the flows of a block (out_b to a third plane buffer, the next flow's
                                                * front conv in the previous flow's tail: csrc/tail_chain.h); 1: every flow on its own */
-    int32_t reserved;
+    int32_t persist_mode;                     /* 2: flows of small-M blocks (hoisted conditioning, <= 4096 rows) run as ONE launch each
+                                               * (csrc/flow_persist.h; same results bit for bit); 0 / 1: a launch per stage (the default:
+                                               * the one-launch form measures at parity or behind it) */
     /* Diagnostic (bench.py's per-block table), normally NULL: HOST array of n_block + 1 hipEvent_t handles.  The whole-model
      * calls record [k] on `stream` in front of the first launch of the k-th block they run (forward: block k, reverse: block
      * n_block - 1 - k) and [n_block] behind the last launch of the last one. */

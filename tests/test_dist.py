@@ -164,3 +164,83 @@ def test_ranks_restore_the_same_step_and_notice_diverged_weights(tmp_path):
         assert r["restored"] == (100, 5.0)
         assert r["lagging"] == 10
         assert r["torn"] == "disagree"
+
+
+# ---- the bf16 gradient exchange (round 5: optim.DataParallelAdam(grad_reduce_dtype="bf16")) ----
+def _bf16_exchange_worker(rank, world, port, q):
+    import numpy as np
+    from tf_flowavenet_amd import optim
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    D.init_from_env("gloo")
+    n = 100003
+    rng = np.random.default_rng(7 + rank)
+    # heavy-tailed like a real gradient: a few large entries, most tiny, some exactly zero
+    g_np = (rng.standard_normal(n) * np.exp(rng.standard_normal(n) * 2.0)).astype(np.float32)
+    g_np[rng.integers(0, n, 500)] = 0.0
+    res = {}
+    for dt in ("fp32", "bf16"):
+        g = torch.from_numpy(g_np.copy())
+        stage = torch.empty(n, dtype=torch.bfloat16) if dt == "bf16" else None
+        works = optim.allreduce_flat(g, None, 30000, True, dt, stage)        # four buckets, the last one short
+        assert len(works) == 4
+        for w in works:
+            w.wait()
+        res[dt] = g.numpy().copy()
+    # one range started early (the per-block exchange of the training step), then the rest
+    g = torch.from_numpy(g_np.copy())
+    stage = torch.empty(n, dtype=torch.bfloat16)
+    w1 = optim.allreduce_slice(g, 50000, n, None, "bf16", stage)
+    w0 = optim.allreduce_slice(g, 0, 50000, None, "bf16", stage)
+    w1.wait(); w0.wait()
+    res["ranges"] = g.numpy().copy()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_is_lockstep_and_bounds_the_step():
+    """grad_reduce_dtype = "bf16": every rank receives the SAME reduced gradient (lock-step of the masters is untouched), it
+    is the fp32 sum up to two bf16 roundings per element, and the clip + Adam step built from it (oracle/optim_np.py, the
+    restatement of train.py:15-32) moves the weights by what the fp32 exchange would up to that noise."""
+    import numpy as np
+    from oracle import optim_np
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for key in ("fp32", "bf16", "ranges"):
+        assert np.array_equal(res[0][key], res[1][key]), key                  # identical on both ranks, bit for bit
+    assert np.array_equal(res[0]["bf16"], res[0]["ranges"])                    # bucket bounds do not matter
+    g32, g16 = res[0]["fp32"].astype(np.float64), res[0]["bf16"].astype(np.float64)
+    # each rank's term rounded to bf16 (2^-9 relative each), the sum rounded once more
+    parts = [np.abs(x) for x in (g32,)]
+    err = np.abs(g16 - g32)
+    scale = np.maximum(np.abs(g32), 1e-30)
+    big = np.abs(g32) > 1e-3 * np.abs(g32).max()
+    assert (err[big] / scale[big]).max() < 2.0 ** -6, (err[big] / scale[big]).max()      # cancellation-free entries: ~2^-8
+    cos = float((g16 * g32).sum() / np.sqrt((g16 * g16).sum() * (g32 * g32).sum()))
+    assert cos > 1.0 - 1e-5, cos
+    assert abs(np.sqrt((g16 * g16).sum()) / np.sqrt((g32 * g32).sum()) - 1.0) < 1e-3    # the global norm the clip sees
+    # the step: same masters, same slots, the two reduced gradients
+    rng = np.random.default_rng(3)
+    w0 = rng.standard_normal(g32.size)
+    outs = []
+    for g in (g32, g16):
+        w, m, v = w0.copy(), np.zeros_like(w0), np.zeros_like(w0)
+        for step in range(1, 4):
+            w, m, v, _ = optim_np.clip_adam_step(w, g / world, m, v, step=step, lr=1e-3)
+        outs.append(w)
+    dw = np.abs(outs[0] - w0)
+    # Adam normalises the step: elements whose gradient is not noise move by ~lr per step either way
+    moved = dw > 1e-4
+    assert np.abs(outs[1] - outs[0])[moved].max() < 2e-5 and np.abs(outs[1] - outs[0]).max() < 3e-3

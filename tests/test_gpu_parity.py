@@ -328,7 +328,7 @@ def test_gate_stream_kernel_against_tap_sharing_kernel(full_model, blk, b, ti, l
 
 @pytest.mark.parametrize("blk,b,ti,layer", [(0, 26, 1000, 0), (0, 8, 8064, 1), (1, 8, 4032, 0), (1, 97, 256, 1), (2, 16, 2016, 1), (2, 25, 1000, 0)])
 def test_co_resident_gate_against_tap_sharing_kernel(full_model, monkeypatch, blk, b, ti, layer):
-    """The experimental co-resident gate (gate_co.h: 4-wave workgroups, two per CU; FWN_GATE_CO=1, read per call) reads the
+    """The experimental co-resident gate (gate_co.h: 4-wave workgroups, two per CU; fwn_set_option("gate_co", 1)) reads the
     same fragment stream as the 8-wave register-streamed kernel in yet another accumulation order (32-channel sub-slices,
     conditioning after the first): same bound against the tap-sharing tile, and repeated launches are bit-identical.
     256-row tiles only (M >= 24 576), all three conditioning widths, both dilations, partial last tiles, Ti = 256."""
@@ -345,10 +345,13 @@ def test_co_resident_gate_against_tap_sharing_kernel(full_model, monkeypatch, bl
     ca = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
     st = torch.cuda.current_stream().cuda_stream
     outs = []
-    for desc, co in ((d, "1"), (d, "1"), (d, "0"), (d_plain, "0")):
-        monkeypatch.setenv("FWN_GATE_CO", co)
+    for desc, co in ((d, 1), (d, 1), (d, 0), (d_plain, 0)):
+        lib.fwn_set_option(b"gate_co", co)
         o = torch.full((m + 8, 256), 7.0, device="cuda", dtype=torch.bfloat16)
-        _lib.check(lib.fwn_gate(C.byref(desc), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
+        try:
+            _lib.check(lib.fwn_gate(C.byref(desc), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
+        finally:
+            lib.fwn_set_option(b"gate_co", 0)
         assert bool((o[m:] == 7.0).all()), "the kernel wrote past row M"
         outs.append(o[:m].float().cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
@@ -378,12 +381,15 @@ def test_persistent_gate_equals_the_one_tile_form_bit_for_bit(full_model, monkey
     st = torch.cuda.current_stream().cuda_stream
 
     def run(flag):
-        monkeypatch.setenv("FWN_RS_PERSIST", flag)
+        lib.fwn_set_option(b"rs_persist", flag)
         o = torch.full((m + 8, 256), 7.0, device="cuda", dtype=torch.bfloat16)
-        _lib.check(lib.fwn_gate(C.byref(d), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
+        try:
+            _lib.check(lib.fwn_gate(C.byref(d), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
+        finally:
+            lib.fwn_set_option(b"rs_persist", -1)
         return o
 
-    want = run("0")
+    want = run(0)
     assert bool((want[m:] == 7.0).all())
     side = torch.cuda.Stream()
     big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
@@ -391,10 +397,10 @@ def test_persistent_gate_equals_the_one_tile_form_bit_for_bit(full_model, monkey
         if rep >= 4:                                  # a bandwidth hog beside the launch
             with torch.cuda.stream(side):
                 big[: 1 << 27].copy_(big[1 << 27:], non_blocking=True)
-        got = run("1")
+        got = run(1)
         torch.cuda.synchronize()
         assert torch.equal(got, want), rep
-    monkeypatch.delenv("FWN_RS_PERSIST")           # the launcher's own choice (persistent from three tiles per workgroup on)
+    # the launcher's own choice (persistent from three tiles per workgroup on)
     o = torch.full((m + 8, 256), 7.0, device="cuda", dtype=torch.bfloat16)
     _lib.check(lib.fwn_gate(C.byref(d), layer, h.data_ptr(), ca.data_ptr(), None, o.data_ptr(), m, ti, st), "fwn_gate")
     assert torch.equal(o, want)
@@ -720,6 +726,90 @@ def test_chained_flows_agree_with_every_flow_on_its_own(full_model, monkeypatch)
                                                                                       float(dw.mean()), float(dw.max())))
         assert float(dzz.mean()) < Z_MEAN and float(dzz.max()) < Z_MAX
         assert float(dw.mean()) < 1e-3 and float(dw.max()) < ABS_WAV
+
+
+def _persist_twins(hp, model, monkeypatch):
+    """Two models from the same parameters (the tables of `model`'s data-dependent init, exported and packed again for both:
+    the device init and the host packing differ in last bits of exp(3 logs)): persist_mode 2 (one launch per small-M flow)
+    and 0 (a launch per stage, the default)."""
+    params = dict(W.synthetic_params(hp, 1234))
+    for k, v in model.export_actnorm().items():
+        params[k] = np.asarray(v, dtype=np.float32).reshape(params[k].shape)
+    plain = FloWaveNet(hp).load_params(params)
+    monkeypatch.setenv("FWN_PERSIST_MODE", "2")
+    one = FloWaveNet(hp).load_params(params)
+    monkeypatch.delenv("FWN_PERSIST_MODE")
+    assert plain._packed.model_desc.persist_mode == 0 and one._packed.model_desc.persist_mode == 2
+    return one, plain
+
+
+@pytest.mark.parametrize("nb,nt", [(8, 16128), (1, 16128), (3, 4096), (1, 2048), (5, 6400)])
+def test_one_launch_flows_equal_the_launch_per_stage_path_bit_for_bit(full_model, monkeypatch, nb, nt):
+    """Round 5 (csrc/flow_persist.h): the flows of the small-M blocks (hoisted conditioning, <= 4096 rows) run as ONE launch
+    each - tickets from an atomic counter, per-row-tile dependency counters, write-through hand-offs - with the arithmetic of
+    the launch-per-stage path: the same MFMA per k-step, the same split-K groups and summation order, the same epilogue
+    expressions.  fwn_model_desc.persist_mode = 2 selects the form (the launch-per-stage path stays the default: DESIGN.md 3.7); log-p, log-det, every latent sample and every
+    waveform sample must be EQUAL.  Shapes: the bench workload (blocks 4 - 7), one clip (blocks 2 - 7: front conv inside the
+    launch from Ch = 16 on, a launch of its own below), clip lengths that put clip edges inside row tiles and leave partial
+    last tiles (4096 / 2048 / 6400 samples: 3 x 16 .. 5 x 25 rows at the last block)."""
+    hp, model0, x, c, z = full_model
+    model, plain = _persist_twins(hp, model0, monkeypatch)
+    xs, cs, zs = x[:nb, :nt].contiguous(), c[:nb, :nt // hp.hop_size].contiguous(), z[:nb, :nt].contiguous()
+    for rep in range(3):
+        lp0, ld0, zp0 = model.forward(xs, cs, return_z=True)
+        w0 = model.reverse(zs, cs)
+        lp1, ld1, zp1 = plain.forward(xs, cs, return_z=True)
+        w1 = plain.reverse(zs, cs)
+        torch.cuda.synchronize()
+        assert torch.equal(zp0, zp1), float((zp0 - zp1).abs().max())
+        assert float(lp0) == float(lp1) and float(ld0) == float(ld1)
+        assert torch.equal(w0, w1), float((w0 - w1).abs().max())
+
+
+@pytest.mark.parametrize("blk,b,inverse", [(7, 8, 0), (7, 1, 1), (5, 3, 0), (4, 8, 1), (3, 1, 0), (2, 1, 1)])
+def test_one_launch_flow_entry_point_and_its_status_word(full_model, blk, b, inverse):
+    """fwn_flow_run_persist against fwn_flow_run on the same operands (one flow, hoisted conditioning from fwn_cond): both
+    planes and the log-det partials bit for bit, the give-up word stays 0, and the call refuses shapes without a one-launch
+    form."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    d = model._packed.flow_descs[blk * hp.n_flow + 2]
+    T = 16128
+    ch = 1 << blk
+    ti = T // (2 * ch)
+    m = b * ti
+    assert lib.fwn_flow_persist_supported(C.byref(d), b, T) == 1
+    assert lib.fwn_flow_persist_supported(C.byref(model._packed.flow_descs[0]), 8, T) == 0     # 64 512 rows
+    rng = np.random.default_rng(blk * 10 + b)
+    st = torch.cuda.current_stream().cuda_stream
+    ca = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    P = torch.empty(hp.n_layer, m, 512, device="cuda", dtype=torch.float32)
+    _lib.check(lib.fwn_cond(ca.data_ptr(), d.Wc[0], P.data_ptr(), 512 * d.kcpad, m * 512, 0, 1, 1, hp.n_layer, m, d.cin, d.kcpad, st), "fwn_cond")
+    xa0 = torch.from_numpy(rng.standard_normal((m, ch)).astype(np.float32) * 0.3).cuda()
+    xb0 = torch.from_numpy(rng.standard_normal((m, ch)).astype(np.float32) * 0.3).cuda()
+    npart = lib.fwn_tail_partials(m)
+    outs = []
+    for persist in (0, 1, 1):
+        xa, xb = xa0.clone(), xb0.clone()
+        h0 = torch.full((m, 256), 3.0, device="cuda", dtype=torch.bfloat16)
+        h1 = torch.full((m, 256), 3.0, device="cuda", dtype=torch.bfloat16)
+        o = torch.full((hp.n_layer, m, 256), 3.0, device="cuda", dtype=torch.bfloat16)
+        part = torch.zeros(npart, device="cuda", dtype=torch.float32)
+        if persist:
+            sync = torch.zeros(lib.fwn_flow_persist_sync_bytes(m, hp.n_layer) // 4, device="cuda", dtype=torch.int32)
+            _lib.check(lib.fwn_flow_run_persist(C.byref(d), b, T, xa.data_ptr(), xb.data_ptr(), h0.data_ptr(), h1.data_ptr(), o.data_ptr(),
+                                                P.data_ptr(), part.data_ptr(), inverse, sync.data_ptr(), st), "fwn_flow_run_persist")
+            assert lib.fwn_flow_persist_status(sync.data_ptr(), st) == 0
+        else:
+            _lib.check(lib.fwn_flow_run(C.byref(d), b, T, xa.data_ptr(), xb.data_ptr(), None, h0.data_ptr(), h1.data_ptr(), o.data_ptr(),
+                                        P.data_ptr(), part.data_ptr(), inverse, 0, st), "fwn_flow_run")
+        torch.cuda.synchronize()
+        outs.append((xa, xb, part, o))
+    for got in outs[1:]:
+        assert torch.equal(got[3], outs[0][3]), "gate outputs differ"
+        assert torch.equal(got[0], outs[0][0]) and torch.equal(got[1], outs[0][1])
+        if not inverse:
+            assert torch.equal(got[2], outs[0][2])
 
 
 def test_full_size_inverse_is_deterministic_and_bounded(full_model):

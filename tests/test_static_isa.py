@@ -11,17 +11,29 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 _ISA = {}
+UNITS = ("flow_kernels", "train_kernels", "aux_kernels")
 
 
-def _flow_kernels_isa(tmp_path_factory):
-    """flow_kernels.hip -> gfx950 ISA, once per session (three minutes of hipcc)."""
-    if "path" not in _ISA:
-        flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=off -fno-slp-vectorize -S --cuda-device-only".split()
-        out = tmp_path_factory.mktemp("isa") / "flow_kernels.s"
-        subprocess.run([HIPCC] + flags + ["-c", os.path.join(CSRC, "flow_kernels.hip"), "-o", str(out)], check=True,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        _ISA["path"] = str(out)
-    return _ISA["path"]
+def _makefile_flags():
+    """The flags libfwn.so is built with, read from the Makefile itself (a hand-copied list would drift: the checks below
+    depend on exact code generation)."""
+    import re
+    text = open(os.path.join(CSRC, "Makefile")).read()
+    arch = re.search(r"^ARCH\s*\?=\s*(\S+)", text, re.M).group(1)
+    flags = re.search(r"^CXXFLAGS\s*=\s*(.*)$", text, re.M).group(1)
+    flags = flags.replace("$(EXTRA)", "").replace("$(ARCH)", arch).split()
+    assert "--offload-arch=gfx950" in flags and "-O3" in flags, flags
+    return flags
+
+
+def _isa(unit, tmp_path_factory):
+    """<unit>.hip -> gfx950 ISA, once per session (flow_kernels.hip: four minutes of hipcc)."""
+    if unit not in _ISA:
+        out = tmp_path_factory.mktemp("isa") / (unit + ".s")
+        subprocess.run([HIPCC] + _makefile_flags() + ["-S", "--cuda-device-only", "-c", os.path.join(CSRC, unit + ".hip"), "-o", str(out)],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _ISA[unit] = str(out)
+    return _ISA[unit]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
@@ -34,8 +46,9 @@ def test_no_register_is_touched_while_an_asm_load_into_it_is_in_flight(tmp_path_
     checker must still see the pattern."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_async_loads as chk
-    flagged = [(name, rep[:2]) for name, body in chk.kernels(_flow_kernels_isa(tmp_path_factory)) for rep in [chk.check(name, body)] if rep]
-    assert not flagged, flagged[:3]
+    for unit in UNITS:       # round 5: the training and auxiliary kernels too (train_kernels.hip runs the same LDS-DMA rings)
+        flagged = [(name, rep[:2]) for name, body in chk.kernels(_isa(unit, tmp_path_factory)) for rep in [chk.check(name, body)] if rep]
+        assert not flagged, (unit, flagged[:3])
     body = ["\tbuffer_load_dwordx4 v[0:3], v9, s[0:3], s4 offen offset:0\n", "\tbuffer_load_dwordx4 v[4:7], v9, s[0:3], s4 offen offset:1024\n",
             "\ts_cbranch_vccz .LBB0_1\n", "\tv_mov_b64_e32 v[10:11], v[0:1]\n", "\ts_waitcnt vmcnt(1)\n", ".LBB0_1:\n",
             "\ts_waitcnt vmcnt(1)\n", "\tv_add_u32_e32 v8, v1, v2\n", "\ts_endpgm\n"]
@@ -43,6 +56,16 @@ def test_no_register_is_touched_while_an_asm_load_into_it_is_in_flight(tmp_path_
     assert len(rep) == 1 and rep[0][1].startswith("v_mov_b64") and rep[0][2] == [0, 1]
     del body[3]
     assert chk.check("k", body) == []
+    # a loop whose SECOND iteration is the wrong one: the same registers are in flight at the label both times,
+    # but behind one store less - the counted wait of the second visit no longer reaches the load
+    loop = ["\tbuffer_load_dwordx4 v[0:3], v9, s[0:3], 0 offen\n", "\tbuffer_store_dword v20, v9, s[0:3], 0 offen\n",
+            "\tbuffer_store_dword v20, v9, s[0:3], 0 offen offset:4\n", ".LBB0_2:\n", "\ts_waitcnt vmcnt(2)\n",
+            "\tv_add_u32_e32 v8, v0, v1\n", "\tbuffer_load_dwordx4 v[0:3], v9, s[0:3], 0 offen\n",
+            "\tbuffer_store_dword v20, v9, s[0:3], 0 offen\n", "\ts_cbranch_scc1 .LBB0_2\n", "\ts_endpgm\n"]
+    rep = chk.check("k", loop)
+    assert len(rep) == 1 and rep[0][1].startswith("v_add_u32") and rep[0][2] == [0, 1]
+    with pytest.raises(chk.WalkLimit):           # running out of steps is an error, never "clean"
+        chk.check("k", loop, max_steps=5)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
@@ -53,9 +76,10 @@ def test_no_ring_barrier_is_crossed_with_lds_reads_in_flight(tmp_path, tmp_path_
     still SEE the pattern: a ring barrier without the wait is flagged."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_barrier_lgkm as chk
-    out = _flow_kernels_isa(tmp_path_factory)
-    flagged = [(name, rep) for name, body in chk.kernels(str(out)) for rep in [chk.check(name, body)] if rep]
-    assert not flagged, flagged[:3]
+    for unit in UNITS:
+        out = _isa(unit, tmp_path_factory)
+        flagged = [(name, rep) for name, body in chk.kernels(str(out)) for rep in [chk.check(name, body)] if rep]
+        assert not flagged, (unit, flagged[:3])
     # the checker on a hand-made body: reads in flight at the barrier, a refill behind it
     body = ["\tds_read_b128 v[0:3], v4\n", "\ts_waitcnt vmcnt(4)\n", "\ts_barrier\n",
             "\tbuffer_load_dwordx4 v5, s[0:3], 0 offen lds\n", "\ts_waitcnt lgkmcnt(0)\n"]

@@ -47,7 +47,7 @@ class ModelDesc(C.Structure):
         ("cond_mode", i32),
         ("gate_fp8", i32),
         ("chain_mode", i32),
-        ("reserved", i32),
+        ("persist_mode", i32),
         ("block_events", C.POINTER(vp)),
     ]
 
@@ -175,6 +175,11 @@ SIGNATURES = {
     "fwn_tail_train": (C.c_int, [C.POINTER(FlowDesc), vp, C.c_int64, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
     "fwn_flow_run": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,
                                C.c_int, vp]),
+    "fwn_flow_persist_supported": (C.c_int, [C.POINTER(FlowDesc), i64, i64]),
+    "fwn_flow_persist_sync_bytes": (i64, [C.c_int, C.c_int]),
+    "fwn_flow_run_persist": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
+    "fwn_flow_persist_status": (C.c_int, [vp, vp]),
+    "fwn_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "fwn_prior_logp": (C.c_int, [vp, i64, vp, C.c_int, vp, vp]),
     "fwn_pack_jobs": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),
     "fwn_tn_gemm": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
@@ -242,6 +247,12 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    # developer switches of the same-box A/B scripts (tools/diag): read ONCE here, handed to the library as options - the
+    # launch path itself reads no environment (round 4's did, on every gate launch)
+    for opt in ("rs_persist", "gate_co"):
+        v = os.environ.get("FWN_OPT_" + opt.upper())
+        if v is not None:
+            lib.fwn_set_option(opt.encode(), int(v))
     _lib = lib
     return lib
 

@@ -368,7 +368,8 @@ struct FlowChain {
 
 static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, const void* ca,
                          void* h0, void* h1, void* o, const float* P, float* partial, int inverse, int ddi,
-                         double* mom, fwn_reduce_fn reduce, void* user, void* h8a, void* h8b, FlowChain* chain, void* stream) {
+                         double* mom, fwn_reduce_fn reduce, void* user, void* h8a, void* h8b, FlowChain* chain, void* stream,
+                         unsigned* sync = nullptr) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(B > 0 && T > 0 && T % (2 * (int64_t)d->Ch) == 0, "fwn_flow_run: T=%lld not divisible by 2*Ch=%d",
@@ -396,6 +397,16 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
     auto fp8_layer = [&](int l) {
         return h8a && h8b && ca && l < d->L && d->Wd8[l] && fwn_gate_fp8_ok(M, dilation_of(l)) && (l > 0 || d->Ch <= 16);
     };
+    // ---- the whole flow as ONE launch (flow_persist.h): small M, hoisted conditioning; `sync` zeroed by the caller ----
+    if (sync && P && !ddi && !h8a && !(chain && (chain->have_h0 || chain->xb_out)) &&
+        fwn_flow_persist_ok(M, d->Ch, d->L, d->npt, d->Wfront2 != nullptr, ((uintptr_t)xa & 15) == 0)) {
+        const int inside = fwn_flow_persist_front_inside(d->Ch);
+        if (!inside)
+            fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h0, h1, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1, nullptr, st);
+        fwn_launch_flow_persist_desc(d, xa, xb, h0, h1, o, P, inverse ? nullptr : partial, sync, M, Ti, inverse, inside, st);
+        if (chain) { chain->h0_next = nullptr; chain->n_partial = fwn_tail_npartials_chain(M, d->Ch, false); }
+        return check_launch("fwn_flow_run_persist");
+    }
     void* h8c = h8a;
     void* h8n = h8b;
     if (!(chain && chain->have_h0))
@@ -448,6 +459,37 @@ int fwn_flow_run_fp8(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, fl
     REQUIRE(h8a && h8b && ALIGNED16(h8a) && ALIGNED16(h8b), "fwn_flow_run_fp8: h8 scratch buffers (16-byte aligned) required");
     return flow_run_impl(d, B, T, xa, xb, ca, h0, h1, o, P, partial, inverse, ddi ? 1 : 0, nullptr, nullptr, nullptr, h8a, h8b,
                          nullptr, stream);
+}
+
+int fwn_flow_persist_supported(const fwn_flow_desc* d, int64_t B, int64_t T) {
+    if (!d || check_desc(d) != FWN_OK || B <= 0 || T <= 0 || T % (2 * (int64_t)d->Ch) != 0) return 0;
+    const int64_t M = B * (T / (2 * d->Ch));
+    if (M > ((int64_t)1 << 30)) return 0;
+    return fwn_flow_persist_ok((int)M, d->Ch, d->L, d->npt, d->Wfront2 != nullptr, true);
+}
+int64_t fwn_flow_persist_sync_bytes(int M, int L) { return (M > 0 && L > 0) ? (int64_t)fwn_flow_persist_sync_words(M, L) * 4 : 0; }
+int fwn_flow_run_persist(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, void* h0, void* h1, void* o,
+                         const float* P, float* partial, int inverse, void* sync, void* stream) {
+    REQUIRE(d && sync && P, "fwn_flow_run_persist: null pointer");
+    REQUIRE(fwn_flow_persist_supported(d, B, T) && (((uintptr_t)xa) & 15) == 0,
+            "fwn_flow_run_persist: this flow / shape has no one-launch form (fwn_flow_persist_supported)");
+    return flow_run_impl(d, B, T, xa, xb, nullptr, h0, h1, o, P, partial, inverse, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, stream, (unsigned*)sync);
+}
+int fwn_flow_persist_status(const void* sync, void* stream) {
+    REQUIRE(sync, "fwn_flow_persist_status: null pointer");
+    unsigned w[2] = {0, 0};
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(w, sync, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(FWN_ERR_HIP, "fwn_flow_persist_status: copy failed");
+    return (int)w[1];
+}
+int fwn_set_option(const char* name, int value) {
+    REQUIRE(name, "fwn_set_option: null name");
+    int* slot = !strcmp(name, "rs_persist") ? &g_fwn_opt_rs_persist : !strcmp(name, "gate_co") ? &g_fwn_opt_gate_co : nullptr;
+    REQUIRE(slot, "fwn_set_option: unknown option '%s'", name);
+    const int old = *slot;
+    *slot = value;
+    return old;
 }
 
 int fwn_prior_logp(const float* planes, int64_t n, const float* partial, int n_partial, float* out2,
@@ -665,7 +707,8 @@ int fwn_clip_adam_dev(float* w, const float* g, float* m, float* v, int64_t n, c
 // Whole-model sequencing
 // ---------------------------------------------------------------------------------------------
 struct Carve {
-    size_t cplanes, up0, up1, planes, plane3, h0, h1, o, P, Ppart, partial, mom, h8a, h8b, total;
+    size_t cplanes, up0, up1, planes, plane3, h0, h1, o, P, Ppart, partial, mom, h8a, h8b, sync, total;
+    size_t sync_stride, sync_bytes;       // one block of counters per flow (flow_persist.h), zeroed once per pass
     int n_partial;
 };
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -676,6 +719,13 @@ static bool hoist_cond(const fwn_model_desc* m, int64_t M, int cin) {
     // small-M blocks: batch the weight-streaming cond GEMMs of all flows - where the conditioning K is long enough to pay for
     // the extra launch and the P round trip
     return M < FWN_TUNE(FWN_HOIST_M, 4096) && cin >= FWN_TUNE(FWN_HOIST_CIN, 256);
+}
+
+// whether block blk's flows run as one launch each (flow_persist.h)
+static bool persist_block(const fwn_model_desc* m, int64_t M, int blk) {
+    if (m->persist_mode != 2 || m->gate_fp8) return false;      // opt-in: measured at parity with / behind the launch-per-stage path
+    const fwn_flow_desc* d = &m->flows[blk * m->n_flow];
+    return hoist_cond(m, M, d->cin) && fwn_flow_persist_ok((int)M, d->Ch, d->L, d->npt, d->Wfront2 != nullptr, true);
 }
 
 static int hop_of(const fwn_model_desc* m) {
@@ -780,6 +830,16 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
     c.mom = off; off = align_up(off + (size_t)m->n_block * m->n_flow * (4 * ((size_t)1 << (m->n_block - 1)) + 1) * 8);
     c.h8a = off; off = align_up(off + (m->gate_fp8 ? Mmax * 256 : 0));      // e4m3 copies of h (fp8 gate path)
     c.h8b = off; off = align_up(off + (m->gate_fp8 ? Mmax * 256 : 0));
+    c.sync_stride = 0;
+    for (int i = 0; i < m->n_block; ++i) {
+        const int64_t M = B * T / ((int64_t)2 << i);
+        if (persist_block(m, M, i)) {
+            const size_t w = (size_t)fwn_flow_persist_sync_words((int)M, m->n_layer) * 4;
+            if (w > c.sync_stride) c.sync_stride = w;
+        }
+    }
+    c.sync_bytes = c.sync_stride * (size_t)m->n_block * m->n_flow;
+    c.sync = off; off = align_up(off + c.sync_bytes);
     c.total = off;
     return c;
 }
@@ -875,6 +935,8 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
 
     run_upsample(m, B, T, mel, ws, c, st);
     fwn_launch_split(x, B, T, planes, st);
+    if (c.sync_bytes && !init && hipMemsetAsync(ws + c.sync, 0, c.sync_bytes, st) != hipSuccess)
+        return fail(FWN_ERR_HIP, "fwn_model_forward: hipMemsetAsync failed");
     int p = 0;
     float* partial = (float*)(ws + c.partial);
     int poff = 0;
@@ -898,8 +960,9 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
             double* mom = (double*)(ws + c.mom) + (size_t)(i * m->n_flow + j) * (4 * ((size_t)1 << (m->n_block - 1)) + 1);
             FlowChain ch = flow_chain(m, d, j + 1 < m->n_flow ? d + 1 : nullptr, (int)M, init != 0, pl.spare, have_h0);
+            unsigned* sync = (!init && persist_block(m, M, i)) ? (unsigned*)(ws + c.sync + (size_t)(i * m->n_flow + j) * c.sync_stride) : nullptr;
             rc = flow_run_impl(d, B, T, pl.at[p], pl.at[p ^ 1], ca, hA, hB, ws + c.o, P, partial + poff, 0, init, mom, reduce, user,
-                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, &ch, stream);
+                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, &ch, stream, sync);
             if (rc) return rc;
             poff += ch.n_partial;
             planes_after_flow(pl, p, ch.xb_out != nullptr);
@@ -950,6 +1013,8 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
 
     run_upsample(m, B, T, mel, ws, c, st);
     fwn_launch_split(z, B, T, planes, st);   // the n_block pre-squeezes of model.py:374-392 are index math
+    if (c.sync_bytes && hipMemsetAsync(ws + c.sync, 0, c.sync_bytes, st) != hipSuccess)
+        return fail(FWN_ERR_HIP, "fwn_model_reverse: hipMemsetAsync failed");
     int p = 0;
     Planes pl{{planes, planes + plane_elems}, (float*)(ws + c.plane3), {planes, planes + plane_elems}};
     for (int i = m->n_block - 1; i >= 0; --i) {
@@ -977,8 +1042,9 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
             const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
             FlowChain ch = flow_chain(m, d, j > 0 ? d - 1 : nullptr, (int)M, false, pl.spare, have_h0);
+            unsigned* sync = persist_block(m, M, i) ? (unsigned*)(ws + c.sync + (size_t)(i * m->n_flow + j) * c.sync_stride) : nullptr;
             rc = flow_run_impl(d, B, T, pl.at[p], pl.at[p ^ 1], ca, hA, hB, ws + c.o, P, nullptr, 1, 0, nullptr, nullptr, nullptr,
-                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, &ch, stream);
+                               m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, &ch, stream, sync);
             if (rc) return rc;
             planes_after_flow(pl, p, ch.xb_out != nullptr);
             have_h0 = ch.h0_next != nullptr;

@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64 * WM * WN) void cond_batch_kernel(CondBatch cb, 
 // Wskip / Wfinal rows are packed in accumulator order (packing.acc_k_perm = bits 2 and 3 of the channel index
 // swapped - an involution), applied to the COLUMN of the 2-byte epilogue stores.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int swap_bits23(int c) { return (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1); }
+#include "tail_zero_prob.h"
 
 struct TailLinProb {      // Y' = ReLU(sum_l A_l[M][256] . W[:, l*256 ..]^T + bias), columns stored at swap_bits23(col)
     static constexpr bool A_DMA = true;
@@ -795,123 +795,6 @@ struct TailLinProb {      // Y' = ReLU(sum_l A_l[M][256] . W[:, l*256 ..]^T + bi
     }
 };
 
-struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of one 32-channel pair tile (tile_n = pt)
-    static constexpr bool A_DMA = true;
-    static constexpr bool ALLOW_256 = false;
-    const bf16* U;        // [M][256]
-    const bf16* Wz;       // [npt*64][256]
-    const float* bz;      // [npt*64]
-    const float* ez;      // [npt*64]
-    const float* an;      // [2][4][Ch]
-    float* xa;
-    float* xb;
-    float* partial;       // [mtiles*8] (forward) or nullptr
-    int M, Ch, npt, inverse;
-    float* save_z;        // optional (training): Z = U Wz + bz, fp32 [M][2 Ch] (log_s channels, then t channels)
-    struct RowCtx { int row; };
-    struct ChunkCtx { int k0; };
-    template <int BK> __device__ int nchunks() const { return FWN_HID / BK; }
-    __device__ RowCtx row_ctx(int row) const { return RowCtx{row}; }
-    template <int BK> __device__ ChunkCtx chunk_ctx(int q) const { return ChunkCtx{q * BK}; }
-    __device__ srd_t a_srd(const ChunkCtx&) const { return make_srd(U, (uint32_t)((size_t)M * FWN_HID * 2)); }
-    __device__ uint32_t a_voff(const ChunkCtx& cc, const RowCtx& rc, int c8) const {
-        return rc.row < M ? (uint32_t)(rc.row * FWN_HID + cc.k0 + c8 * 8) * 2u : FWN_OOB;
-    }
-    __device__ srd_t b_srd(const ChunkCtx&) const { return make_srd(Wz, (uint32_t)(npt * 64u * FWN_HID * 2u)); }
-    __device__ uint32_t b_voff(const ChunkCtx& cc, int n, int c8) const {
-        return (uint32_t)(n * FWN_HID + cc.k0 + c8 * 8) * 2u;
-    }
-    __device__ float acc_init(int col) const { return bz[col]; }     // ZeroConv bias: (acc + b) * exp(3 scale)
-    // gemm_ring.h PREFETCH (small tiles): the two planes' elements this lane transforms in place (no other lane touches them)
-    static constexpr bool PREFETCH = true;
-    template <int MI>
-    __device__ void prefetch(float (&pre)[MI][32], int mrow0, int ncol0, int lane) const {
-        const int tau = (ncol0 >> 6) * 32 + (lane & 31);
-        const uint32_t plane_bytes = (uint32_t)((size_t)M * Ch * 4);
-        const srd_t sxa = make_srd(xa, plane_bytes), sxb = make_srd(xb, plane_bytes);
-        const uint32_t voff = tau < Ch ? (uint32_t)((mrow0 + 4 * (lane >> 5)) * Ch + tau) * 4u : FWN_OOB;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t so = (uint32_t)((mi * 32 + acc_row_c(r)) * Ch * 4);
-                pre[mi][r] = buf_load_f32(sxb, voff, so);
-                pre[mi][16 + r] = buf_load_f32(sxa, voff, so);
-            }
-    }
-    template <int MI>
-    __device__ void epilogue_pre(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
-        epilogue_impl<MI, true>(acc, mrow0, ncol0, lane, pre);
-    }
-    template <int MI>
-    __device__ void epilogue(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane) const {
-        const float none[MI][32] = {};
-        epilogue_impl<MI, false>(acc, mrow0, ncol0, lane, none);
-    }
-    template <int MI, bool PRE>
-    __device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
-        const int lr = lane & 31, pt = ncol0 >> 6;
-        const int tau = pt * 32 + lr;
-        const bool chok = tau < Ch;
-        const int tc = chok ? tau : 0;
-        const float els = ez[pt * 64 + lr], et = ez[pt * 64 + 32 + lr];
-        const float* an_a = an;
-        const float* an_b = an + 4 * Ch;
-        const float a_sh = an_a[tc], a_sc = an_a[Ch + tc], a_isc = an_a[2 * Ch + tc], a_l3 = an_a[3 * Ch + tc];
-        const float b_sh = an_b[tc], b_sc = an_b[Ch + tc], b_isc = an_b[2 * Ch + tc], b_l3 = an_b[3 * Ch + tc];
-        const uint32_t plane_bytes = (uint32_t)((size_t)M * Ch * 4);
-        const srd_t sxa = make_srd(xa, plane_bytes), sxb = make_srd(xb, plane_bytes);
-        const int rbase = mrow0 + 4 * (lane >> 5);
-        const uint32_t voff = chok ? (uint32_t)(rbase * Ch + tau) * 4u : FWN_OOB;     // rows past M fall off the descriptor
-        const srd_t sz = make_srd(save_z ? save_z : xb, save_z ? (uint32_t)((size_t)M * 2 * Ch * 4) : 0u);
-        const uint32_t zoff = chok ? (uint32_t)(rbase * 2 * Ch + tau) * 4u : FWN_OOB;
-        float lsum = 0.0f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            float xbv[16], xav[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t so = (uint32_t)((mi * 32 + acc_row_c(r)) * Ch * 4);
-                xbv[r] = PRE ? pre[mi][r] : buf_load_f32(sxb, voff, so);
-                xav[r] = PRE ? pre[mi][16 + r] : buf_load_f32(sxa, voff, so);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t so = (uint32_t)((mi * 32 + acc_row_c(r)) * Ch * 4);
-                const bool ok = chok && rbase + mi * 32 + acc_row_c(r) < M;
-                const float ls = acc[mi][0][r] * els, t = acc[mi][1][r] * et;
-                float ob, oa;
-                if (!inverse) {
-                    const float yb = (xbv[r] + b_sh) * b_sc;                  // ActNorm (model.py:86-94)
-                    ob = (yb - t) * __expf(-ls);                               // model.py:134
-                    oa = (xav[r] + a_sh) * a_sc;
-                    lsum += ok ? (a_l3 + b_l3 - ls) : 0.0f;                    // model.py:135 + :80
-                } else {
-                    const float yb = xbv[r] * __expf(ls) + t;                  // model.py:156
-                    ob = yb * b_isc - b_sh;                                    // ActNorm^-1 (model.py:97-102)
-                    oa = xav[r] * a_isc - a_sh;
-                }
-                buf_store_f32(sxb, voff, so, ob);
-                buf_store_f32(sxa, voff, so, oa);
-                if (save_z) {
-                    buf_store_f32(sz, zoff, 2 * so, acc[mi][0][r]);
-                    buf_store_f32(sz, zoff, 2 * so + (uint32_t)(Ch * 4), acc[mi][1][r]);
-                }
-            }
-        }
-        if (partial) {          // one slot per (row tile, pair tile, wave row): fixed order, summed by prior_kernel
-#pragma unroll
-            for (int s = 32; s > 0; s >>= 1) lsum += __shfl_xor(lsum, s);
-            const int tile_m = mrow0 >> 6, wm = (mrow0 >> 5) & 1;
-            if (lane == 0) {
-                partial[(tile_m * 4 + pt) * 2 + wm] = lsum;
-                if (pt == 0)
-                    for (int p2 = npt; p2 < 4; ++p2) partial[(tile_m * 4 + p2) * 2 + wm] = 0.0f;
-            }
-        }
-    }
-};
-
 #include "tail_chain.h"
 
 // ---------------------------------------------------------------------------
@@ -946,6 +829,21 @@ int fwn_tail_npartials_chain(int M, int Ch, int front) {       // log-det partia
     return (M + rw - 1) / rw;
 }
 int fwn_tail_npartials(int M) { return fwn_tail_npartials_chain(M, 0, 0); }
+
+// process-wide developer options (fwn_set_option in api.hip; round 4 read two environment variables on every gate launch)
+int g_fwn_opt_rs_persist = -1, g_fwn_opt_gate_co = 0;
+// compute units of the CURRENT device, cached per device (a process may drive several)
+int fwn_device_cus() {
+    static int cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 2) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
 
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -1064,21 +962,16 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
         // soaks clean inside overlapped passes at 8 / 16 / 32 clips.  Used where a workgroup gets three tiles or more (from
         // 13 clips of 16128 samples on at block 0: 32 clips -1.9 % on the one-stream pair, -0.8 % on the overlapped step);
         // at the bench's 8 clips (two tiles per workgroup) the overlapped step is 1.5 % slower with it: one tile per
-        // workgroup there.  FWN_RS_PERSIST=0 / 1 (read per call) forces either form.
-        const char* pe = getenv("FWN_RS_PERSIST");
-        static const int ncu = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 2) n = 256;
-            return n & ~1;
-        }();
+        // workgroup there.  fwn_set_option("rs_persist", 0 / 1) forces either form (round 4 read an environment variable here, per launch).
+        const int ncu = fwn_device_cus() & ~1;
         const int mt = gate_stream_mt(M);
-        const bool persist = mt == 8 && (pe && (pe[0] == '0' || pe[0] == '1') ? pe[0] == '1' : ((M + 255) / 256) * 2 >= 3 * ncu);
+        const int pe = g_fwn_opt_rs_persist;            // fwn_set_option("rs_persist", ..): -1 auto
+        const bool persist = mt == 8 && (pe >= 0 ? pe == 1 : ((M + 255) / 256) * 2 >= 3 * ncu);
         // 256-row tiles, experimental: the co-resident form (gate_co.h: 4-wave workgroups of 256 rows x 64 channels, two per
         // CU) reads the same stream.  Stand-alone it is 1 - 5 % faster per launch than the 8-wave form (tools/bench_gate_co.hip),
         // inside the overlapped passes the step is unchanged (5.82 against 5.80 ms, three interleaved rounds on one box):
-        // FWN_GATE_CO=1 selects it, the product keeps the 8-wave form.
-        const char* co_env = getenv("FWN_GATE_CO");        // read per call: tests/test_gpu_parity.py flips it inside one process
-        const bool co = co_env && co_env[0] == '1';
+        // fwn_set_option("gate_co", 1) selects it, the product keeps the 8-wave form.
+        const bool co = g_fwn_opt_gate_co == 1;            // fwn_set_option("gate_co", 1): tests flip it inside one process
         if (mt == 8 && co && !persist) {
             const int grid4 = ((M + 255) / 256) * 4;
 #define X(n) if (nkc == n) hipLaunchKernelGGL((gate_co_kernel<n>), dim3(grid4), dim3(256), 0, st, a);

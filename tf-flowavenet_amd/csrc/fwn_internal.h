@@ -65,6 +65,17 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
                      float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse, void* scratch_s,
                      void* scratch_u, const fwn_tail_chain* chain, hipStream_t st);
 
+// one flow of the small-M chain as one launch (flow_persist.h)
+struct fwn_flow_desc;
+int fwn_flow_persist_sync_words(int M, int L);
+int fwn_flow_persist_ok(int M, int Ch, int L, int npt, bool has_w2, bool xa_aligned);
+int fwn_flow_persist_front_inside(int Ch);
+void fwn_launch_flow_persist_desc(const fwn_flow_desc* d, float* xa, float* xb, void* hA, void* hB, void* o, const float* P,
+                                  float* partial, unsigned* sync, int M, int Ti, int inverse, int has_front, hipStream_t st);
+// process-wide developer options (fwn_set_option): -1 = auto
+extern int g_fwn_opt_rs_persist, g_fwn_opt_gate_co;
+int fwn_device_cus();            // compute units of the current device (cached per device)
+
 int fwn_tail_rows(int M);        // rows per fused-tail workgroup
 int fwn_tail_is_split(int M);    // the N-split tail (ring GEMMs; needs [2][M][256] bf16 scratch) serves this M
 int fwn_tail_npartials(int M);   // log-det partial slots a plain (un-chained) tail launch writes

@@ -1037,7 +1037,7 @@ __device__ __forceinline__ void tn_gemm_body(const TnGroup& grp, const int bid) 
     for (int q = 0; q < nq; ++q) {
         const int pending = min(nq, q + D - 1) - (q + 1);
         if (pending >= 1) FWN_WAIT_VMCNT(PX + PY); else FWN_WAIT_VMCNT(0);
-        __builtin_amdgcn_s_barrier();
+        FWN_RING_BARRIER();      // the slot read by the previous chunk is refilled behind it: retire this wave's LDS reads first (gemm_ring.h)
         if (q + D - 1 < nq) issue(q + D - 1);
         const unsigned char* xa = lds + (q % D) * SLOT + (wi >> 1) * TILE;
         const unsigned char* ya = lds + (q % D) * SLOT + (XP + (wj >> 1)) * TILE;

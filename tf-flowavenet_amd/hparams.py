@@ -24,6 +24,9 @@ _COMMON = dict(
     # not in the reference: run the dilated taps of the gated layers on the fp8 (e4m3) MFMA path where the shape has
     # such a kernel (BASELINE configs[4]); inference only, log_p stays within the 1e-3 tolerance (tests/test_fp8.py)
     gate_fp8=False,
+    # not in the reference: dtype of the data-parallel gradient exchange (utils.py:34-60 averages fp32 tower gradients):
+    # "fp32", or "bf16" = half the bytes over xGMI; masters, Adam slots and the update stay fp32
+    grad_reduce_dtype="fp32",
 )
 
 _22K = dict(n_fft=1024, hop_size=256, sample_rate=22050, fmax=7600, max_time_steps=6400,

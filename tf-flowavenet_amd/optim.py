@@ -62,15 +62,50 @@ def bucket_bounds(n: int, bucket_elems: int):
     return [(lo, min(n, lo + bucket_elems)) for lo in range(0, n, bucket_elems)]
 
 
-def allreduce_flat(grad, group=None, bucket_elems=64 << 20, async_op=True):
+REDUCE_DTYPES = ("fp32", "bf16")
+
+
+class _Bf16Work:
+    """Handle of one bf16 all-reduce of a slice of the fp32 gradient: ``wait()`` waits for the collective, then widens the
+    summed bf16 values back into the fp32 slice (stream-ordered on the GPU like the collective's own wait)."""
+
+    def __init__(self, work, dst, src16):
+        self.work, self.dst, self.src16 = work, dst, src16
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(self.src16)
+
+
+def allreduce_slice(g, lo, hi, group=None, reduce_dtype="fp32", stage=None):
+    """Start the all-reduce (sum) of ``g[lo:hi]`` and return its handle.  reduce_dtype "bf16" (362 MB
+    instead of 724.5 MB per step over xGMI): the slice is rounded to bf16 into ``stage[lo:hi]`` (a bf16 buffer as long as
+    g), summed there by the collective - every rank receives the same bf16 sums, so the lock-step of the masters is
+    untouched - and widened back on ``wait()``.  Each rank's contribution carries one bf16 rounding (2^-9 relative) and so
+    does every partial sum of the ring: against the fp32 exchange the reduced gradient moves by <= ~2^-8 per element
+    relative to the largest partial sum (tests/test_dist.py bounds the step built from it)."""
+    import torch.distributed as dist
+    if reduce_dtype not in REDUCE_DTYPES:
+        raise ValueError("grad_reduce_dtype must be one of %s" % (REDUCE_DTYPES,))
+    if reduce_dtype == "fp32":
+        return dist.all_reduce(g[lo:hi], group=group, async_op=True)
+    s16 = stage[lo:hi]
+    s16.copy_(g[lo:hi])
+    return _Bf16Work(dist.all_reduce(s16, group=group, async_op=True), g[lo:hi], s16)
+
+
+def allreduce_flat(grad, group=None, bucket_elems=64 << 20, async_op=True, reduce_dtype="fp32", stage=None):
     """Sum ``grad`` (flat tensor, any device) over ranks bucket by bucket.  Buckets are issued
     back to back (asynchronously) so a caller can interleave them with backward compute; xGMI is
     point-to-point, so fewer, larger buckets (256 MB of fp32 each by default) keep every link busy.
-    Returns the list of work handles (already waited when async_op=False)."""
+    Returns the list of work handles (already waited when async_op=False).  reduce_dtype / stage: ``allreduce_slice``."""
+    import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return []
-    works = [dist.all_reduce(grad[lo:hi], group=group, async_op=True) for lo, hi in bucket_bounds(grad.numel(), bucket_elems)]
+    if reduce_dtype == "bf16" and stage is None:
+        stage = torch.empty(grad.numel(), dtype=torch.bfloat16, device=grad.device)
+    works = [allreduce_slice(grad, lo, hi, group, reduce_dtype, stage) for lo, hi in bucket_bounds(grad.numel(), bucket_elems)]
     if not async_op:
         for w in works:
             w.wait()
@@ -82,12 +117,18 @@ class DataParallelAdam:
     norm -> clip -> Adam, returning the (device) global gradient norm."""
 
     def __init__(self, hp, params, device="cuda", clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8, group=None,
-                 bucket_elems=64 << 20):
+                 bucket_elems=64 << 20, grad_reduce_dtype="fp32"):
         import torch
+        if grad_reduce_dtype not in REDUCE_DTYPES:
+            raise ValueError("grad_reduce_dtype must be one of %s" % (REDUCE_DTYPES,))
         self.layout = FlatLayout(hp)
         self.device = device
         self.group = group
         self.bucket_elems = bucket_elems
+        # "bf16": the gradient exchange moves bf16 (half the xGMI bytes, SURVEY section 8e); masters, Adam slots, the global
+        # norm and the update stay fp32.  The staging buffer is allocated on first use.
+        self.grad_reduce_dtype = grad_reduce_dtype
+        self._g16 = None
         # True: issue the collectives even in a one-rank group (tests / bench exercise the RCCL path on one GPU)
         self.force_collectives = False
         self.clip, self.b1, self.b2, self.eps = clip, beta1, beta2, eps
@@ -158,7 +199,13 @@ class DataParallelAdam:
             return None
         if dist.get_world_size(self.group) == 1 and not self.force_collectives:
             return None
-        return dist.all_reduce(self.g[lo:hi], group=self.group, async_op=True)
+        return allreduce_slice(self.g, lo, hi, self.group, self.grad_reduce_dtype, self._stage())
+
+    def _stage(self):
+        import torch
+        if self.grad_reduce_dtype == "bf16" and self._g16 is None:
+            self._g16 = torch.empty(self.g.numel(), dtype=torch.bfloat16, device=self.g.device)
+        return self._g16
 
     def step(self, loss_scale=1.0, works=None):
         """``self.g`` holds this rank's gradient of (loss_scale * loss).  works: handles of all-reduces
@@ -166,7 +213,7 @@ class DataParallelAdam:
         import torch
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
-        for w in (allreduce_flat(self.g, self.group, self.bucket_elems) if works is None else works):
+        for w in (allreduce_flat(self.g, self.group, self.bucket_elems, True, self.grad_reduce_dtype, self._stage()) if works is None else works):
             if w is not None:
                 w.wait()
         gscale = 1.0 / (world * float(loss_scale))

@@ -656,6 +656,8 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
     md.cond_mode = int(cond_mode)
     # developer switch (same-box A/B, tests): FWN_CHAIN_MODE=1 runs every flow on its own like round 2 (fwn.h chain_mode)
     md.chain_mode = int(os.environ.get("FWN_CHAIN_MODE", "0"))
+    # developer switch: FWN_PERSIST_MODE=2 runs the small-M flows as ONE launch each (fwn.h persist_mode; default: a launch per stage)
+    md.persist_mode = int(os.environ.get("FWN_PERSIST_MODE", "0"))
     md.gate_fp8 = 1 if gate_fp8 else 0
     torch.cuda.current_stream(dev).synchronize()
     if gate_fp8:                                   # the exponents the pack kernels chose, in one copy

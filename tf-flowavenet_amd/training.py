@@ -724,7 +724,7 @@ class Trainer:
         import os
         from .optim import DataParallelAdam
         self.hp, self.device = hparams, device
-        self.opt = DataParallelAdam(hparams, params, device, group=group)
+        self.opt = DataParallelAdam(hparams, params, device, group=group, grad_reduce_dtype=getattr(hparams, "grad_reduce_dtype", "fp32"))
         self.engine = GradEngine(hparams, device)
         if graph is None:
             graph = os.environ.get("FWN_TRAIN_GRAPH", "1") != "0"

@@ -85,10 +85,18 @@ def decode(body):
     return recs
 
 
-def check(name, body, max_steps=4000000):
+class WalkLimit(RuntimeError):
+    """The walk ran into max_steps: nothing may be concluded about the kernel (never report it clean)."""
+
+
+def check(name, body, max_steps=20000000):
     """Walk the control-flow graph (not the listing: hipcc lays a loop's latch out in front of its header): both arms of
-    every conditional branch; a state = (program counter at a label, the destination registers still in flight); a state
-    seen before is not walked again."""
+    every conditional branch; a state = (program counter at a label, the QUEUE of operations in flight - the destination
+    registers of every entry in issue order from the oldest register still in flight on, entries without a destination
+    (LDS-DMA, stores) behind it included: a later
+    `s_waitcnt vmcnt(N)` retires by position, so two visits of a label with the same registers in flight but queues of
+    different depth are different states - round 4's key (registers only) pruned a loop's second iteration whose counted
+    waits reached less far than the first's); a state seen before is not walked again.  Running into max_steps raises."""
     recs = decode(body)
     reports, seen_rep, seen = [], set(), set()
     work = [(0, ())]
@@ -107,7 +115,14 @@ def check(name, body, max_steps=4000000):
             if kind == "skip":
                 continue
             if kind == "label":
-                key = (pc, frozenset(inflight))
+                # what matters about the queue: which registers are in flight and how many operations are younger than each
+                # (a later `s_waitcnt vmcnt(N)` retires by position); the counter saturates at 63, so counts are capped -
+                # a loop that issues stores beside a load it never waits for then reaches a fixed point
+                while len(queue) > 80 and not any(inflight.get(r) == queue[0][0] for r in queue[0][1]):
+                    del queue[0]                     # register-free entries that no vmcnt(N <= 63) distinguishes any more
+                n = len(queue)
+                key = (pc, tuple((frozenset(r for r in regs if inflight.get(r) == idx), min(n - 1 - i, 64))
+                                 for i, (idx, regs) in enumerate(queue) if any(inflight.get(r) == idx for r in regs)))
                 if key in seen:
                     break
                 seen.add(key)
@@ -143,6 +158,8 @@ def check(name, body, max_steps=4000000):
                     seen_rep.add(pc)
                     hit.sort()
                     reports.append((pc, t, hit, (inflight[hit[0]], body[inflight[hit[0]] - 1].strip())))
+    if steps >= max_steps:
+        raise WalkLimit("%s: control-flow walk stopped after %d steps" % (name, steps))
     reports.sort()
     return reports
 

@@ -39,6 +39,8 @@ def stage_of(name):
         return "tail"
     if name.startswith("cond_"):
         return "cond"
+    if name.startswith("flow_persist_kernel"):
+        return "flow"                    # round 5: one launch per flow of the small-M chain (csrc/flow_persist.h)
     return "other"
 
 
@@ -69,12 +71,12 @@ def main():
         if base.startswith("prior_kernel") or base.startswith("merge_kernel"):
             passes.append(("fwd" if base.startswith("prior_kernel") else "inv", cur))
             cur = None
-    stages = ("front", "gate", "res", "tail", "cond", "other")
+    stages = ("front", "gate", "res", "tail", "cond", "flow", "other")
     out = {}
     for direction in ("fwd", "inv"):
         sel = [p for d, p in passes if d == direction]
         # only whole-model passes without the data-dependent init: 48 coupling launches, no ddi kernel
-        closes = lambda n: n.startswith("tail_kernel") or "TailZeroProb" in n
+        closes = lambda n: n.startswith("tail_kernel") or "TailZeroProb" in n or n.startswith("flow_persist_kernel")
         good = []
         for p in sel:
             if sum(1 for _, _, n in p if closes(n)) == N_BLOCK * N_FLOW and not any(n.startswith("ddi_") for _, _, n in p):
@@ -127,11 +129,11 @@ def main():
         print("%s: %d passes, kernel time %.3f ms/pass (first launch -> last end: %.3f ms), %.1f GFLOP -> %.3f of the 2.5 PF bf16 peak (span: %.3f)"
               % (direction, npass, kernel_ms, span / npass / 1e6, tot_flop / 1e9, out[direction]["frac_of_mfma_peak_kernel_time"],
                  out[direction]["frac_of_mfma_peak_span"]))
-        print("  block   rows  launches      us   GFLOP   frac |  front    gate     res    tail    cond")
+        print("  block   rows  launches      us   GFLOP   frac |  front    gate     res    tail    cond    flow (one launch per flow)")
         for t in table:
-            print("  %5d %6d %9d %7.1f %7.1f %6.3f | %6.1f %7.1f %7.1f %7.1f %7.1f" % (
+            print("  %5d %6d %9d %7.1f %7.1f %6.3f | %6.1f %7.1f %7.1f %7.1f %7.1f %7.1f" % (
                 t["block"], t["rows"], t["launches"], t["us"], t["gflop"], t["frac"], t.get("front_us", 0), t.get("gate_us", 0),
-                t.get("res_us", 0), t.get("tail_us", 0), t.get("cond_us", 0)))
+                t.get("res_us", 0), t.get("tail_us", 0), t.get("cond_us", 0), t.get("flow_us", 0)))
         print("  upsample / split / merge / prior / copies: %.1f us" % other_us)
     if a.json:
         import os
