@@ -207,7 +207,10 @@ __device__ __forceinline__ void ps_kloop(f32x16 (&tot)[2], float c0, float c1, c
         }                                                                                                              \
     } while (0)
     // (sched_barrier: left alone, hipcc interleaves every read with the MFMA that needs it and waits for it at once)
-    if constexpr (TWO) {                                       // (the ZeroConv: 16 k-steps; one buffer - two would spill)
+    if constexpr (TWO || NACC == 4) {
+        // one buffer: the ZeroConv (two column halves) and the four-chain form (four accumulators) have no registers for a
+        // second one - a spilled register means scratch memory, and a kernel that needs scratch starts several microseconds
+        // later than one that does not; four independent MFMA chains cover most of the read latency by themselves
         for (int idx = 0; idx < nch; ++idx) {
             PS_LD(idx, fa, fb, fc);
             __builtin_amdgcn_sched_barrier(0);
