@@ -292,7 +292,30 @@ def _median_pass_s(fn, iters):
     return ts[len(ts) // 2] * 1e-3
 
 
-def latency_b1(model, hp, t, dev, iters=10):
+def one_launch_twin(model, hp, params, dev):
+    """The same parameters (the data-dependent init's tables exported from `model`) packed twice more: with
+    fwn_model_desc.persist_mode = 2 (csrc/flow_persist.h: ONE launch per small-M flow) and with the default (a launch per
+    stage) - the pair whose results must be equal bit for bit (the device init and the host packing of `model` itself differ
+    in last bits of exp(3 logs))."""
+    import numpy as np
+    from tf_flowavenet_amd.model import FloWaveNet
+    p2 = dict(params)
+    for k, v in model.export_actnorm().items():
+        p2[k] = np.asarray(v, dtype=np.float32).reshape(np.asarray(p2[k]).shape)
+    plain = FloWaveNet(hp, device=dev).load_params(p2)
+    old = os.environ.get("FWN_PERSIST_MODE")
+    os.environ["FWN_PERSIST_MODE"] = "2"
+    try:
+        one = FloWaveNet(hp, device=dev).load_params(p2)
+    finally:
+        if old is None:
+            del os.environ["FWN_PERSIST_MODE"]
+        else:
+            os.environ["FWN_PERSIST_MODE"] = old
+    return one, plain
+
+
+def latency_b1(model, hp, t, dev, iters=10, params=None):
     """configs[1] at the latency shape: ONE 16128-sample clip, forward and inverse, HIP events on the launch stream."""
     import torch
     from tf_flowavenet_amd import weights as W
@@ -307,7 +330,22 @@ def latency_b1(model, hp, t, dev, iters=10):
     fwd, inv = timed(lambda: model.forward(x, c)), timed(lambda: model.reverse(z, c))
     flop = flop_per_sample(hp) * t
     bound = BOUND_US.get("B1_T%d" % t)
+    one_launch = None
+    if params is not None:       # round 5: the same clip with one launch per small-M flow (opt-in form), next to the default
+        try:
+            one, plain = one_launch_twin(model, hp, params, dev)
+            f1, i1 = timed(lambda: one.forward(x, c)), timed(lambda: one.reverse(z, c))
+            a, b_ = one.forward(x, c, return_z=True), plain.forward(x, c, return_z=True)
+            same = bool(torch.equal(a[2], b_[2])) and float(a[0]) == float(b_[0]) and float(a[1]) == float(b_[1]) and \
+                bool(torch.equal(one.reverse(z, c), plain.reverse(z, c)))
+            one_launch = {"fwd_ms": f1 * 1e3, "inv_ms": i1 * 1e3, "bit_identical_to_launch_per_stage": same,
+                          "what": "fwn_model_desc.persist_mode = 2: blocks 2 - 7 of this clip as one launch per flow "
+                                  "(csrc/flow_persist.h; DESIGN.md section 3.7); the default path is the line's fwd_ms / inv_ms"}
+            del one, plain
+        except Exception as e:   # a diagnostic: never instead of the line
+            one_launch = {"error": "%s: %s" % (type(e).__name__, e)}
     return {"workload": "configs[1] latency shape: B=1, T=%d" % t, "fwd_ms": fwd * 1e3, "inv_ms": inv * 1e3,
+            "one_launch_flows": one_launch,
             "fwd_mfma_frac": flop / fwd / 1e12 / MFMA_PEAK_TFLOPS, "inv_mfma_frac": flop / inv / 1e12 / MFMA_PEAK_TFLOPS,
             "survey_bound_us": bound, "fwd_frac_of_survey_bound": bound * 1e-6 / fwd if bound else None,
             "inv_frac_of_survey_bound": bound * 1e-6 / inv if bound else None,
@@ -712,7 +750,7 @@ def main():
         }
         out["roofline"] = gate_roofline(model, hp, b, t)
         out["path"] = path_roofline(hp, b, t, fwd_s, inv_s, block_table(model, hp, b, t, x, c, z))
-        out["latency_b1"] = None if args.no_latency else latency_b1(model, hp, t, dev)
+        out["latency_b1"] = None if args.no_latency else latency_b1(model, hp, t, dev, params=params)
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None
         else:

@@ -252,8 +252,9 @@ int fwn_flow_run_persist(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
 int fwn_flow_persist_status(const void* sync, void* stream);
 
 /* ---- process-wide developer options (replaces the environment variables the launch path read in round 4) ----
- * name: "rs_persist" (-1 auto, 0 / 1: the register-streamed gate's persistent form off / on), "gate_co" (0 / 1: the
- * experimental co-resident gate).  Returns the previous value, or FWN_ERR_ARG for an unknown name. */
+ * name: "rs_persist" (-1 auto, 0 / 1: the register-streamed gate's persistent form off / on).  Returns the previous value,
+ * or FWN_ERR_ARG for an unknown name.  (Round 4's second switch, the experimental co-resident gate, left the library:
+ * tools/gate_co.h + tools/bench_gate_co.hip.) */
 int fwn_set_option(const char* name, int value);
 
 /* The same flow with the gated layers' dilated taps in fp8 wherever fwn_gate_fp8_supported says so (other layers /
@@ -500,7 +501,10 @@ typedef struct fwn_train_desc {
     int32_t zero_dead_res;                      /* != 0: also zero the gradients of the dead last-layer res_conv */
     /* != 0 (with side_stream): nothing consumes a block's gradients before the end of the call (one rank: no all-reduce),
      * so the side stream is NOT joined into `stream` block by block - the data-gradient chain never waits for the weight
-     * gradients - but once, behind block 0; on_block_done(n_block - 1 .. 0) are then all called at that point, in order. */
+     * gradients - but once, behind block 0; on_block_done(n_block - 1 .. 0) are then all called at that point, in order
+     * (each still fires only after its block's gradients are complete in `stream` order - but none of them early: a hook that
+     * starts collectives to overlap them with the backward pass wants 0 here).  On an error return every path first joins the
+     * side stream into `stream`: nothing of the call is left running on it. */
     int32_t defer_block_done;
     /* Optional second hipStream_t (NULL: one stream).  The weight gradients of block i (grouped TN GEMMs + weight-norm
      * backward) and its conditioning-gradient GEMMs then run on it under the data-gradient chain of block i - 1 and are

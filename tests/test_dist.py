@@ -222,12 +222,17 @@ def test_bf16_gradient_exchange_is_lockstep_and_bounds_the_step():
         assert np.array_equal(res[0][key], res[1][key]), key                  # identical on both ranks, bit for bit
     assert np.array_equal(res[0]["bf16"], res[0]["ranges"])                    # bucket bounds do not matter
     g32, g16 = res[0]["fp32"].astype(np.float64), res[0]["bf16"].astype(np.float64)
-    # each rank's term rounded to bf16 (2^-9 relative each), the sum rounded once more
-    parts = [np.abs(x) for x in (g32,)]
+    # each rank's term rounded to bf16 (2^-9 relative each), the sum rounded once more - to nearest by RCCL, by truncation in
+    # gloo's bf16 reduction (measured here: 1.9 x 2^-8): |error| <= 3 x 2^-8 (|a| + |b|) per element (relative to the SUM it
+    # can be anything where the two ranks' terms cancel)
+    terms = []
+    for rank in range(world):
+        rng = np.random.default_rng(7 + rank)
+        t = (rng.standard_normal(g32.size) * np.exp(rng.standard_normal(g32.size) * 2.0)).astype(np.float32)
+        t[rng.integers(0, g32.size, 500)] = 0.0
+        terms.append(np.abs(t.astype(np.float64)))
     err = np.abs(g16 - g32)
-    scale = np.maximum(np.abs(g32), 1e-30)
-    big = np.abs(g32) > 1e-3 * np.abs(g32).max()
-    assert (err[big] / scale[big]).max() < 2.0 ** -6, (err[big] / scale[big]).max()      # cancellation-free entries: ~2^-8
+    assert (err <= 3 * 2.0 ** -8 * (terms[0] + terms[1]) + 1e-30).all(), float((err / (terms[0] + terms[1] + 1e-30)).max())
     cos = float((g16 * g32).sum() / np.sqrt((g16 * g16).sum() * (g32 * g32).sum()))
     assert cos > 1.0 - 1e-5, cos
     assert abs(np.sqrt((g16 * g16).sum()) / np.sqrt((g32 * g32).sum()) - 1.0) < 1e-3    # the global norm the clip sees
@@ -238,9 +243,10 @@ def test_bf16_gradient_exchange_is_lockstep_and_bounds_the_step():
     for g in (g32, g16):
         w, m, v = w0.copy(), np.zeros_like(w0), np.zeros_like(w0)
         for step in range(1, 4):
-            w, m, v, _ = optim_np.clip_adam_step(w, g / world, m, v, step=step, lr=1e-3)
+            (gc,), _ = optim_np.clip_by_global_norm([g / world], 1.0)
+            w, m, v = optim_np.adam_step(w, gc, m, v, step, 1e-3)
         outs.append(w)
-    dw = np.abs(outs[0] - w0)
-    # Adam normalises the step: elements whose gradient is not noise move by ~lr per step either way
-    moved = dw > 1e-4
-    assert np.abs(outs[1] - outs[0])[moved].max() < 2e-5 and np.abs(outs[1] - outs[0]).max() < 3e-3
+    # Adam normalises the step (every element moves by ~lr per step whatever its gradient's size), so where the ranks' terms
+    # cancel and the bf16 sum differs in relative terms - or in sign - an element can end up to 2 x 3 lr away; those are few:
+    d = np.abs(outs[1] - outs[0])
+    assert d.max() <= 6.1e-3 and np.median(d) < 3e-6 and (d > 3e-4).mean() < 0.01, (d.max(), np.median(d), (d > 3e-4).mean())

@@ -249,7 +249,7 @@ def load():
         fn.argtypes = args
     # developer switches of the same-box A/B scripts (tools/diag): read ONCE here, handed to the library as options - the
     # launch path itself reads no environment (round 4's did, on every gate launch)
-    for opt in ("rs_persist", "gate_co"):
+    for opt in ("rs_persist",):
         v = os.environ.get("FWN_OPT_" + opt.upper())
         if v is not None:
             lib.fwn_set_option(opt.encode(), int(v))

@@ -527,7 +527,6 @@ struct GateProb {
 
 #include "gate_halo.h"
 #include "gate_rs.h"
-#include "gate_co.h"
 
 // ---- residual 1x1: h' = (h + res_conv(o)) * sqrt(0.5), modules.py:126-128 ------------------
 struct ResProb {
@@ -800,13 +799,19 @@ struct TailLinProb {      // Y' = ReLU(sum_l A_l[M][256] . W[:, l*256 ..]^T + bi
 // ---------------------------------------------------------------------------
 // Host-side launchers (called from the C-ABI in api.hip)
 // ---------------------------------------------------------------------------
+// FWN_TAIL128_TWO = 1: from FWN_TAIL256_MIN rows on (block 0 of the 8-clip pass: two workgroups of 128 rows per CU exist)
+// the fused tail runs as 128-row workgroups with 32-wide phase-1 chunks in TWO 32 KB slots (72 KB of LDS: two per CU, one's
+// DMA latency and epilogue under the other's MFMA chains) instead of one 256-row workgroup per CU.  Measured below.
+#ifndef FWN_TAIL128_TWO
+#define FWN_TAIL128_TWO 0
+#endif
 #ifndef FWN_TAIL256_MIN
 #define FWN_TAIL256_MIN (192 * 256)
 #endif
 #ifndef FWN_TAIL_SPLIT_MAX
 #define FWN_TAIL_SPLIT_MAX 12288      // rows up to which the N-split tail (three ring GEMMs) replaces the fused tail
 #endif
-int fwn_tail_rows(int M) { return M >= FWN_TAIL256_MIN ? 256 : 128; }   // rows per fused-tail workgroup
+int fwn_tail_rows(int M) { return (M >= FWN_TAIL256_MIN && !FWN_TUNE(FWN_TAIL128_TWO, FWN_TAIL128_TWO)) ? 256 : 128; }   // rows per fused-tail workgroup
 int fwn_tail_is_split(int M) { return M <= FWN_TUNE(FWN_TAIL_SPLIT_MAX, FWN_TAIL_SPLIT_MAX); }
 // M <= FWN_TAIL_SPLIT_MAX: the skip sum as a ring GEMM that splits its weights over workgroups, then either (FWN_TAIL_SPLIT_CHAIN,
 // default) tail_kernel<.., HAS_P1 = false> = final conv + ZeroConv + coupling in one launch of 64-row workgroups, or the round-2
@@ -830,8 +835,8 @@ int fwn_tail_npartials_chain(int M, int Ch, int front) {       // log-det partia
 }
 int fwn_tail_npartials(int M) { return fwn_tail_npartials_chain(M, 0, 0); }
 
-// process-wide developer options (fwn_set_option in api.hip; round 4 read two environment variables on every gate launch)
-int g_fwn_opt_rs_persist = -1, g_fwn_opt_gate_co = 0;
+// process-wide developer option (fwn_set_option in api.hip; round 4 read two environment variables on every gate launch)
+int g_fwn_opt_rs_persist = -1;
 // compute units of the CURRENT device, cached per device (a process may drive several)
 int fwn_device_cus() {
     static int cache[64];
@@ -967,18 +972,6 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
         const int mt = gate_stream_mt(M);
         const int pe = g_fwn_opt_rs_persist;            // fwn_set_option("rs_persist", ..): -1 auto
         const bool persist = mt == 8 && (pe >= 0 ? pe == 1 : ((M + 255) / 256) * 2 >= 3 * ncu);
-        // 256-row tiles, experimental: the co-resident form (gate_co.h: 4-wave workgroups of 256 rows x 64 channels, two per
-        // CU) reads the same stream.  Stand-alone it is 1 - 5 % faster per launch than the 8-wave form (tools/bench_gate_co.hip),
-        // inside the overlapped passes the step is unchanged (5.82 against 5.80 ms, three interleaved rounds on one box):
-        // fwn_set_option("gate_co", 1) selects it, the product keeps the 8-wave form.
-        const bool co = g_fwn_opt_gate_co == 1;            // fwn_set_option("gate_co", 1): tests flip it inside one process
-        if (mt == 8 && co && !persist) {
-            const int grid4 = ((M + 255) / 256) * 4;
-#define X(n) if (nkc == n) hipLaunchKernelGGL((gate_co_kernel<n>), dim3(grid4), dim3(256), 0, st, a);
-            FWN_RS_CASES(X)
-#undef X
-            return;
-        }
         const int ntiles = ((M + 32 * mt - 1) / (32 * mt)) * 2, grid = persist && ntiles > ncu ? ncu : ntiles;
 #define X(n)                                                                                                                   \
         if (nkc == n) {                                                                                                        \
@@ -1193,6 +1186,7 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
         return;
     }
     if (fwn_tail_rows(M) == 256) TAIL_BY_NPT(8, 4, 32, false, true);
+    else if (M >= FWN_TAIL256_MIN) TAIL_BY_NPT(4, 2, 32, true, true);
     else TAIL_BY_NPT(4, 3, 64, true, true);
 #undef TAIL_BY_NPT
 #undef TAIL_LAUNCH

@@ -73,7 +73,7 @@ int fwn_flow_persist_front_inside(int Ch);
 void fwn_launch_flow_persist_desc(const fwn_flow_desc* d, float* xa, float* xb, void* hA, void* hB, void* o, const float* P,
                                   float* partial, unsigned* sync, int M, int Ti, int inverse, int has_front, hipStream_t st);
 // process-wide developer options (fwn_set_option): -1 = auto
-extern int g_fwn_opt_rs_persist, g_fwn_opt_gate_co;
+extern int g_fwn_opt_rs_persist;
 int fwn_device_cus();            // compute units of the current device (cached per device)
 
 int fwn_tail_rows(int M);        // rows per fused-tail workgroup

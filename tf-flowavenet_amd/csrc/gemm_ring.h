@@ -296,28 +296,35 @@ __device__ __forceinline__ void gemm_ring_body(const Prob& p, int tile_m, int ti
         // sum the KSP partial accumulators: groups 1.. park theirs in LDS (the ring is drained)
         constexpr int TILE_F = MI * 2 * 16 * 64;           // floats per wave
         static_assert((KSP - 1) * WM * WN * TILE_F * 4 <= D * SLOT, "reduction scratch must fit the ring");
-        float* red = (float*)lds;
+        // 16-byte LDS accesses, lane-contiguous: [wave][register quad][lane][4 floats] - the same adds in the same order as
+        // the 4-byte form of rounds 2 - 4, which took 1.5 us of a 6 us launch (round 5: clock stamps of the one-launch flow,
+        // profiles/r05_persist_stamps.txt; 96 ds_read_b32 + waits per summing wave against 24 ds_read_b128)
+        float4* red = (float4*)lds;
         FWN_RING_BARRIER();      // the partial sums are parked in the ring's slots: the last fragment reads must have returned
         if (wk > 0) {
-            float* dst = red + ((wk - 1) * WM * WN + wmn) * TILE_F + lane;
+            float4* dst = red + ((wk - 1) * WM * WN + wmn) * (TILE_F / 4) + lane;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[((mi * 2 + ni) * 16 + r) * 64] = acc[mi][ni][r];
+                    for (int q = 0; q < 4; ++q)
+                        dst[((mi * 2 + ni) * 4 + q) * 64] = make_float4(acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]);
         }
         __syncthreads();
         if (wk > 0) return;
 #pragma unroll
         for (int g = 1; g < KSP; ++g) {
-            const float* src = red + ((g - 1) * WM * WN + wmn) * TILE_F + lane;
+            const float4* src = red + ((g - 1) * WM * WN + wmn) * (TILE_F / 4) + lane;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += src[((mi * 2 + ni) * 16 + r) * 64];
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 t = src[((mi * 2 + ni) * 4 + q) * 64];
+                        acc[mi][ni][4 * q] += t.x; acc[mi][ni][4 * q + 1] += t.y; acc[mi][ni][4 * q + 2] += t.z; acc[mi][ni][4 * q + 3] += t.w;
+                    }
         }
     }
     if (FWN_ABL >= 4) {     // ablation: keep the accumulators live without the epilogue

@@ -446,6 +446,18 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         fwn_gemm_desc dca[FWN_MAX_LAYERS]; int ndca;      // conditioning-gradient GEMMs (accumulate into the mel image: order kept)
     };
     std::vector<Deferred> pending;        // the flows of the block whose weight gradients are still to be enqueued
+    // Error exits: once anything has been handed to the side stream, EVERY return path joins it into `st` first -
+    // otherwise weight-gradient kernels of up to n_block blocks (defer_block_done: all of them) would keep reading and
+    // writing the caller's workspace and gradient buffers after the call has returned an error.  Event-based, so it is also
+    // legal while the stream is being captured.
+    struct SideJoinGuard {
+        hipStream_t st, side; EventPool* evp; bool armed;
+        ~SideJoinGuard() {
+            if (!armed || !side || !evp) return;
+            hipEvent_t e = evp->get();
+            if (!e || hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) hipStreamSynchronize(side);
+        }
+    } side_guard{st, side, evp, false};
     int pending_block = -1;               // block whose weight gradients run on the side stream, not yet joined
     // a hook that returns non-zero stops the sequencing where it stands (the side stream is joined at that point)
     bool hook_failed = false;
@@ -544,6 +556,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     // side stream: everything enqueued on `st` so far happens before what `side` gets next
     auto fork_side = [&]() -> bool {
         hipEvent_t e = evp->get();
+        side_guard.armed = true;
         return e && hipEventRecord(e, st) == hipSuccess && hipStreamWaitEvent(side, e, 0) == hipSuccess;
     };
     auto join_side = [&]() -> bool {
@@ -743,6 +756,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
     if (on_block_done && on_block_done(user, -1) != 0) return hook_stop();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: %s", hipGetErrorString(e));
+    side_guard.armed = false;             // every block was joined on the way (join_pending)
     return FWN_OK;
 }
 

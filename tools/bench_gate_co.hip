@@ -2,9 +2,9 @@
 // register-streamed gate (csrc/gate_rs.h) on the same random operands and the same fragment stream: comparison of the
 // outputs (accumulation orders differ: one-ulp ties), then interleaved timing rounds.  Compiles in seconds (only the two
 // gate headers), unlike tools/bench_gate_rs.hip which carries every flow kernel.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize tools/bench_gate_co.hip -o tools/gate_co_bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -Itools tools/bench_gate_co.hip -o tools/gate_co_bin
 //   tools/gate_co_bin [B] [first block] [last block] [dil]        (-DFWN_RS_STAMP: per-item s_memtime stamps)
-#include "../tf-flowavenet_amd/csrc/gate_co.h"
+#include "gate_co.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

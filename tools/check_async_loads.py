@@ -90,49 +90,48 @@ class WalkLimit(RuntimeError):
 
 
 def check(name, body, max_steps=20000000):
-    """Walk the control-flow graph (not the listing: hipcc lays a loop's latch out in front of its header): both arms of
-    every conditional branch; a state = (program counter at a label, the QUEUE of operations in flight - the destination
-    registers of every entry in issue order from the oldest register still in flight on, entries without a destination
-    (LDS-DMA, stores) behind it included: a later
-    `s_waitcnt vmcnt(N)` retires by position, so two visits of a label with the same registers in flight but queues of
-    different depth are different states - round 4's key (registers only) pruned a loop's second iteration whose counted
-    waits reached less far than the first's); a state seen before is not walked again.  Running into max_steps raises."""
+    """Abstract walk of the control-flow graph (not the listing: hipcc lays a loop's latch out in front of its header): both
+    arms of every conditional branch.  State = for every VGPR with a load in flight, the number of vector-memory operations
+    issued after that load (they retire in issue order: `s_waitcnt vmcnt(N)` retires exactly the registers with at least N
+    younger operations; the hardware counter saturates at 63, counts are capped at 64).  At a label the states of all paths
+    are MERGED - union of the registers, the SMALLEST count of each (the case in which it stays in flight longest) - and a
+    path whose state adds nothing to what the label has already seen is not walked again: the walk is a monotone data-flow
+    iteration and terminates, and it is conservative (it can flag a path combination that cannot occur; it cannot miss a
+    touch).  Round 4's key (the set of registers alone) pruned a loop's second iteration whose counted waits reached less far
+    than the first's; enumerating whole queues instead does not terminate on kernels with dozens of loads in
+    flight.  Running into max_steps raises WalkLimit - never "clean"."""
     recs = decode(body)
-    reports, seen_rep, seen = [], set(), set()
-    work = [(0, ())]
+    reports, seen_rep = [], set()
+    at_label = {}                                 # pc -> merged state (reg -> (min younger count, line of the load))
+    work = [(0, {})]
     steps = 0
-    while work and steps < max_steps:
-        pc, q0 = work.pop()
-        queue = list(q0)                         # (line, dst regs) in issue order
-        inflight = {}
-        for idx, regs in queue:
-            for r in regs:
-                inflight[r] = idx
-        while pc < len(recs) and steps < max_steps:
+    while work:
+        pc, st0 = work.pop()
+        st = dict(st0)
+        while pc < len(recs):
+            if steps >= max_steps:
+                raise WalkLimit("%s: control-flow walk stopped after %d steps" % (name, steps))
             kind, pay = recs[pc]
             pc += 1
             steps += 1
             if kind == "skip":
                 continue
             if kind == "label":
-                # what matters about the queue: which registers are in flight and how many operations are younger than each
-                # (a later `s_waitcnt vmcnt(N)` retires by position); the counter saturates at 63, so counts are capped -
-                # a loop that issues stores beside a load it never waits for then reaches a fixed point
-                while len(queue) > 80 and not any(inflight.get(r) == queue[0][0] for r in queue[0][1]):
-                    del queue[0]                     # register-free entries that no vmcnt(N <= 63) distinguishes any more
-                n = len(queue)
-                key = (pc, tuple((frozenset(r for r in regs if inflight.get(r) == idx), min(n - 1 - i, 64))
-                                 for i, (idx, regs) in enumerate(queue) if any(inflight.get(r) == idx for r in regs)))
-                if key in seen:
-                    break
-                seen.add(key)
+                old = at_label.get(pc)
+                if old is None:
+                    at_label[pc] = dict(st)
+                else:
+                    changed = False
+                    for r, (y, ln) in st.items():
+                        if r not in old or old[r][0] > y:
+                            old[r] = (y, ln)
+                            changed = True
+                    if not changed:
+                        break
+                    st = dict(old)
             elif kind == "wait":
-                if pay < len(queue):
-                    for idx, regs in queue[:len(queue) - pay]:
-                        for r in regs:
-                            if inflight.get(r) == idx:
-                                del inflight[r]
-                    del queue[:len(queue) - pay]
+                if st:
+                    st = {r: v for r, v in st.items() if v[0] < pay}
             elif kind == "end":
                 break
             elif kind == "jump":
@@ -141,25 +140,25 @@ def check(name, body, max_steps=20000000):
                 pc = pay
             elif kind == "cond":
                 if pay >= 0:
-                    work.append((pay, tuple(queue)))
+                    work.append((pay, dict(st)))
             elif kind == "vm":
                 touched, dst, t = pay
-                hit = sorted(r for r in touched if r in inflight)
+                # (a load INTO a register whose earlier load is still in flight is harmless: they return in issue order)
+                hit = sorted(r for r in touched if r in st and r not in dst)
                 if hit and pc not in seen_rep:
                     seen_rep.add(pc)
-                    reports.append((pc, t, hit, (inflight[hit[0]], body[inflight[hit[0]] - 1].strip())))
-                queue.append((pc, dst))
+                    reports.append((pc, t, hit, (st[hit[0]][1], body[st[hit[0]][1] - 1].strip())))
+                if st:
+                    st = {r: (min(y + 1, 64), ln) for r, (y, ln) in st.items()}
                 for r in dst:
-                    inflight[r] = pc
+                    st[r] = (0, pc)
             else:
                 touched, t = pay
-                hit = [r for r in touched if r in inflight]
+                hit = [r for r in touched if r in st]
                 if hit and pc not in seen_rep:
                     seen_rep.add(pc)
                     hit.sort()
-                    reports.append((pc, t, hit, (inflight[hit[0]], body[inflight[hit[0]] - 1].strip())))
-    if steps >= max_steps:
-        raise WalkLimit("%s: control-flow walk stopped after %d steps" % (name, steps))
+                    reports.append((pc, t, hit, (st[hit[0]][1], body[st[hit[0]][1] - 1].strip())))
     reports.sort()
     return reports
 

@@ -1,5 +1,5 @@
 # GPU box: bench.py's step / pass / gate-launch times under different environment settings, interleaved.
-#   bash tools/diag/ab_bench_env.sh [rounds] "FWN_OPT_GATE_CO=0" "FWN_OPT_GATE_CO=1"
+#   bash tools/diag/ab_bench_env.sh [rounds] "FWN_OPT_RS_PERSIST=0" "FWN_OPT_RS_PERSIST=1"
 cd "$(dirname "$0")/../.."
 rounds=$1; shift
 for i in $(seq 1 $rounds); do

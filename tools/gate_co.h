@@ -18,7 +18,7 @@
 //   * The price: every activation row is staged by four workgroups instead of two (L2 -> LDS bytes per tile pair 776 KB
 //     against 600 KB) and the items are half as long.
 #pragma once
-#include "gate_rs.h"
+#include "../tf-flowavenet_amd/csrc/gate_rs.h"
 
 template <int NKC>
 struct CoPlan {
