@@ -850,6 +850,49 @@ def test_overlapped_streams_soak(full_model, nb, lanes, steps):
     assert (bad_f, bad_i) == (0, 0), "%d forward / %d inverse passes of %d differ from the one-stream result" % (bad_f, bad_i, steps // 12 * 12)
 
 
+@pytest.mark.parametrize("nb,lanes,steps", [(8, 3, 96), (1, 6, 144), (3, 4, 96)])
+def test_one_launch_flows_under_overlapped_lanes_and_a_bandwidth_hog(full_model, monkeypatch, nb, lanes, steps):
+    """The one-launch flows (persist_mode = 2) in bench.py's arrangement: several lanes per direction - up to twelve spinning
+    grids of up to 256 workgroups each in flight beside chip-filling kernels of other lanes and a copy stream that keeps the
+    memory system busy.  Two claims of csrc/flow_persist.h are on trial: (1) no deadlock whatever the residency (tickets are
+    taken by running workgroups and only ever wait for smaller tickets) - the test finishes; (2) the hand-off protocol
+    (write-through stores, drained, one agent-scope add; sc1 register loads behind the poll, no fence) under UNEVEN load with
+    every buffer re-used flow after flow (L1 / L2 lines of the previous flow's data at the same addresses) - every pass equals
+    the one-stream result bit for bit."""
+    hp, model0, x, c, z = full_model
+    model, _ = _persist_twins(hp, model0, monkeypatch)
+    nt = 16128
+    xs, cs, zs = x[:nb, :nt].contiguous(), c[:nb, :nt // hp.hop_size].contiguous(), z[:nb, :nt].contiguous()
+    ref_nll = torch.stack(model.forward(xs, cs)).clone()
+    ref_wav = model.reverse(zs, cs).clone()
+    torch.cuda.synchronize()
+    lf = [torch.cuda.Stream() for _ in range(lanes)]
+    li = [torch.cuda.Stream() for _ in range(lanes)]
+    hog = torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    bad_f = bad_i = 0
+    cur = torch.cuda.current_stream()
+    for rnd in range(steps // 12):
+        outs = []
+        for s_ in lf + li + [hog]:
+            s_.wait_stream(cur)
+        for k in range(12):
+            if rnd % 2 and k % 3 == 0:
+                with torch.cuda.stream(hog):
+                    big[: 1 << 27].copy_(big[1 << 27:], non_blocking=True)
+            with torch.cuda.stream(lf[k % lanes]):
+                nll = torch.stack(model.forward(xs, cs))
+            with torch.cuda.stream(li[k % lanes]):
+                wav = model.reverse(zs, cs).clone()
+            outs.append((nll, wav))
+        for s_ in lf + li + [hog]:
+            cur.wait_stream(s_)
+        torch.cuda.synchronize()
+        bad_f += sum(int(not torch.equal(nll, ref_nll)) for nll, _ in outs)
+        bad_i += sum(int(not torch.equal(wav, ref_wav)) for _, wav in outs)
+    assert (bad_f, bad_i) == (0, 0), "%d forward / %d inverse passes of %d differ from the one-stream result" % (bad_f, bad_i, steps // 12 * 12)
+
+
 def test_ten_second_clip_batch_of_clips_is_clipwise_identical(full_model):
     """BASELINE configs[3] shards 10 s clips over GPUs; one GPU may also take several: every clip of a B=2 call equals
     the same clip synthesised alone at the B=1 tile shapes up to bf16 rounding flips (values are checked against the

@@ -455,7 +455,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         ~SideJoinGuard() {
             if (!armed || !side || !evp) return;
             hipEvent_t e = evp->get();
-            if (!e || hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) hipStreamSynchronize(side);
+            if (!e || hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) (void)hipStreamSynchronize(side);
         }
     } side_guard{st, side, evp, false};
     int pending_block = -1;               // block whose weight gradients run on the side stream, not yet joined
