@@ -735,6 +735,36 @@ def test_one_launch_flows_equal_the_launch_per_stage_path_bit_for_bit(full_model
         assert torch.equal(w0, w1), float((w0 - w1).abs().max())
 
 
+@pytest.mark.parametrize("variant", ["one_layer", "8khz", "three_layers"])
+def test_one_launch_flows_on_other_model_shapes(monkeypatch, variant):
+    """The one-launch form beyond the default hyper-parameters: n_layer = 1 (no residual stage: front, gate, skip, final,
+    ZeroConv - the S / U buffers swap roles), the 8 kHz model (hparams8000: n_block = 5, hop 96: 84-row clips at the last block)
+    and n_layer = 3, where the form does not exist and persist_mode = 2 must quietly keep the launch-per-stage path.  Random
+    ActNorm tables (no data-dependent init), both directions, every sample equal."""
+    from tf_flowavenet_amd.hparams import hparams8000
+    if variant == "one_layer":
+        hp, b, t = default_hparams().replace(n_block=6, n_flow=2, n_layer=1), 3, 4096
+    elif variant == "8khz":
+        hp, b, t = hparams8000().replace(n_flow=2), 2, 96 * 32 * 2
+    else:
+        hp, b, t = default_hparams().replace(n_block=5, n_flow=2, n_layer=3), 2, 4096
+    params = W.synthetic_params(hp, 99, actnorm="random")
+    plain = FloWaveNet(hp).load_params(params)
+    monkeypatch.setenv("FWN_PERSIST_MODE", "2")
+    one = FloWaveNet(hp).load_params(params)
+    monkeypatch.delenv("FWN_PERSIST_MODE")
+    inp = W.synthetic_inputs(hp, b, t)
+    x, c, z = dev(inp["x"]), dev(inp["c"]), dev(inp["z"])
+    for _ in range(2):
+        lp0, ld0, z0 = one.forward(x, c, return_z=True)
+        lp1, ld1, z1 = plain.forward(x, c, return_z=True)
+        assert torch.equal(z0, z1) and float(lp0) == float(lp1) and float(ld0) == float(ld1)
+        assert torch.equal(one.reverse(z, c), plain.reverse(z, c))
+    lib = _lib.load()
+    d = one._packed.flow_descs[(hp.n_block - 1) * hp.n_flow]
+    assert lib.fwn_flow_persist_supported(C.byref(d), b, t) == (0 if variant == "three_layers" else 1)
+
+
 @pytest.mark.parametrize("blk,b,inverse", [(7, 8, 0), (7, 1, 1), (5, 3, 0), (4, 8, 1), (3, 1, 0), (2, 1, 1)])
 def test_one_launch_flow_entry_point_and_its_status_word(full_model, blk, b, inverse):
     """fwn_flow_run_persist against fwn_flow_run on the same operands (one flow, hoisted conditioning from fwn_cond): both
