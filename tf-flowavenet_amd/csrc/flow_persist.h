@@ -159,14 +159,19 @@ enum { PS_FRONT = 0, PS_GATE = 1, PS_RES = 2, PS_SKIP = 3, PS_FINAL = 4, PS_ZERO
 // ascending order through LDS.  Here ONE wave takes every k-step of its output quadrant and keeps the NACC = KSP partial sums
 // in accumulators of its own (k-step mod NACC): the same products into the same sums, the groups added in the same order -
 // without the two barriers and the LDS round trip (1.5 us of a 6 us ticket), and the chains are independent, so the MFMAs
-// issue back to back.  Four k-steps at a time, the NEXT four's fragment reads in flight under the current MFMAs
-// (the prefetch is unconditional - the last one re-reads its own chunk - so the loop body is straight-line code and hipcc
-// counts its lgkmcnt waits; a conditional prefetch made it wait lgkmcnt(0) in front of every MFMA).
+// issue back to back.
+// The k-step count NSEG * KPS is a template parameter and the loop is unrolled in full: every fragment address is then a
+// per-lane base (one of 8 per segment for A, one of 4 for B: the XOR half of the swizzle,
+// (2 kc + lh) ^ (row & 15) = 2 (kc ^ (row >> 1 & 7)) + (lh ^ (row & 1))) plus an IMMEDIATE offset, so the loop body is one or
+// two ds_reads and one MFMA per k-step with no address arithmetic (computed per k-step, the arithmetic of ONE wave per SIMD
+// set the pace: 105 cycles per 32-cycle MFMA), and the reads run PS_D k-steps ahead of the MFMAs in a ring of fragment
+// registers; hipcc counts the lgkmcnt waits of straight-line code exactly.
 // TWO: both column halves of the row half (two waves: the ZeroConv, whose epilogue pairs columns n and n + 32 in a lane).
-template <int NACC, bool TWO>
+#define PS_D 3
+template <int NACC, bool TWO, int NSEG, int KPS>
 __device__ __forceinline__ void ps_kloop(f32x16 (&tot)[2], float c0, float c1, const unsigned char* bq, const unsigned char* img,
-                                         int so0, int so1, int so2, int nseg, int kps, int lr, int lh) {
-    constexpr int NH = TWO ? 2 : 1;
+                                         int so0, int so1, int so2, int lr, int lh) {
+    constexpr int NH = TWO ? 2 : 1, NK = NSEG * KPS;
     f32x16 acc[NACC][NH];
 #pragma unroll
     for (int g = 0; g < NACC; ++g)
@@ -175,63 +180,31 @@ __device__ __forceinline__ void ps_kloop(f32x16 (&tot)[2], float c0, float c1, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][h][r] = g == 0 ? (h == 0 ? c0 : c1) : 0.0f;
     const int bsw = (lr >> 1) & 7;
-    const int cl = kps == 16 ? 2 : kps == 8 ? 1 : 0;           // log2 of the chunks (of four k-steps) per segment
-    const int nch = nseg << cl;
-    // per-lane bases such that a fragment address is base XOR (a wave-uniform constant of the k-step): the 16-byte piece
-    // index (2 kc + lh) ^ (row & 15) = 2 (kc ^ (row >> 1 & 7)) + (lh ^ (row & 1)), so the swizzle costs ONE v_xor per fragment
-    // (computed per k-step from scratch, the address arithmetic - a dozen VALU instructions of one wave - set the pace of
-    // the loop: 110 cycles per 32-cycle MFMA)
-    auto abase = [&](int row) -> unsigned { return (unsigned)(row * 512 + ((lh ^ (row & 1)) << 4) + (((row >> 1) & 7) << 5)); };
-    const unsigned ab0 = abase(so0), ab1 = abase(so1), ab2 = abase(so2);
+    const unsigned ab0 = (unsigned)(so0 * 512 + ((lh ^ (so0 & 1)) << 4) + (((so0 >> 1) & 7) << 5));
+    const unsigned ab1 = (unsigned)(so1 * 512 + ((lh ^ (so1 & 1)) << 4) + (((so1 >> 1) & 7) << 5));
+    const unsigned ab2 = (unsigned)(so2 * 512 + ((lh ^ (so2 & 1)) << 4) + (((so2 >> 1) & 7) << 5));
     const unsigned bb = (unsigned)(((lh ^ (bsw & 1)) << 4) + ((bsw >> 1) << 5));
-    // two fragment buffers (A, B0[, B1] of four k-steps each), alternating without copies
-    bf16x8 fa[4], fb[4], fc[4], ga[4], gb[4], gc[4];
-#define PS_LD(IDX, A_, B_, C_)                                                                                         \
+    bf16x8 fa[PS_D], fb[PS_D], fc[PS_D];
+#define PS_RD(KS, SLOT)                                                                                                \
     do {                                                                                                               \
-        const int idx_ = (IDX);                                                                                        \
-        const int sg_ = idx_ >> cl, j0_ = (idx_ & ((1 << cl) - 1)) * 4;                                                \
+        const int ks_ = (KS), sg_ = ks_ / KPS, kc_ = ks_ % KPS;                                                        \
         const unsigned ab_ = sg_ == 0 ? ab0 : sg_ == 1 ? ab1 : ab2;                                                    \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                \
-            const int kc_ = j0_ + u, ks_ = sg_ * kps + kc_;                                                            \
-            A_[u] = *(const bf16x8*)(img + (ab_ ^ (unsigned)(((kc_ & 7) << 5) | ((kc_ >> 3) << 8))));                  \
-            const unsigned char* bs_ = bq + ((bb ^ (unsigned)((ks_ & 3) << 5)) + (unsigned)((ks_ >> 2) * 8192));       \
-            B_[u] = *(const bf16x8*)bs_;                                                                               \
-            if constexpr (TWO) C_[u] = *(const bf16x8*)(bs_ + 32 * 128);                                               \
-        }                                                                                                              \
+        fa[SLOT] = *(const bf16x8*)(img + (ab_ ^ (unsigned)((kc_ & 7) << 5)) + ((kc_ >> 3) << 8));                     \
+        const unsigned char* bs_ = bq + (bb ^ (unsigned)((ks_ & 3) << 5)) + (ks_ >> 2) * 8192;                         \
+        fb[SLOT] = *(const bf16x8*)bs_;                                                                                \
+        if constexpr (TWO) fc[SLOT] = *(const bf16x8*)(bs_ + 32 * 128);                                                \
     } while (0)
-#define PS_MM(A_, B_, C_)                                                                                              \
-    do {                                                                                                               \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                                \
-            acc[u % NACC][0] = mfma32(A_[u], B_[u], acc[u % NACC][0]);                                                 \
-            if constexpr (TWO) acc[u % NACC][NH - 1] = mfma32(A_[u], C_[u], acc[u % NACC][NH - 1]);                    \
-        }                                                                                                              \
-    } while (0)
-    // (sched_barrier: left alone, hipcc interleaves every read with the MFMA that needs it and waits for it at once)
-    if constexpr (TWO || NACC == 4) {
-        // one buffer: the ZeroConv (two column halves) and the four-chain form (four accumulators) have no registers for a
-        // second one - a spilled register means scratch memory, and a kernel that needs scratch starts several microseconds
-        // later than one that does not; four independent MFMA chains cover most of the read latency by themselves
-        for (int idx = 0; idx < nch; ++idx) {
-            PS_LD(idx, fa, fb, fc);
-            __builtin_amdgcn_sched_barrier(0);
-            PS_MM(fa, fb, fc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        PS_LD(0, fa, fb, fc);
-        for (int idx = 0; idx < nch; idx += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-            PS_LD(idx + 1 < nch ? idx + 1 : nch - 1, ga, gb, gc);
-            __builtin_amdgcn_sched_barrier(0);
-            PS_MM(fa, fb, fc);
-            __builtin_amdgcn_sched_barrier(0);
-            PS_LD(idx + 2 < nch ? idx + 2 : nch - 1, fa, fb, fc);
-            __builtin_amdgcn_sched_barrier(0);
-            if (idx + 1 < nch) PS_MM(ga, gb, gc);
-        }
+#pragma unroll
+    for (int ks = 0; ks < (PS_D < NK ? PS_D : NK); ++ks) PS_RD(ks, ks);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        acc[ks % NACC][0] = mfma32(fa[ks % PS_D], fb[ks % PS_D], acc[ks % NACC][0]);
+        if constexpr (TWO) acc[ks % NACC][NH - 1] = mfma32(fa[ks % PS_D], fc[ks % PS_D], acc[ks % NACC][NH - 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + PS_D < NK) PS_RD(ks + PS_D, ks % PS_D);
     }
-#undef PS_LD
-#undef PS_MM
+#undef PS_RD
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         tot[h] = acc[0][h];
@@ -462,9 +435,16 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
             const float c1 = (bias_p && two) ? bias_p[n0 + 32 + lr] : 0.0f;
             const unsigned char* const bq = bw + (nh * 32 + lr) * 128;
             if (active) {
-                if (two) ps_kloop<2, true>(acc[0], c0, c1, bq, lds, so0, so1, so2, nseg, kps, lr, lh);
-                else if (ksp == 4) ps_kloop<4, false>(acc[0], c0, c1, bq, lds, so0, so1, so2, nseg, kps, lr, lh);
-                else ps_kloop<1, false>(acc[0], c0, c1, bq, lds, so0, so1, so2, nseg, kps, lr, lh);
+                if (ty == PS_ZERO) ps_kloop<2, true, 1, 16>(acc[0], c0, c1, bq, lds, so0, so1, so2, lr, lh);
+                else if (ty == PS_GATE) {
+                    if (ksp == 4) ps_kloop<4, false, 3, 16>(acc[0], c0, c1, bq, lds, so0, so1, so2, lr, lh);
+                    else ps_kloop<1, false, 3, 16>(acc[0], c0, c1, bq, lds, so0, so1, so2, lr, lh);
+                } else if (ty == PS_FRONT) {
+                    if (kps == 16) ps_kloop<1, false, 3, 16>(acc[0], c0, c1, bq, lds, so0, so1, so2, lr, lh);
+                    else if (kps == 8) ps_kloop<1, false, 3, 8>(acc[0], c0, c1, bq, lds, so0, so1, so2, lr, lh);
+                    else ps_kloop<1, false, 3, 4>(acc[0], c0, c1, bq, lds, so0, so1, so2, lr, lh);
+                } else if (nseg == 2) ps_kloop<4, false, 2, 16>(acc[0], c0, c1, bq, lds, so0, so1, so2, lr, lh);
+                else ps_kloop<4, false, 1, 16>(acc[0], c0, c1, bq, lds, so0, so1, so2, lr, lh);
             }
         }
         PS_STAMP(4);
