@@ -294,18 +294,19 @@ def _median_pass_s(fn, iters):
 
 def one_launch_twin(model, hp, params, dev):
     """The same parameters (the data-dependent init's tables exported from `model`) packed twice more: with
-    fwn_model_desc.persist_mode = 2 (csrc/flow_persist.h: ONE launch per small-M flow) and with the default (a launch per
-    stage) - the pair whose results must be equal bit for bit (the device init and the host packing of `model` itself differ
+    fwn_model_desc.persist_mode = 2 (csrc/flow_persist.h: ONE launch per flow wherever the form exists) and 1 (a launch per
+    stage everywhere; the default, 0, takes the one-launch form up to 256 rows) - the pair whose results must be equal bit for bit (the device init and the host packing of `model` itself differ
     in last bits of exp(3 logs))."""
     import numpy as np
     from tf_flowavenet_amd.model import FloWaveNet
     p2 = dict(params)
     for k, v in model.export_actnorm().items():
         p2[k] = np.asarray(v, dtype=np.float32).reshape(np.asarray(p2[k]).shape)
-    plain = FloWaveNet(hp, device=dev).load_params(p2)
     old = os.environ.get("FWN_PERSIST_MODE")
-    os.environ["FWN_PERSIST_MODE"] = "2"
     try:
+        os.environ["FWN_PERSIST_MODE"] = "1"
+        plain = FloWaveNet(hp, device=dev).load_params(p2)
+        os.environ["FWN_PERSIST_MODE"] = "2"
         one = FloWaveNet(hp, device=dev).load_params(p2)
     finally:
         if old is None:
@@ -331,16 +332,19 @@ def latency_b1(model, hp, t, dev, iters=10, params=None):
     flop = flop_per_sample(hp) * t
     bound = BOUND_US.get("B1_T%d" % t)
     one_launch = None
-    if params is not None:       # round 5: the same clip with one launch per small-M flow (opt-in form), next to the default
+    if params is not None:       # round 5: the same clip with one launch per flow wherever the form exists, and with none
         try:
             one, plain = one_launch_twin(model, hp, params, dev)
             f1, i1 = timed(lambda: one.forward(x, c)), timed(lambda: one.reverse(z, c))
+            f0, i0 = timed(lambda: plain.forward(x, c)), timed(lambda: plain.reverse(z, c))
             a, b_ = one.forward(x, c, return_z=True), plain.forward(x, c, return_z=True)
             same = bool(torch.equal(a[2], b_[2])) and float(a[0]) == float(b_[0]) and float(a[1]) == float(b_[1]) and \
                 bool(torch.equal(one.reverse(z, c), plain.reverse(z, c)))
-            one_launch = {"fwd_ms": f1 * 1e3, "inv_ms": i1 * 1e3, "bit_identical_to_launch_per_stage": same,
+            one_launch = {"fwd_ms": f1 * 1e3, "inv_ms": i1 * 1e3, "launch_per_stage_fwd_ms": f0 * 1e3, "launch_per_stage_inv_ms": i0 * 1e3,
+                          "bit_identical_to_launch_per_stage": same,
                           "what": "fwn_model_desc.persist_mode = 2: blocks 2 - 7 of this clip as one launch per flow "
-                                  "(csrc/flow_persist.h; DESIGN.md section 3.7); the default path is the line's fwd_ms / inv_ms"}
+                                  "(csrc/flow_persist.h; DESIGN.md section 3.7), and = 1: a launch per stage everywhere; the "
+                                  "line's fwd_ms / inv_ms are the default (0): one launch per flow up to 256 rows (blocks 5 - 7)"}
             del one, plain
         except Exception as e:   # a diagnostic: never instead of the line
             one_launch = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -423,9 +423,10 @@ typedef struct fwn_model_desc {
     int32_t gate_fp8;                         /* != 0: fp8 dilated taps where supported (needs flows[].Wd8) */
     int32_t chain_mode;                       /* 0: chain the flows of a block (out_b to a third plane buffer, the next flow's
                                                * front conv in the previous flow's tail: csrc/tail_chain.h); 1: every flow on its own */
-    int32_t persist_mode;                     /* 2: flows of small-M blocks (hoisted conditioning, <= 4096 rows) run as ONE launch each
-                                               * (csrc/flow_persist.h; same results bit for bit); 0 / 1: a launch per stage (the default:
-                                               * the one-launch form measures at parity or behind it) */
+    int32_t persist_mode;                     /* flows of small-M blocks (hoisted conditioning) as ONE launch each (csrc/flow_persist.h;
+                                               * same results bit for bit as a launch per stage): 0 = where that measured faster
+                                               * (<= 256 rows: DESIGN.md section 3.7), 1 = never, 2 = wherever the form exists
+                                               * (<= 4096 rows, n_layer <= 2) */
     /* Diagnostic (bench.py's per-block table), normally NULL: HOST array of n_block + 1 hipEvent_t handles.  The whole-model
      * calls record [k] on `stream` in front of the first launch of the k-th block they run (forward: block k, reverse: block
      * n_block - 1 - k) and [n_block] behind the last launch of the last one. */

@@ -110,27 +110,23 @@ __device__ __forceinline__ void ps_issue_weights(unsigned char* bw, const bf16* 
     }
 }
 
-// (rows outside [0, M) as zeros): issue half
+// Rows g0 + (tid >> 5) + 16 j (j < NP), 16-byte piece tid & 31, of a row-major [M][256] bf16 matrix that other workgroups of
+// this launch wrote: 16-byte sc1 buffer loads to registers - rows outside [0, M) read as zeros by the buffer's bounds (a negative
+// row is a huge unsigned offset) - and from there into the swizzled LDS image (lds_off256: the XOR term is the same for
+// every j, so both sides are one per-lane base plus j * 8 KiB).  Behind the wait for the producers this is the critical
+// path of the level: one add per load, no selects.
 template <int NP, int OFF, int NV>
-__device__ __forceinline__ void ps_rows_issue(u32x4 (&v)[NV], const bf16* src, int g0, int nrows, int M, int tid) {
+__device__ __forceinline__ void ps_rows_issue(u32x4 (&v)[NV], const srd_t& src, int g0, int tid) {
+    const uint32_t voff = (uint32_t)((g0 + (tid >> 5)) * 512 + (tid & 31) * 16);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int p = tid + j * 512, row = p >> 5, c = p & 31, g = g0 + row;
-        const bool ok = row < nrows && (unsigned)g < (unsigned)M;
-        ps_ld16(v[OFF + j], src + (size_t)(ok ? g : 0) * FWN_HID + c * 8);
-    }
+    for (int j = 0; j < NP; ++j) v[OFF + j] = __builtin_amdgcn_raw_buffer_load_b128(src, voff + (uint32_t)(j * 8192), 0, 16);   // aux 16 = sc1
 }
 template <int NP, int OFF, int NV>
-__device__ __forceinline__ void ps_rows_write(const u32x4 (&v)[NV], unsigned char* img, int g0, int nrows, int M, int tid) {
+__device__ __forceinline__ void ps_rows_write(const u32x4 (&v)[NV], unsigned char* img, int nrows, int tid) {
+    unsigned char* const p = img + lds_off256(tid >> 5, tid & 31);
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int p = tid + j * 512, row = p >> 5, c = p & 31, g = g0 + row;
-        if (row < nrows) {
-            const bool ok = (unsigned)g < (unsigned)M;
-            u32x4 z = {0u, 0u, 0u, 0u};
-            *(u32x4*)(img + lds_off256(row, c)) = ok ? v[OFF + j] : z;
-        }
-    }
+    for (int j = 0; j < NP; ++j)
+        if (j * 16 + 16 <= nrows || (tid >> 5) + j * 16 < nrows) *(u32x4*)(p + j * 8192) = v[OFF + j];
 }
 
 // 8 consecutive columns c8 * 8 .. + 7 of row `row` (0 .. 63) of the parked 64 x 64 fp32 tile (two wave tiles in
@@ -167,7 +163,15 @@ enum { PS_FRONT = 0, PS_GATE = 1, PS_RES = 2, PS_SKIP = 3, PS_FINAL = 4, PS_ZERO
 // set the pace: 105 cycles per 32-cycle MFMA), and the reads run PS_D k-steps ahead of the MFMAs in a ring of fragment
 // registers; hipcc counts the lgkmcnt waits of straight-line code exactly.
 // TWO: both column halves of the row half (two waves: the ZeroConv, whose epilogue pairs columns n and n + 32 in a lane).
+#ifndef PS_D
 #define PS_D 3
+#endif
+#ifndef FWN_PS_OPAQUE
+#define FWN_PS_OPAQUE 0
+#endif
+#ifndef FWN_PS_EARLY
+#define FWN_PS_EARLY 0
+#endif
 template <int NACC, bool TWO, int NSEG, int KPS>
 __device__ __forceinline__ void ps_kloop(f32x16 (&tot)[2], float c0, float c1, const unsigned char* bq, const unsigned char* img,
                                          int so0, int so1, int so2, int lr, int lh) {
@@ -222,9 +226,8 @@ __device__ __forceinline__ void ps_kloop(f32x16 (&tot)[2], float c0, float c1, c
 __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[FWN_PS_LDS];
     unsigned* const misc = (unsigned*)(lds + FWN_PS_LDS - 256);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 31, lh = lane >> 5;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int wm = wave & 1;
     const int M = a.M, Ti = a.Ti, L = a.L;
     const int RT = (M + 63) >> 6;
@@ -254,14 +257,21 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
     // ---- the first ticket (the next one is taken while this one is worked on) ----
     if (wave == 0) {
         unsigned t = 0;
-        if (lane == 0) t = ps_add(a.sync, 1u);
+        if (tid0 == 0) t = ps_add(a.sync, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
-        if (lane == 0) misc[0] = t;
+        if (tid0 == 0) misc[0] = t;
     }
     PS_BARRIER();
     unsigned t_cur = misc[0];
     int it = 0;
     while ((int)t_cur < total) {
+        // (opaque per ticket: hipcc otherwise hoists every lane-constant address term of every stage out of this loop and
+        // keeps them all in registers across the K loops - scratch memory; recomputing them is a few VALU instructions)
+        int tid = tid0;
+#if FWN_PS_OPAQUE
+        asm volatile("" : "+v"(tid));
+#endif
+        const int lane = tid & 63, lr = lane & 31, lh = lane >> 5;
         // decode (wave-uniform)
         int s = 0, rem = (int)t_cur;
         for (;; ++s) {
@@ -313,6 +323,32 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
 
         // ---- 2. everything that does not depend on other workgroups: the weights (LDS-DMA), the epilogue's operands ----
         ps_issue_weights(bw, Wt, wrows, ldb, n0, nsub, wave, lane);
+        // the epilogue's operands that no other workgroup of this launch writes, requested BEFORE the wait for the producers
+        // (their round trip hides behind it): gate: the hoisted conditioning projection of this lane's item (row tid >> 2,
+        // 8 channels; an earlier launch wrote it: plain loads); res: the bias of its 8 columns
+        float4 pf0, pf1, pg0, pg1;
+        pf0 = pf1 = pg0 = pg1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // ZeroConv: the plane elements its coupling transforms (TailZeroProb's own prefetch; only this ticket touches them)
+        TailZeroProb zp{hlast, a.Wzero, a.bzero, a.ezero, a.an, a.xa, a.xb, a.partial, M, a.Ch, a.npt, a.inverse, nullptr};
+        float zpre[1][32];
+#define PS_LOAD_P() do { \
+        if (ty == PS_GATE && tid < 256) { \
+            const int row = m0 + (tid >> 2); \
+            const float* pr = a.P + (size_t)ly * M * 512 + (size_t)(row < M ? row : M - 1) * 512 + n0 + (tid & 3) * 8; \
+            pf0 = *(const float4*)pr; pf1 = *(const float4*)(pr + 4); \
+            pg0 = *(const float4*)(pr + 32); pg1 = *(const float4*)(pr + 36); \
+        } else if (ty == PS_RES) { \
+            const float* br = a.bres[ly] + n0 + (tid & 7) * 8; \
+            pf0 = *(const float4*)br; pf1 = *(const float4*)(br + 4); \
+        } \
+        } while (0)
+#define PS_LOAD_Z() do { if (ty == PS_ZERO && wave < 2) zp.template prefetch<1>(zpre, m0 + wm * 32, n0, lane); } while (0)
+#if FWN_PS_EARLY & 1
+        PS_LOAD_P();
+#endif
+#if FWN_PS_EARLY & 2
+        PS_LOAD_Z();
+#endif
 #ifndef FWN_PS_STAMP_CLK
         PS_STAMP(1);
 #endif
@@ -340,6 +376,7 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
 
         // ---- 4. the activation rows -> LDS image(s) ----
         u32x4 hin = {0u, 0u, 0u, 0u};
+        const uint32_t hbytes = (uint32_t)((size_t)M * FWN_HID * 2);
         int zrow = 0;                                          // image row that reads as zeros (gate / front: taps outside the clip)
         if (ty == PS_FRONT) {
             // rows m0 - 1 .. m0 + 64 of the a-plane (an earlier launch wrote it: plain loads) as (hi | lo) bf16, ActNorm applied;
@@ -389,30 +426,24 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
             const int R = 64 + 2 * dil;
             zrow = R;
             u32x4 v[5];
-            ps_rows_issue<5, 0>(v, hc, m0 - dil, R, M, tid);
-            PS_WAIT5(v);
-            ps_rows_write<5, 0>(v, lds, m0 - dil, R, M, tid);
+            ps_rows_issue<5, 0>(v, make_srd(hc, hbytes), m0 - dil, tid);
+            ps_rows_write<5, 0>(v, lds, R, tid);
             if (tid < 32) { u32x4 z = {0u, 0u, 0u, 0u}; *(u32x4*)(lds + lds_off256(R, tid)) = z; }
         } else if (ty == PS_SKIP && L == 2) {
             u32x4 v[8];
-            ps_rows_issue<4, 0>(v, a.o, m0, 64, M, tid);
-            ps_rows_issue<4, 4>(v, a.o + (size_t)M * FWN_HID, m0, 64, M, tid);
-            PS_WAIT8(v);
-            ps_rows_write<4, 0>(v, lds, m0, 64, M, tid);
-            ps_rows_write<4, 4>(v, lds + 64 * 512, m0, 64, M, tid);
+            ps_rows_issue<4, 0>(v, make_srd(a.o, hbytes), m0, tid);
+            ps_rows_issue<4, 4>(v, make_srd(a.o + (size_t)M * FWN_HID, hbytes), m0, tid);
+            ps_rows_write<4, 0>(v, lds, 64, tid);
+            ps_rows_write<4, 4>(v, lds + 64 * 512, 64, tid);
         } else {
             // skip (L = 1) / res / final / zero: one image of the tile's rows; res: + the residual rows of this lane's
             // epilogue item (row tid >> 3, 8 columns) - handed-off bytes as well
             const bf16* src = ty == PS_RES ? a.o + (size_t)ly * M * FWN_HID : ty == PS_SKIP ? a.o : ty == PS_FINAL ? hfree : hlast;
-            u32x4 v[5];
-            ps_rows_issue<4, 0>(v, src, m0, 64, M, tid);
-            {
-                const int row = m0 + (tid >> 3);
-                ps_ld16(v[4], (ty == PS_RES ? (const bf16*)hc : src) + (size_t)(row < M ? row : 0) * FWN_HID + n0 + (tid & 7) * 8);
-            }
-            PS_WAIT5(v);
-            hin = v[4];
-            ps_rows_write<4, 0>(v, lds, m0, 64, M, tid);
+            u32x4 v[4];
+            ps_rows_issue<4, 0>(v, make_srd(src, hbytes), m0, tid);
+            hin = __builtin_amdgcn_raw_buffer_load_b128(make_srd(ty == PS_RES ? (const bf16*)hc : src, hbytes),
+                                                        (uint32_t)((m0 + (tid >> 3)) * 512 + n0 * 2 + (tid & 7) * 16), 0, 16);
+            ps_rows_write<4, 0>(v, lds, 64, tid);
         }
         PS_BARRIER();
         PS_STAMP(3);
@@ -448,24 +479,12 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
             }
         }
         PS_STAMP(4);
-        // the epilogue's operands, requested here so that they are not live across the K loop (its fragment buffers and the
-        // four accumulators fill the register file): gate: the hoisted conditioning projection of this lane's item (row
-        // tid >> 2, 8 channels; an earlier launch wrote it: plain loads); res: the bias of its 8 columns
-        float4 pf0, pf1, pg0, pg1;
-        pf0 = pf1 = pg0 = pg1 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ty == PS_GATE && tid < 256) {
-            const int row = m0 + (tid >> 2);
-            const float* pr = a.P + (size_t)ly * M * 512 + (size_t)(row < M ? row : M - 1) * 512 + n0 + (tid & 3) * 8;
-            pf0 = *(const float4*)pr; pf1 = *(const float4*)(pr + 4);
-            pg0 = *(const float4*)(pr + 32); pg1 = *(const float4*)(pr + 36);
-        } else if (ty == PS_RES) {
-            const float* br = a.bres[ly] + n0 + (tid & 7) * 8;
-            pf0 = *(const float4*)br; pf1 = *(const float4*)(br + 4);
-        }
-        // ZeroConv: the plane elements its coupling transforms (TailZeroProb's own prefetch; only this ticket touches them)
-        TailZeroProb zp{hlast, a.Wzero, a.bzero, a.ezero, a.an, a.xa, a.xb, a.partial, M, a.Ch, a.npt, a.inverse, nullptr};
-        float zpre[1][32];
-        if (ty == PS_ZERO && wave < 2) zp.template prefetch<1>(zpre, m0 + wm * 32, n0, lane);
+#if !(FWN_PS_EARLY & 1)
+        PS_LOAD_P();
+#endif
+#if !(FWN_PS_EARLY & 2)
+        PS_LOAD_Z();
+#endif
         FWN_RING_BARRIER();                                    // the park overlays image / weights: every fragment read has returned
         // ---- 7. epilogue ----
         if (ty == PS_ZERO) {
