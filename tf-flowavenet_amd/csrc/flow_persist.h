@@ -94,7 +94,8 @@ __device__ __forceinline__ void ps_ld16(u32x4& v, const void* p) {
 // LDS: [image(s) | weight sub-chunks]; the split-K reduction scratch (48 KB) and the epilogue park (16 KB) reuse the front
 // of it once the K loop is over.  Largest stage: a gate = 71 rows x 512 B + 64 columns x 768 x 2 B.
 #define FWN_PS_IMG_MAX (72 * 512)                  // 70 halo rows + the zero row, 1 KiB aligned
-#define FWN_PS_LDS (FWN_PS_IMG_MAX + 64 * 768 * 2 + 256)
+#define FWN_PS_EPI (FWN_PS_IMG_MAX + 64 * 768 * 2)   // 16 KiB: the epilogue's operands (gate: the P tile, res: the bias), by LDS-DMA
+#define FWN_PS_LDS (FWN_PS_EPI + 16384 + 256)
 #define FWN_PS_PARK (48 * 1024)
 
 // weights: rows [n0, n0 + 64) x columns [0, 64 nsub) of W[..][ldb] -> nsub sub-chunks of [64][64] bf16 in the ring's
@@ -165,12 +166,6 @@ enum { PS_FRONT = 0, PS_GATE = 1, PS_RES = 2, PS_SKIP = 3, PS_FINAL = 4, PS_ZERO
 // TWO: both column halves of the row half (two waves: the ZeroConv, whose epilogue pairs columns n and n + 32 in a lane).
 #ifndef PS_D
 #define PS_D 3
-#endif
-#ifndef FWN_PS_OPAQUE
-#define FWN_PS_OPAQUE 0
-#endif
-#ifndef FWN_PS_EARLY
-#define FWN_PS_EARLY 0
 #endif
 template <int NACC, bool TWO, int NSEG, int KPS>
 __device__ __forceinline__ void ps_kloop(f32x16 (&tot)[2], float c0, float c1, const unsigned char* bq, const unsigned char* img,
@@ -265,12 +260,9 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
     unsigned t_cur = misc[0];
     int it = 0;
     while ((int)t_cur < total) {
-        // (opaque per ticket: hipcc otherwise hoists every lane-constant address term of every stage out of this loop and
-        // keeps them all in registers across the K loops - scratch memory; recomputing them is a few VALU instructions)
-        int tid = tid0;
-#if FWN_PS_OPAQUE
-        asm volatile("" : "+v"(tid));
-#endif
+        // (lane-constant address terms: hipcc hoists them out of this loop, i.e. in front of the first wait for producers -
+        // deliberately left so: made opaque per ticket they are recomputed BEHIND the wait, on the critical path: +3 % per pass)
+        const int tid = tid0;
         const int lane = tid & 63, lr = lane & 31, lh = lane >> 5;
         // decode (wave-uniform)
         int s = 0, rem = (int)t_cur;
@@ -323,32 +315,24 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
 
         // ---- 2. everything that does not depend on other workgroups: the weights (LDS-DMA), the epilogue's operands ----
         ps_issue_weights(bw, Wt, wrows, ldb, n0, nsub, wave, lane);
-        // the epilogue's operands that no other workgroup of this launch writes, requested BEFORE the wait for the producers
-        // (their round trip hides behind it): gate: the hoisted conditioning projection of this lane's item (row tid >> 2,
-        // 8 channels; an earlier launch wrote it: plain loads); res: the bias of its 8 columns
-        float4 pf0, pf1, pg0, pg1;
-        pf0 = pf1 = pg0 = pg1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // the epilogue's operands that no other workgroup of this launch writes, requested BEFORE the wait for the producers -
+        // by LDS-DMA like the weights, so that they cost no registers across the K loop and no round trip behind it: gate: the
+        // hoisted conditioning projection of the tile (64 rows x 64 packed-N columns fp32 = 16 one-KiB pieces of 4 rows; an
+        // earlier launch wrote it; rows past M read as zeros and are never stored); res: the bias of the 64 columns
+        unsigned char* const epi = lds + FWN_PS_EPI;
+        if (ty == PS_GATE) {
+            const srd_t sp = make_srd(a.P + (size_t)ly * M * 512, (uint32_t)((size_t)M * 2048));
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int pid = wave + q * 8;
+                buf_load16_lds(sp, (uint32_t)((m0 + pid * 4 + (lane >> 4)) * 2048 + n0 * 4 + (lane & 15) * 16), epi + pid * 1024);
+            }
+        } else if (ty == PS_RES && wave == 0) {
+            if (lane < 16) buf_load16_lds(make_srd(a.bres[ly], 1024u), (uint32_t)(n0 * 4 + lane * 16), epi);
+        }
         // ZeroConv: the plane elements its coupling transforms (TailZeroProb's own prefetch; only this ticket touches them)
         TailZeroProb zp{hlast, a.Wzero, a.bzero, a.ezero, a.an, a.xa, a.xb, a.partial, M, a.Ch, a.npt, a.inverse, nullptr};
         float zpre[1][32];
-#define PS_LOAD_P() do { \
-        if (ty == PS_GATE && tid < 256) { \
-            const int row = m0 + (tid >> 2); \
-            const float* pr = a.P + (size_t)ly * M * 512 + (size_t)(row < M ? row : M - 1) * 512 + n0 + (tid & 3) * 8; \
-            pf0 = *(const float4*)pr; pf1 = *(const float4*)(pr + 4); \
-            pg0 = *(const float4*)(pr + 32); pg1 = *(const float4*)(pr + 36); \
-        } else if (ty == PS_RES) { \
-            const float* br = a.bres[ly] + n0 + (tid & 7) * 8; \
-            pf0 = *(const float4*)br; pf1 = *(const float4*)(br + 4); \
-        } \
-        } while (0)
-#define PS_LOAD_Z() do { if (ty == PS_ZERO && wave < 2) zp.template prefetch<1>(zpre, m0 + wm * 32, n0, lane); } while (0)
-#if FWN_PS_EARLY & 1
-        PS_LOAD_P();
-#endif
-#if FWN_PS_EARLY & 2
-        PS_LOAD_Z();
-#endif
 #ifndef FWN_PS_STAMP_CLK
         PS_STAMP(1);
 #endif
@@ -479,12 +463,7 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
             }
         }
         PS_STAMP(4);
-#if !(FWN_PS_EARLY & 1)
-        PS_LOAD_P();
-#endif
-#if !(FWN_PS_EARLY & 2)
-        PS_LOAD_Z();
-#endif
+        if (ty == PS_ZERO && wave < 2) zp.template prefetch<1>(zpre, m0 + wm * 32, n0, lane);
         FWN_RING_BARRIER();                                    // the park overlays image / weights: every fragment read has returned
         // ---- 7. epilogue ----
         if (ty == PS_ZERO) {
@@ -516,6 +495,9 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
                     float fv[8], gv[8];
                     ps_take8(parkw, row, 2 * cg, 2 * cg + 1, fv);
                     ps_take8(parkw, row, 8 + 2 * cg, 8 + 2 * cg + 1, gv);
+                    const float* pl = (const float*)epi + row * 64 + cg * 8;
+                    const float4 pf0 = *(const float4*)pl, pf1 = *(const float4*)(pl + 4);
+                    const float4 pg0 = *(const float4*)(pl + 32), pg1 = *(const float4*)(pl + 36);
                     const float pf[8] = {pf0.x, pf0.y, pf0.z, pf0.w, pf1.x, pf1.y, pf1.z, pf1.w};
                     const float pg[8] = {pg0.x, pg0.y, pg0.z, pg0.w, pg1.x, pg1.y, pg1.z, pg1.w};
                     Pack16 out;
@@ -541,6 +523,7 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
                 }
                 Pack16 out;
                 if (ty == PS_RES) {
+                    const float4 pf0 = *(const float4*)((const float*)epi + c8 * 8), pf1 = *(const float4*)((const float*)epi + c8 * 8 + 4);
                     const float bb[8] = {pf0.x, pf0.y, pf0.z, pf0.w, pf1.x, pf1.y, pf1.z, pf1.w};
                     Pack16 hv;
                     hv.w = hin;
