@@ -94,8 +94,8 @@ __device__ __forceinline__ void ps_ld16(u32x4& v, const void* p) {
 // LDS: [image(s) | weight sub-chunks]; the split-K reduction scratch (48 KB) and the epilogue park (16 KB) reuse the front
 // of it once the K loop is over.  Largest stage: a gate = 71 rows x 512 B + 64 columns x 768 x 2 B.
 #define FWN_PS_IMG_MAX (72 * 512)                  // 70 halo rows + the zero row, 1 KiB aligned
-#define FWN_PS_EPI (FWN_PS_IMG_MAX + 64 * 768 * 2)   // 16 KiB: the epilogue's operands (gate: the P tile, res: the bias), by LDS-DMA
-#define FWN_PS_LDS (FWN_PS_EPI + 16384 + 256)
+#define FWN_PS_EPI (FWN_PS_IMG_MAX + 64 * 768 * 2)   // the epilogue's operands by LDS-DMA (gate: the P tile, res: the bias, ZeroConv: plane tiles + tables)
+#define FWN_PS_LDS (FWN_PS_EPI + 18432 + 256)
 #define FWN_PS_PARK (48 * 1024)
 
 // weights: rows [n0, n0 + 64) x columns [0, 64 nsub) of W[..][ldb] -> nsub sub-chunks of [64][64] bf16 in the ring's
@@ -330,9 +330,10 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
         } else if (ty == PS_RES && wave == 0) {
             if (lane < 16) buf_load16_lds(make_srd(a.bres[ly], 1024u), (uint32_t)(n0 * 4 + lane * 16), epi);
         }
-        // ZeroConv: the plane elements its coupling transforms (TailZeroProb's own prefetch; only this ticket touches them)
+        // ZeroConv: the plane elements its coupling transforms (only this ticket touches them) and its tables
         TailZeroProb zp{hlast, a.Wzero, a.bzero, a.ezero, a.an, a.xa, a.xb, a.partial, M, a.Ch, a.npt, a.inverse, nullptr};
-        float zpre[1][32];
+        static_assert(TailZeroProb::LDS_BYTES <= 18432, "epilogue operand region");
+        if (ty == PS_ZERO) zp.stage_lds(epi, m0, n0, wave, lane);
 #ifndef FWN_PS_STAMP_CLK
         PS_STAMP(1);
 #endif
@@ -463,13 +464,12 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
             }
         }
         PS_STAMP(4);
-        if (ty == PS_ZERO && wave < 2) zp.template prefetch<1>(zpre, m0 + wm * 32, n0, lane);
         FWN_RING_BARRIER();                                    // the park overlays image / weights: every fragment read has returned
         // ---- 7. epilogue ----
         if (ty == PS_ZERO) {
-            // ZeroConv + coupling + both ActNorms + log-det partial: TailZeroProb's epilogue as it stands (plain loads and
-            // stores: only this ticket touches these plane elements, and the NEXT launch reads them)
-            if (wave < 2) zp.template epilogue_pre<1>(acc, m0 + wm * 32, n0, lane, zpre);
+            // ZeroConv + coupling + both ActNorms + log-det partial: TailZeroProb's epilogue expressions on operands staged in LDS
+            // (plain stores: only this ticket touches these plane elements, and the NEXT launch reads them)
+            if (wave < 2) zp.epilogue_lds(acc, m0 + wm * 32, n0, lane, epi);
         } else {
             // the 64 x 64 fp32 tile -> LDS (lds_epi_park's layout, two 32-row wave tiles), then rows of 8 columns per lane:
             // ONE 16-byte write-through store per lane

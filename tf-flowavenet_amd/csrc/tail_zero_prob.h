@@ -59,17 +59,52 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
         const float none[MI][32] = {};
         epilogue_impl<MI, false>(acc, mrow0, ncol0, lane, none);
     }
-    template <int MI, bool PRE>
-    __device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32]) const {
+    // The one-launch flow (flow_persist.h) stages everything this epilogue reads in LDS before it waits for its producers
+    // (stage_lds: LDS-DMA, no registers): the two planes' tile as [2][64 rows][CW = min(Ch, 32)] fp32 (rows past M zeros)
+    // at `lt`, behind it exp(3 scale) of the pair tile [64] and the eight ActNorm rows [8][32].  MI = 1 only.
+    static constexpr int LDS_BYTES = 2 * 64 * 32 * 4 + 256 + 8 * 32 * 4;
+    __device__ __forceinline__ void stage_lds(unsigned char* lt, int m0, int ncol0, int wave, int lane) const {
+        const int pt = ncol0 >> 6, cw = Ch < 32 ? Ch : 32, cl = 31 - __clz(cw);
+        const uint32_t plane_bytes = (uint32_t)((size_t)M * Ch * 4);
+        const srd_t sxa = make_srd(xa, plane_bytes), sxb = make_srd(xb, plane_bytes);
+        for (int q = wave; q < 2 * cw; q += 8) {               // 64 elements of 4 bytes per piece
+            const int pl = q >= cw, idx = (q - pl * cw) * 64 + lane, row = idx >> cl, ch = idx & (cw - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pl ? sxa : sxb, (lds_ptr_t)(lt + pl * 8192 + (q - pl * cw) * 256), 4,
+                                                     (uint32_t)((m0 + row) * Ch + pt * 32 + ch) * 4u, 0, 0, 0);
+        }
+        if (wave == 7) __builtin_amdgcn_raw_ptr_buffer_load_lds(make_srd(ez, (uint32_t)(npt * 64 * 4)), (lds_ptr_t)(lt + 16384), 4,
+                                                                 (uint32_t)(pt * 64 + lane) * 4u, 0, 0, 0);
+        if (wave >= 3 && wave < 7) {
+            const int k = (wave - 3) * 2 + (lane >> 5), tau = pt * 32 + (lane & 31);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(make_srd(an, (uint32_t)(8 * Ch * 4)), (lds_ptr_t)(lt + 16384 + 256 + (wave - 3) * 256), 4,
+                                                     (uint32_t)(k * Ch + (tau < Ch ? tau : 0)) * 4u, 0, 0, 0);
+        }
+    }
+    __device__ void epilogue_lds(const f32x16 (&acc)[1][2], int mrow0, int ncol0, int lane, const unsigned char* lt) const {
+        const float none[1][32] = {};
+        epilogue_impl<1, false, true>(acc, mrow0, ncol0, lane, none, lt);
+    }
+    template <int MI, bool PRE, bool LDS = false>
+    __device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32],
+                                                  const unsigned char* lt = nullptr) const {
         const int lr = lane & 31, pt = ncol0 >> 6;
         const int tau = pt * 32 + lr;
         const bool chok = tau < Ch;
         const int tc = chok ? tau : 0;
-        const float els = ez[pt * 64 + lr], et = ez[pt * 64 + 32 + lr];
         const float* an_a = an;
         const float* an_b = an + 4 * Ch;
-        const float a_sh = an_a[tc], a_sc = an_a[Ch + tc], a_isc = an_a[2 * Ch + tc], a_l3 = an_a[3 * Ch + tc];
-        const float b_sh = an_b[tc], b_sc = an_b[Ch + tc], b_isc = an_b[2 * Ch + tc], b_l3 = an_b[3 * Ch + tc];
+        float els, et, a_sh, a_sc, a_isc, a_l3, b_sh, b_sc, b_isc, b_l3;
+        if constexpr (LDS) {
+            const float* cz = (const float*)(lt + 16384);
+            const float* ca = cz + 64 + lr;
+            els = cz[lr]; et = cz[32 + lr];
+            a_sh = ca[0]; a_sc = ca[32]; a_isc = ca[64]; a_l3 = ca[96];
+            b_sh = ca[128]; b_sc = ca[160]; b_isc = ca[192]; b_l3 = ca[224];
+        } else {
+            els = ez[pt * 64 + lr]; et = ez[pt * 64 + 32 + lr];
+            a_sh = an_a[tc]; a_sc = an_a[Ch + tc]; a_isc = an_a[2 * Ch + tc]; a_l3 = an_a[3 * Ch + tc];
+            b_sh = an_b[tc]; b_sc = an_b[Ch + tc]; b_isc = an_b[2 * Ch + tc]; b_l3 = an_b[3 * Ch + tc];
+        }
         const uint32_t plane_bytes = (uint32_t)((size_t)M * Ch * 4);
         const srd_t sxa = make_srd(xa, plane_bytes), sxb = make_srd(xb, plane_bytes);
         const int rbase = mrow0 + 4 * (lane >> 5);
@@ -83,8 +118,15 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const uint32_t so = (uint32_t)((mi * 32 + acc_row_c(r)) * Ch * 4);
-                xbv[r] = PRE ? pre[mi][r] : buf_load_f32(sxb, voff, so);
-                xav[r] = PRE ? pre[mi][16 + r] : buf_load_f32(sxa, voff, so);
+                if constexpr (LDS) {
+                    const int cw = Ch < 32 ? Ch : 32;
+                    const float* e = (const float*)lt + ((mrow0 & 63) + 4 * (lane >> 5) + acc_row_c(r)) * cw + (lr < cw ? lr : 0);
+                    xbv[r] = e[0];
+                    xav[r] = e[2048];
+                } else {
+                    xbv[r] = PRE ? pre[mi][r] : buf_load_f32(sxb, voff, so);
+                    xav[r] = PRE ? pre[mi][16 + r] : buf_load_f32(sxa, voff, so);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
