@@ -295,7 +295,7 @@ def _median_pass_s(fn, iters):
 def one_launch_twin(model, hp, params, dev):
     """The same parameters (the data-dependent init's tables exported from `model`) packed twice more: with
     fwn_model_desc.persist_mode = 2 (csrc/flow_persist.h: ONE launch per flow wherever the form exists) and 1 (a launch per
-    stage everywhere; the default, 0, takes the one-launch form up to 256 rows) - the pair whose results must be equal bit for bit (the device init and the host packing of `model` itself differ
+    stage everywhere; the default, 0, takes the one-launch form up to 512 rows) - the pair whose results must be equal bit for bit (the device init and the host packing of `model` itself differ
     in last bits of exp(3 logs))."""
     import numpy as np
     from tf_flowavenet_amd.model import FloWaveNet
@@ -344,7 +344,7 @@ def latency_b1(model, hp, t, dev, iters=10, params=None):
                           "bit_identical_to_launch_per_stage": same,
                           "what": "fwn_model_desc.persist_mode = 2: blocks 2 - 7 of this clip as one launch per flow "
                                   "(csrc/flow_persist.h; DESIGN.md section 3.7), and = 1: a launch per stage everywhere; the "
-                                  "line's fwd_ms / inv_ms are the default (0): one launch per flow up to 256 rows (blocks 5 - 7)"}
+                                  "line's fwd_ms / inv_ms are the default (0): one launch per flow up to 512 rows (blocks 4 - 7)"}
             del one, plain
         except Exception as e:   # a diagnostic: never instead of the line
             one_launch = {"error": "%s: %s" % (type(e).__name__, e)}

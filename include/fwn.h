@@ -425,7 +425,7 @@ typedef struct fwn_model_desc {
                                                * front conv in the previous flow's tail: csrc/tail_chain.h); 1: every flow on its own */
     int32_t persist_mode;                     /* flows of small-M blocks (hoisted conditioning) as ONE launch each (csrc/flow_persist.h;
                                                * same results bit for bit as a launch per stage): 0 = where that measured faster
-                                               * (<= 256 rows: DESIGN.md section 3.7), 1 = never, 2 = wherever the form exists
+                                               * (<= 512 rows: DESIGN.md section 3.7), 1 = never, 2 = wherever the form exists
                                                * (<= 4096 rows, n_layer <= 2) */
     /* Diagnostic (bench.py's per-block table), normally NULL: HOST array of n_block + 1 hipEvent_t handles.  The whole-model
      * calls record [k] on `stream` in front of the first launch of the k-th block they run (forward: block k, reverse: block

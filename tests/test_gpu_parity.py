@@ -700,7 +700,7 @@ def test_chained_flows_agree_with_every_flow_on_its_own(full_model, monkeypatch)
 def _persist_twins(hp, model, monkeypatch):
     """Two models from the same parameters (the tables of `model`'s data-dependent init, exported and packed again for both:
     the device init and the host packing differ in last bits of exp(3 logs)): persist_mode 2 (one launch per small-M flow)
-    and 1 (a launch per stage everywhere; the default, 0, takes the one-launch form up to 256 rows)."""
+    and 1 (a launch per stage everywhere; the default, 0, takes the one-launch form up to 512 rows)."""
     params = dict(W.synthetic_params(hp, 1234))
     for k, v in model.export_actnorm().items():
         params[k] = np.asarray(v, dtype=np.float32).reshape(params[k].shape)
@@ -718,7 +718,7 @@ def test_one_launch_flows_equal_the_launch_per_stage_path_bit_for_bit(full_model
     """Round 5 (csrc/flow_persist.h): the flows of the small-M blocks (hoisted conditioning, <= 4096 rows) run as ONE launch
     each - tickets from an atomic counter, per-row-tile dependency counters, write-through hand-offs - with the arithmetic of
     the launch-per-stage path: the same MFMA per k-step, the same split-K groups and summation order, the same epilogue
-    expressions.  fwn_model_desc.persist_mode = 2 takes the form wherever it exists, 1 nowhere (the default, 0: up to 256 rows); log-p, log-det, every latent sample and every
+    expressions.  fwn_model_desc.persist_mode = 2 takes the form wherever it exists, 1 nowhere (the default, 0: up to 512 rows); log-p, log-det, every latent sample and every
     waveform sample must be EQUAL.  Shapes: the bench workload (blocks 4 - 7), one clip (blocks 2 - 7: front conv inside the
     launch from Ch = 16 on, a launch of its own below), clip lengths that put clip edges inside row tiles and leave partial
     last tiles (4096 / 2048 / 6400 samples: 3 x 16 .. 5 x 25 rows at the last block)."""

@@ -723,11 +723,11 @@ static bool hoist_cond(const fwn_model_desc* m, int64_t M, int cin) {
 
 // whether block blk's flows run as one launch each (flow_persist.h)
 static bool persist_block(const fwn_model_desc* m, int64_t M, int blk) {
-    // 0: where it measured ahead of the launch-per-stage path (<= 256 rows: blocks 5 - 7 of one clip; at 504 rows - block 7 of the 8-clip
-    // pass - the form is 5 % ahead on one stream and 2 % BEHIND under overlapped lanes: 256 workgroups that mostly wait hold every
-    // CU's LDS), 1: nowhere, 2: wherever the form exists.  Same results bit for bit either way.
+    // 0: where it measured ahead of the launch-per-stage path (<= 512 rows: blocks 4 - 7 of one clip, block 7 of the 8-clip
+    // pass - there with one level's worth of workgroups, flow_persist.h's launcher), 1: nowhere,
+    // 2: wherever the form exists.  Same results bit for bit either way.
     if (m->persist_mode == 1 || m->gate_fp8) return false;
-    if (m->persist_mode != 2 && M > FWN_TUNE(FWN_PERSIST_AUTO_ROWS, 256)) return false;
+    if (m->persist_mode != 2 && M > FWN_TUNE(FWN_PERSIST_AUTO_ROWS, 512)) return false;
     const fwn_flow_desc* d = &m->flows[blk * m->n_flow];
     return hoist_cond(m, M, d->cin) && fwn_flow_persist_ok((int)M, d->Ch, d->L, d->npt, d->Wfront2 != nullptr, true);
 }

@@ -595,10 +595,13 @@ void fwn_launch_flow_persist_desc(const fwn_flow_desc* d, float* xa, float* xb, 
 static void fwn_launch_flow_persist(const PersistArgs& a, hipStream_t st) {
     const int ncu = fwn_device_cus();
     // one workgroup per ticket while the chip has room: a workgroup that holds a ticket of a LATER stage requests that
-    // ticket's weights at once and waits for its producers with them in LDS - the run-ahead that hides the weight stream
+    // ticket's weights at once and waits for its producers with them in LDS - the run-ahead that hides the weight stream.
+    // From 8 row tiles on (288+ tickets) only one level's worth of workgroups (8 per row tile): 256 workgroups that mostly wait
+    // would hold every CU's LDS against the other lanes' kernels (8-clip overlapped step, block 7 = 504 rows: 44.6 M samples/s
+    // with the full grid, 45.7 with 64 workgroups, 45.3 with a launch per stage; one stream: no difference)
     const int RT = (a.M + 63) / 64;
     const int total = RT * ((a.has_front ? 4 : 0) + a.L * 8 + (a.L - 1) * 4 + 8 + a.npt);
-    const int cap = FWN_TUNE(FWN_PERSIST_GRID, 0) > 0 ? FWN_TUNE(FWN_PERSIST_GRID, 0) : ncu;
+    const int cap = FWN_TUNE(FWN_PERSIST_GRID, 0) > 0 ? FWN_TUNE(FWN_PERSIST_GRID, 0) : RT >= 8 && 8 * RT < ncu ? 8 * RT : ncu;
     const int grid = total < cap ? total : cap;
     hipLaunchKernelGGL(flow_persist_kernel, dim3(grid), dim3(512), 0, st, a);
 }

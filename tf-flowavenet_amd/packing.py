@@ -657,7 +657,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
     # developer switch (same-box A/B, tests): FWN_CHAIN_MODE=1 runs every flow on its own like round 2 (fwn.h chain_mode)
     md.chain_mode = int(os.environ.get("FWN_CHAIN_MODE", "0"))
     # developer switch (fwn.h persist_mode): FWN_PERSIST_MODE=2 runs every small-M flow as ONE launch, 1 none; default 0 = those
-    # of <= 256 rows, where the form measured faster
+    # of <= 512 rows, where the form measured faster
     md.persist_mode = int(os.environ.get("FWN_PERSIST_MODE", "0"))
     md.gate_fp8 = 1 if gate_fp8 else 0
     torch.cuda.current_stream(dev).synchronize()
