@@ -697,7 +697,7 @@ def test_chained_flows_agree_with_every_flow_on_its_own(full_model, monkeypatch)
         assert float(dw.mean()) < 1e-3 and float(dw.max()) < ABS_WAV
 
 
-def _persist_twins(hp, model, monkeypatch):
+def _persist_twins(hp, model, monkeypatch, with_default=False):
     """Two models from the same parameters (the tables of `model`'s data-dependent init, exported and packed again for both:
     the device init and the host packing differ in last bits of exp(3 logs)): persist_mode 2 (one launch per small-M flow)
     and 1 (a launch per stage everywhere; the default, 0, takes the one-launch form up to 512 rows)."""
@@ -710,6 +710,10 @@ def _persist_twins(hp, model, monkeypatch):
     one = FloWaveNet(hp).load_params(params)
     monkeypatch.delenv("FWN_PERSIST_MODE")
     assert plain._packed.model_desc.persist_mode == 1 and one._packed.model_desc.persist_mode == 2
+    if with_default:
+        auto = FloWaveNet(hp).load_params(params)
+        assert auto._packed.model_desc.persist_mode == 0
+        return one, plain, auto
     return one, plain
 
 
@@ -723,17 +727,18 @@ def test_one_launch_flows_equal_the_launch_per_stage_path_bit_for_bit(full_model
     launch from Ch = 16 on, a launch of its own below), clip lengths that put clip edges inside row tiles and leave partial
     last tiles (4096 / 2048 / 6400 samples: 3 x 16 .. 5 x 25 rows at the last block)."""
     hp, model0, x, c, z = full_model
-    model, plain = _persist_twins(hp, model0, monkeypatch)
+    model, plain, auto = _persist_twins(hp, model0, monkeypatch, with_default=True)
     xs, cs, zs = x[:nb, :nt].contiguous(), c[:nb, :nt // hp.hop_size].contiguous(), z[:nb, :nt].contiguous()
     for rep in range(3):
-        lp0, ld0, zp0 = model.forward(xs, cs, return_z=True)
-        w0 = model.reverse(zs, cs)
         lp1, ld1, zp1 = plain.forward(xs, cs, return_z=True)
         w1 = plain.reverse(zs, cs)
-        torch.cuda.synchronize()
-        assert torch.equal(zp0, zp1), float((zp0 - zp1).abs().max())
-        assert float(lp0) == float(lp1) and float(ld0) == float(ld1)
-        assert torch.equal(w0, w1), float((w0 - w1).abs().max())
+        for m_ in (model, auto):       # wherever the form exists; the default (up to 512 rows, the small grid from 8 row tiles on)
+            lp0, ld0, zp0 = m_.forward(xs, cs, return_z=True)
+            w0 = m_.reverse(zs, cs)
+            torch.cuda.synchronize()
+            assert torch.equal(zp0, zp1), float((zp0 - zp1).abs().max())
+            assert float(lp0) == float(lp1) and float(ld0) == float(ld1)
+            assert torch.equal(w0, w1), float((w0 - w1).abs().max())
 
 
 @pytest.mark.parametrize("variant", ["one_layer", "8khz", "three_layers"])
