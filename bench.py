@@ -577,7 +577,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cond-mode", type=int, default=0)
     ap.add_argument("--serial", action="store_true", help="forward and inverse on one stream (no overlap)")
-    ap.add_argument("--lanes", type=int, default=3,
+    ap.add_argument("--lanes", type=int, default=7,
                     help="HIP streams per direction; successive (independent) steps rotate over them")
     ap.add_argument("--no-train", action="store_true", help="skip the configs[2] training-step leg")
     ap.add_argument("--no-rtf", action="store_true", help="skip the configs[3] 10 s clip leg")
@@ -657,10 +657,18 @@ def main():
     # leave most CUs idle) then overlap the MFMA-bound kernels of the other.  --serial puts
     # everything on one stream.  --lanes L gives each direction L streams, step k on lane k % L:
     # with 2L chains in flight the overlap no longer depends on the two passes drifting out of
-    # phase (measured: 1 lane 7.3 ms/step, 2 lanes 7.4, 3 lanes 6.6, 8 lanes 6.6).
+    # phase (round 1: 1 lane 7.3 ms/step, 2 lanes 7.4, 3 lanes 6.6, 8 lanes 6.6; round 5, three runs each on one box:
+    # 3 lanes 5.68 ms, 5 lanes 5.63, 7 lanes 5.59 - and 4 / 6 / 8 lanes 5.92 / 5.76 / 5.69: HIP maps streams onto four hardware
+    # queues in creation order, so with 4 or 8 lanes a step's forward and inverse lane share a queue; profiles/r05_lanes.txt).
     lanes_f = [torch.cuda.Stream(dev) for _ in range(args.lanes)]
     lanes_i = [torch.cuda.Stream(dev) for _ in range(args.lanes)]
     step_no = [0]
+    if not args.serial:
+        # resources, not steps: every lane's scratch (one workspace per stream, model._workspace) exists before the warm-up, so
+        # that with fewer warm-up steps than lanes no allocation falls into the timed region
+        for st in lanes_f + lanes_i:
+            with torch.cuda.stream(st):
+                model._workspace(b, t)
 
     def enqueue_step():
         s_fwd, s_inv = lanes_f[step_no[0] % args.lanes], lanes_i[step_no[0] % args.lanes]
