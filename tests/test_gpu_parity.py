@@ -851,11 +851,11 @@ def test_concurrent_streams_reproduce_the_serial_result(full_model, nb, nt):
         assert torch.equal(got, ref_wav if kind == "inv" else ref_nll), kind
 
 
-@pytest.mark.parametrize("nb,lanes,steps", [(8, 3, 312), (1, 6, 312)])
+@pytest.mark.parametrize("nb,lanes,steps", [(8, 3, 312), (8, 7, 168), (1, 6, 312)])
 def test_overlapped_streams_soak(full_model, nb, lanes, steps):
     """The soak behind the headline mode (tools/diag/lanes_flake.py as a test): `steps` overlapped steps
-    in bench.py's arrangement - `lanes` HIP streams per direction, forward and inverse passes of independent steps in
-    flight together, kernels of every kind sharing CUs - and every one of them bit-identical to the one-stream pass.
+    in bench.py's arrangement - `lanes` HIP streams per direction (the bench's default is 7 since round 5), forward and inverse
+    passes of independent steps in flight together, kernels of every kind sharing CUs - and every one of them bit-identical to the one-stream pass.
     The two silent-corruption findings of this project fired in about 1 step of 10 (SLP packed math, round 2) and 1 of
     50 (a ring refilled behind a barrier crossed with LDS reads in flight, round 3: DESIGN.md section 3.5); front_mfma_kernel
     runs at its real LDS size here, co-resident with other workgroups."""
