@@ -398,7 +398,7 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
         return h8a && h8b && ca && l < d->L && d->Wd8[l] && fwn_gate_fp8_ok(M, dilation_of(l)) && (l > 0 || d->Ch <= 16);
     };
     // ---- the whole flow as ONE launch (flow_persist.h): small M, hoisted conditioning; `sync` zeroed by the caller ----
-    if (sync && P && !ddi && !h8a && !(chain && (chain->have_h0 || chain->xb_out)) &&
+    if (sync && P && !ddi && !(h8a && ca) && !(chain && (chain->have_h0 || chain->xb_out)) &&
         fwn_flow_persist_ok(M, d->Ch, d->L, d->npt, d->Wfront2 != nullptr, ((uintptr_t)xa & 15) == 0)) {
         const int inside = fwn_flow_persist_front_inside(d->Ch);
         if (!inside)
@@ -726,7 +726,7 @@ static bool persist_block(const fwn_model_desc* m, int64_t M, int blk) {
     // 0: where it measured ahead of the launch-per-stage path (<= 512 rows: blocks 4 - 7 of one clip, block 7 of the 8-clip
     // pass - there with one level's worth of workgroups, flow_persist.h's launcher), 1: nowhere,
     // 2: wherever the form exists.  Same results bit for bit either way.
-    if (m->persist_mode == 1 || m->gate_fp8) return false;
+    if (m->persist_mode == 1) return false;       // (gate_fp8 models too: fp8 taps need fused conditioning and >= 12288 rows - never these blocks)
     if (m->persist_mode != 2 && M > FWN_TUNE(FWN_PERSIST_AUTO_ROWS, 512)) return false;
     const fwn_flow_desc* d = &m->flows[blk * m->n_flow];
     return hoist_cond(m, M, d->cin) && fwn_flow_persist_ok((int)M, d->Ch, d->L, d->npt, d->Wfront2 != nullptr, true);

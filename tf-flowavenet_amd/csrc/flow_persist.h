@@ -1,7 +1,8 @@
 // One flow of the small-M chain as ONE launch (round 5): front conv -> [gate -> res] x (L - 1) -> gate -> skip sum -> final
 // conv -> ZeroConv + coupling, modules.py:161-186 / model.py:121-161, for the row counts where every stage is a launch of a
-// handful of workgroups (blocks 4 - 7 of the 8-clip pass, every block from 2 on at one clip: ~7 dependent launches of
-// 5 - 9 us per flow).
+// handful of workgroups (~7 dependent launches of 5 - 9 us per flow).  The whole-model calls take it up
+// to 512 rows by default (fwn_model_desc.persist_mode: blocks 4 - 7 of one clip, block 7 of the 8-clip pass; section 3.7 has the
+// per-block table of where it wins); the form exists up to 4096 rows.
 //
 // Shape of the thing
 //  * The flow is cut into TICKETS = (stage, 64-row tile i, 64-column tile j), numbered stage-major.  Workgroups (8 waves,
@@ -10,14 +11,15 @@
 //    were taken by workgroups that are running (no spinning grid can starve another; any number of lanes may overlap).
 //  * Dependencies are per row tile: done[stage][i] counts the column tiles of (stage, i) that have published.  A gate tile
 //    waits for the previous stage's row tiles i - 1 .. i + 1 (dilation halo), the others for row tile i.  No grid barrier.
-//  * ALL weights of a ticket (64 output columns x K <= 768: <= 96 KB) are requested by LDS-DMA BEFORE the wait for its
-//    dependencies; behind the wait only the activation rows are fetched (<= 64 KB, one round trip) and the K loop runs
-//    out of LDS without a single wait or barrier.
+//  * EVERYTHING a ticket needs that no other workgroup of the launch writes is requested by LDS-DMA BEFORE the wait for its
+//    dependencies: its weights (64 output columns x K <= 768: <= 96 KB), the gate's hoisted conditioning tile, the res bias,
+//    the ZeroConv's plane tiles and tables.  Behind the wait only the activation rows are fetched (<= 64 KB, one round trip)
+//    and the K loop runs out of LDS without a single wait or barrier.
 //  * Hand-offs between workgroups follow the programming guide's Guideline 16, first row of its table: every handed-off
 //    byte is stored write-through (16-byte sc1 stores from a row-major epilogue), every storing wave drains (vmcnt(0)), the
 //    workgroup's barrier, ONE lane adds to the row tile's counter (agent scope); the consumer's wave 0 polls that word with
-//    relaxed agent-scope loads, a workgroup barrier, then EVERY load of handed-off bytes is a 16-byte sc1 load to registers
-//    (global_load_dwordx4 ... sc1 from inline asm, then ds_write into the swizzled LDS image).  No fence anywhere.
+//    relaxed agent-scope loads, a workgroup barrier, then EVERY load of handed-off bytes is a 16-byte sc1 buffer load to
+//    registers (the descriptor's bounds return the zero rows), written whole into the swizzled LDS image.  No fence anywhere.
 //  * Arithmetic = the launch-per-stage path's, bit for bit: the same MFMA per k-step, the k-steps dealt to the same KSP
 //    accumulation groups (k-step mod 4; mod 2 for the ZeroConv; one group for the front conv), partial sums added in the
 //    same order, the same epilogue expressions.  tests/test_gpu_parity.py compares the two paths with ==.
@@ -79,15 +81,6 @@ __device__ __forceinline__ void ps_wait_ge(const unsigned* p, unsigned need, uns
     }
 }
 
-// 16-byte sc1 load to registers, hidden from hipcc's wait bookkeeping on purpose (it is waited for by PS_WAITn below, in
-// the same straight-line code; tools/check_async_loads.py audits the ISA for any touch of the destinations in between)
-__device__ __forceinline__ void ps_ld16(u32x4& v, const void* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-}
-#define PS_WAIT1(v) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]) :: "memory")
-#define PS_WAIT4(v) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory")
-#define PS_WAIT5(v) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]) :: "memory")
-#define PS_WAIT8(v) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory")
 // every wave's LDS and vector-memory operations retired, then the workgroup's barrier
 #define PS_BARRIER() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
