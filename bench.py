@@ -658,8 +658,9 @@ def main():
     # everything on one stream.  --lanes L gives each direction L streams, step k on lane k % L:
     # with 2L chains in flight the overlap no longer depends on the two passes drifting out of
     # phase (round 1: 1 lane 7.3 ms/step, 2 lanes 7.4, 3 lanes 6.6, 8 lanes 6.6; round 5, three runs each on one box:
-    # 3 lanes 5.68 ms, 5 lanes 5.63, 7 lanes 5.59 - and 4 / 6 / 8 lanes 5.92 / 5.76 / 5.69: odd counts win whatever the order
-    # the streams are created in (not understood; profiles/r05_lanes.txt).
+    # 3 lanes 5.68 ms, 5 lanes 5.63, 7 lanes 5.59 at 30 steps - and 4 / 6 / 8 lanes 5.92 / 5.76 / 5.69: odd counts win whatever
+    # the order the streams are created in; the margin depends on how the timed steps fall onto the lanes: +0.5 % at 20 steps,
+    # +-0 at 60, -3 % at 10 against 3 lanes; profiles/r05_lanes.txt).
     lanes_f = [torch.cuda.Stream(dev) for _ in range(args.lanes)]
     lanes_i = [torch.cuda.Stream(dev) for _ in range(args.lanes)]
     step_no = [0]
