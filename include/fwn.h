@@ -244,7 +244,9 @@ int fwn_flow_run(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float*
  * Preconditions (fwn_flow_persist_supported != 0): conditioning hoisted (P given, ca == NULL), n_layer <= 2,
  * M = B * T / (2 Ch) <= 4096 rows, forward or inverse without data-dependent init, bf16 gates.
  * sync: fwn_flow_persist_sync_bytes(M, L) bytes of device memory that the CALLER ZEROES (stream-ordered) before every call;
- * sync[1] != 0 afterwards = a bounded spin gave up (fwn_flow_persist_status reads it back: that one synchronises). */
+ * sync[1] != 0 afterwards = a bounded spin gave up (fwn_flow_persist_status reads it back: that one synchronises); the flow's
+ * outputs are then NaN (plane elements and log-det partials of the row tiles down the chain), also inside the whole-model
+ * calls: log_p / logdet / the waveform come back NaN, never silently wrong. */
 int fwn_flow_persist_supported(const fwn_flow_desc* d, int64_t B, int64_t T);
 int64_t fwn_flow_persist_sync_bytes(int M, int L);
 int fwn_flow_run_persist(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, void* h0, void* h1, void* o,
@@ -252,7 +254,8 @@ int fwn_flow_run_persist(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
 int fwn_flow_persist_status(const void* sync, void* stream);
 
 /* ---- process-wide developer options (replaces the environment variables the launch path read in round 4) ----
- * name: "rs_persist" (-1 auto, 0 / 1: the register-streamed gate's persistent form off / on).  Returns the previous value,
+ * name: "rs_persist" (-1 auto, 0 / 1: the register-streamed gate's persistent form off / on); "persist_spin_us" (bound of the
+ * one-launch flow's dependency spins in microseconds, 0 = the default 2 s: tests shorten it to provoke a give-up).  Returns the previous value,
  * or FWN_ERR_ARG for an unknown name.  (Round 4's second switch, the experimental co-resident gate, left the library:
  * tools/gate_co.h + tools/bench_gate_co.hip.) */
 int fwn_set_option(const char* name, int value);

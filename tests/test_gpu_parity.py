@@ -818,6 +818,62 @@ def test_one_launch_flow_entry_point_and_its_status_word(full_model, blk, b, inv
             assert torch.equal(got[2], outs[0][2])
 
 
+def test_one_launch_flow_that_gives_up_waiting_returns_nans_and_says_so(full_model):
+    """A bounded spin of the one-launch flow that gives up must not pass silently: with the bound shortened to 1 us
+    (fwn_set_option("persist_spin_us")) consumers give up long before their producers publish; the call then returns
+    (no hang), fwn_flow_persist_status reports the give-up word, and the flow's outputs - plane elements and log-det partials -
+    are NaN, so that the whole-model calls built on it return NaN for log_p / logdet / the waveform, never a wrong number.  With the
+    default bound restored the same call is clean again."""
+    hp, model, x, c, z = full_model
+    lib = _lib.load()
+    blk, b, T = 5, 3, 16128
+    d = model._packed.flow_descs[blk * hp.n_flow + 1]
+    ch = 1 << blk
+    m = b * (T // (2 * ch))
+    rng = np.random.default_rng(5)
+    st = torch.cuda.current_stream().cuda_stream
+    ca = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    P = torch.empty(hp.n_layer, m, 512, device="cuda", dtype=torch.float32)
+    _lib.check(lib.fwn_cond(ca.data_ptr(), d.Wc[0], P.data_ptr(), 512 * d.kcpad, m * 512, 0, 1, 1, hp.n_layer, m, d.cin, d.kcpad, st), "fwn_cond")
+    xa0 = torch.from_numpy(rng.standard_normal((m, ch)).astype(np.float32) * 0.3).cuda()
+    xb0 = torch.from_numpy(rng.standard_normal((m, ch)).astype(np.float32) * 0.3).cuda()
+
+    def run():
+        xa, xb = xa0.clone(), xb0.clone()
+        h0 = torch.zeros(m, 256, device="cuda", dtype=torch.bfloat16)
+        h1 = torch.zeros(m, 256, device="cuda", dtype=torch.bfloat16)
+        o = torch.zeros(hp.n_layer, m, 256, device="cuda", dtype=torch.bfloat16)
+        part = torch.zeros(lib.fwn_tail_partials(m), device="cuda", dtype=torch.float32)
+        sync = torch.zeros(lib.fwn_flow_persist_sync_bytes(m, hp.n_layer) // 4, device="cuda", dtype=torch.int32)
+        _lib.check(lib.fwn_flow_run_persist(C.byref(d), b, T, xa.data_ptr(), xb.data_ptr(), h0.data_ptr(), h1.data_ptr(), o.data_ptr(),
+                                            P.data_ptr(), part.data_ptr(), 0, sync.data_ptr(), st), "fwn_flow_run_persist")
+        status = lib.fwn_flow_persist_status(sync.data_ptr(), st)
+        torch.cuda.synchronize()
+        return status, xa, xb, part
+
+    old = lib.fwn_set_option(b"persist_spin_us", 1)
+    try:
+        status, xa, xb, part = run()
+    finally:
+        lib.fwn_set_option(b"persist_spin_us", old)
+    assert status != 0, "a 1 us bound must make some consumer give up"
+    assert bool(torch.isnan(part).any()) and bool(torch.isnan(xb).any()), "a give-up must poison the flow's outputs"
+    status, xa, xb, part = run()
+    assert status == 0 and bool(torch.isfinite(part).all()) and bool(torch.isfinite(xa).all()) and bool(torch.isfinite(xb).all())
+    # the whole-model calls (one clip: blocks 4 - 7 run as one launch per flow by default)
+    xs, cs, zs = x[:1, :T].contiguous(), c[:1, :T // hp.hop_size].contiguous(), z[:1, :T].contiguous()
+    old = lib.fwn_set_option(b"persist_spin_us", 1)
+    try:
+        lp, ld = model.forward(xs, cs)
+        wav = model.reverse(zs, cs)
+        torch.cuda.synchronize()
+    finally:
+        lib.fwn_set_option(b"persist_spin_us", old)
+    assert not np.isfinite(float(lp) + float(ld)) and not bool(torch.isfinite(wav).all())
+    lp, ld = model.forward(xs, cs)
+    assert np.isfinite(float(lp)) and np.isfinite(float(ld)) and bool(torch.isfinite(model.reverse(zs, cs)).all())
+
+
 def test_full_size_inverse_is_deterministic_and_bounded(full_model):
     hp, model, x, c, z = full_model
     w1 = model.reverse(z, c)

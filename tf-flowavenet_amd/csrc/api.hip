@@ -485,7 +485,7 @@ int fwn_flow_persist_status(const void* sync, void* stream) {
 }
 int fwn_set_option(const char* name, int value) {
     REQUIRE(name, "fwn_set_option: null name");
-    int* slot = !strcmp(name, "rs_persist") ? &g_fwn_opt_rs_persist : nullptr;
+    int* slot = !strcmp(name, "rs_persist") ? &g_fwn_opt_rs_persist : !strcmp(name, "persist_spin_us") ? &g_fwn_opt_persist_spin_us : nullptr;
     REQUIRE(slot, "fwn_set_option: unknown option '%s'", name);
     const int old = *slot;
     *slot = value;

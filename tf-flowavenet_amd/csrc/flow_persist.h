@@ -23,8 +23,9 @@
 //  * Arithmetic = the launch-per-stage path's, bit for bit: the same MFMA per k-step, the k-steps dealt to the same KSP
 //    accumulation groups (k-step mod 4; mod 2 for the ZeroConv; one group for the front conv), partial sums added in the
 //    same order, the same epilogue expressions.  tests/test_gpu_parity.py compares the two paths with ==.
-//  * Every spin is bounded (2 s of the 100 MHz reference clock): a give-up sets sync[1] and the ticket goes on with
-//    whatever is there (fwn_flow_persist_status reads the word).
+//  * Every spin is bounded (2 s of the 100 MHz reference clock; fwn_set_option("persist_spin_us")): a give-up sets sync[1],
+//    the ticket goes on with whatever is there, and the ZeroConv tickets down the chain turn their outputs into NaN - the
+//    call's log-p / log-det / waveform are NaN, never silently wrong (fwn_flow_persist_status reads the word).
 //
 // sync block (caller zeroes it before the launch; the whole-model calls zero all of a pass's blocks with one memset):
 //   sync[0] ticket counter, sync[1] give-up code, sync[8 + s * RT + i] = done[s][i].
@@ -55,6 +56,7 @@ struct PersistArgs {
     float* partial;       // forward: log-det partial slots ((M + 63) / 64 * 8), inverse: nullptr
     unsigned* sync;
     int M, Ti, Ch, npt, L, inverse, has_front;
+    unsigned spin_ticks;  // bound of every spin in ticks of the 100 MHz reference clock (fwn_set_option("persist_spin_us"); default 2 s)
 #ifdef FWN_PS_STAMP
     unsigned long long* stamps;   // diagnostic build: [ticket][8] s_memrealtime stamps of wave 0
 #endif
@@ -68,13 +70,13 @@ __device__ __forceinline__ unsigned ps_add(unsigned* p, unsigned v) {
     return __hip_atomic_fetch_add((ps_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wave 0 only: until *p >= need (relaxed agent-scope polls + s_sleep); a give-up after 2 s sets *err
-__device__ __forceinline__ void ps_wait_ge(const unsigned* p, unsigned need, unsigned* err, unsigned code) {
+__device__ __forceinline__ void ps_wait_ge(const unsigned* p, unsigned need, unsigned* err, unsigned code, unsigned spin_ticks) {
     if (ps_ld(p) >= need) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         __builtin_amdgcn_s_sleep(1);
         if (ps_ld(p) >= need) return;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)spin_ticks) {
             __hip_atomic_store((ps_gu32*)err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
@@ -338,13 +340,13 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
                 if (sp >= 0) {
                     const unsigned need = (unsigned)st_ntn(sp);
                     for (int d = -1; d <= 1; ++d)
-                        if ((unsigned)(ti + d) < (unsigned)RT) ps_wait_ge(done + sp * RT + ti + d, need, err, 1u + s);
+                        if ((unsigned)(ti + d) < (unsigned)RT) ps_wait_ge(done + sp * RT + ti + d, need, err, 1u + s, a.spin_ticks);
                 }
             } else if (ty != PS_FRONT) {
-                ps_wait_ge(done + sp * RT + ti, (unsigned)st_ntn(sp), err, 1u + s);
+                ps_wait_ge(done + sp * RT + ti, (unsigned)st_ntn(sp), err, 1u + s, a.spin_ticks);
                 if (ty == PS_FINAL)          // U overwrites the h buffer the last gate reads: its neighbours' halo reads first
                     for (int d = -1; d <= 1; d += 2)
-                        if ((unsigned)(ti + d) < (unsigned)RT) ps_wait_ge(done + (sp - 1) * RT + ti + d, 8u, err, 1u + s);
+                        if ((unsigned)(ti + d) < (unsigned)RT) ps_wait_ge(done + (sp - 1) * RT + ti + d, 8u, err, 1u + s, a.spin_ticks);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -352,6 +354,9 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
         asm volatile("" ::: "memory");
         PS_STAMP(2);
 
+        // (ZeroConv: the give-up word, requested here so that its round trip is over by the epilogue)
+        unsigned errw = 0u;
+        if (ty == PS_ZERO) errw = ps_ld(err);
         // ---- 4. the activation rows -> LDS image(s) ----
         u32x4 hin = {0u, 0u, 0u, 0u};
         const uint32_t hbytes = (uint32_t)((size_t)M * FWN_HID * 2);
@@ -462,7 +467,10 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
         if (ty == PS_ZERO) {
             // ZeroConv + coupling + both ActNorms + log-det partial: TailZeroProb's epilogue expressions on operands staged in LDS
             // (plain stores: only this ticket touches these plane elements, and the NEXT launch reads them)
-            if (wave < 2) zp.epilogue_lds(acc, m0 + wm * 32, n0, lane, epi);
+            // A spin that gave up anywhere up the chain of this row tile (sync[1] != 0: the stores of the ticket that set it were
+            // drained before it published) must not pass silently: this ticket's plane elements and log-det partial become NaN,
+            // so log_p / log-det / the waveform of the call are NaN (and fwn_flow_persist_status reports the word).
+            if (wave < 2) zp.epilogue_lds(acc, m0 + wm * 32, n0, lane, epi, errw != 0u);
         } else {
             // the 64 x 64 fp32 tile -> LDS (lds_epi_park's layout, two 32-row wave tiles), then rows of 8 columns per lane:
             // ONE 16-byte write-through store per lane
@@ -547,6 +555,7 @@ __global__ __launch_bounds__(512) void flow_persist_kernel(PersistArgs a) {
 }
 
 // ---- host side ----
+int g_fwn_opt_persist_spin_us = 0;         // fwn_set_option("persist_spin_us", ..): 0 = the default bound (2 s)
 int fwn_flow_persist_sync_words(int M, int L) {
     const int RT = (M + 63) / 64;
     int w = (FWN_PS_HDR + (2 * L + 3) * RT + 3) & ~3;     // multiple of 16 bytes
@@ -582,6 +591,7 @@ void fwn_launch_flow_persist_desc(const fwn_flow_desc* d, float* xa, float* xb, 
     a.Wzero = (const bf16*)d->Wzero; a.bzero = d->bzero; a.ezero = d->ezero;
     a.hA = (bf16*)hA; a.hB = (bf16*)hB; a.o = (bf16*)o; a.P = P; a.partial = partial; a.sync = sync;
     a.M = M; a.Ti = Ti; a.Ch = d->Ch; a.npt = d->npt; a.L = d->L; a.inverse = inverse; a.has_front = has_front;
+    a.spin_ticks = g_fwn_opt_persist_spin_us > 0 ? (unsigned)(g_fwn_opt_persist_spin_us > 40000000 ? 4000000000u : (unsigned)g_fwn_opt_persist_spin_us * 100u) : 200000000u;
     fwn_launch_flow_persist(a, st);
 }
 

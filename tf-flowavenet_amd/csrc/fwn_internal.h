@@ -74,6 +74,7 @@ void fwn_launch_flow_persist_desc(const fwn_flow_desc* d, float* xa, float* xb, 
                                   float* partial, unsigned* sync, int M, int Ti, int inverse, int has_front, hipStream_t st);
 // process-wide developer options (fwn_set_option): -1 = auto
 extern int g_fwn_opt_rs_persist;
+extern int g_fwn_opt_persist_spin_us;     // flow_persist.h: bound of the one-launch flow's spins in microseconds (0 = 2 s)
 int fwn_device_cus();            // compute units of the current device (cached per device)
 
 int fwn_tail_rows(int M);        // rows per fused-tail workgroup

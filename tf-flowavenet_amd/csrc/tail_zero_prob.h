@@ -80,13 +80,14 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
                                                      (uint32_t)(k * Ch + (tau < Ch ? tau : 0)) * 4u, 0, 0, 0);
         }
     }
-    __device__ void epilogue_lds(const f32x16 (&acc)[1][2], int mrow0, int ncol0, int lane, const unsigned char* lt) const {
+    // bad: a producer of this ticket gave up waiting (flow_persist.h): every output of the ticket becomes NaN
+    __device__ void epilogue_lds(const f32x16 (&acc)[1][2], int mrow0, int ncol0, int lane, const unsigned char* lt, bool bad) const {
         const float none[1][32] = {};
-        epilogue_impl<1, false, true>(acc, mrow0, ncol0, lane, none, lt);
+        epilogue_impl<1, false, true>(acc, mrow0, ncol0, lane, none, lt, bad);
     }
     template <int MI, bool PRE, bool LDS = false>
     __device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[MI][2], int mrow0, int ncol0, int lane, const float (&pre)[MI][32],
-                                                  const unsigned char* lt = nullptr) const {
+                                                  const unsigned char* lt = nullptr, bool bad = false) const {
         const int lr = lane & 31, pt = ncol0 >> 6;
         const int tau = pt * 32 + lr;
         const bool chok = tau < Ch;
@@ -144,6 +145,10 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
                     ob = yb * b_isc - b_sh;                                    // ActNorm^-1 (model.py:97-102)
                     oa = xav[r] * a_isc - a_sh;
                 }
+                if constexpr (LDS) {
+                    ob = bad ? __builtin_nanf("") : ob;
+                    oa = bad ? __builtin_nanf("") : oa;
+                }
                 buf_store_f32(sxb, voff, so, ob);
                 buf_store_f32(sxa, voff, so, oa);
                 if (save_z) {
@@ -155,6 +160,7 @@ struct TailZeroProb {     // (log_s | t) = U' Wz, then the coupling + ActNorm of
         if (partial) {          // one slot per (row tile, pair tile, wave row): fixed order, summed by prior_kernel
 #pragma unroll
             for (int s = 32; s > 0; s >>= 1) lsum += __shfl_xor(lsum, s);
+            if constexpr (LDS) lsum = bad ? __builtin_nanf("") : lsum;
             const int tile_m = mrow0 >> 6, wm = (mrow0 >> 5) & 1;
             if (lane == 0) {
                 partial[(tile_m * 4 + pt) * 2 + wm] = lsum;
