@@ -518,7 +518,8 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             fwn_tn_group_launch(D.tn.job + g0, D.tn.n - g0 < FWN_MAX_GROUP ? D.tn.n - g0 : FWN_MAX_GROUP, (int)D.m, (int)D.ti, s_);
         return wg_wn(D, s_);
     };
-    auto weight_grads_block = [&](std::vector<Deferred>& flows, hipStream_t s_) -> int {      // all flows of a block (side stream)
+    // after_small: recorded on s_ behind stage (1) of the block's last flow (block 0: the conditioning gradient is complete there)
+    auto weight_grads_block = [&](std::vector<Deferred>& flows, hipStream_t s_, hipEvent_t after_small) -> int {      // all flows of a block (side stream)
         if (flows.empty()) return FWN_OK;
         const fwn_tn_job* gj[FWN_MAX_GROUP * 2];
         int gn[FWN_MAX_GROUP * 2], ng = 0;
@@ -530,6 +531,8 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             wg_small(flows[k], s_);
             wg_place(flows[k], part);
         }
+        if (after_small && hipEventRecord(after_small, s_) != hipSuccess)
+            return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: hipEventRecord failed");
         TREQUIRE(part - pl.tn_part <= tn_partial_floats(md, flows[0].i, flows[0].m),
                  "fwn_train_loss_and_grads: block %d: weight-gradient partials need %ld floats, planned %ld", flows[0].i,
                  (long)(part - pl.tn_part), tn_partial_floats(md, flows[0].i, flows[0].m));
@@ -577,11 +580,16 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
         pending_block = -1;
         return true;
     };
-    auto hand_over = [&]() -> int {          // fork, then everything in `pending` to the side stream
+    hipEvent_t dca_done = nullptr;          // side stream, block 0: behind the last conditioning-gradient GEMM of the call
+    auto hand_over = [&](bool last_block) -> int {          // fork, then everything in `pending` to the side stream
         if (!fork_side()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: forking the side stream failed");
         // (FWN_SKIP_WG: developer builds only - times the data-gradient chain alone; the gradients are then wrong)
         if (!FWN_TUNE(FWN_SKIP_WG, 0)) {
-            const int rc = weight_grads_block(pending, side);
+            if (last_block) {
+                dca_done = evp->get();
+                if (!dca_done) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: hipEventCreate failed");
+            }
+            const int rc = weight_grads_block(pending, side, dca_done);
             if (rc != FWN_OK) return rc;
         }
         pending.clear();
@@ -718,15 +726,21 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             if (side && j == 0) {      // this block's weight gradients: under the next block's chain
                 if (!join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");
                 if (hook_failed) return hook_stop();
-                const int rc = hand_over();
+                const int rc = hand_over(i == 0);
                 if (rc != FWN_OK) return rc;
                 pending_block = i;
             }
         }
     }
-    // the first block's: the conditioning gradient is complete only now
-    if (side && !join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");
-    if (hook_failed) return hook_stop();
+    // The conditioning gradient is complete behind stage (1) of block 0's weight gradients (side stream): the up-sampling
+    // backward waits for THAT event and runs under the rest of block 0's side work (its grouped TN GEMM and weight-norm
+    // backward: ~1 ms in which the chain's queue had nothing to do); block 0 is joined and reported behind it.
+    if (side && dca_done) {
+        if (hipStreamWaitEvent(st, dca_done, 0) != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: hipStreamWaitEvent failed");
+    } else if (side) {
+        if (!join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");
+        if (hook_failed) return hook_stop();
+    }
     // up-sampling transposed convolutions (model.py:301-311), last stage first
     hipLaunchKernelGGL(planes_to_rows_kernel, dim3(grid_of(B * T * nmel)), dim3(256), 0, st, pl.dcplanes, (const bf16*)pl.cplanes, B * T, half, pl.up_dy,
                        pl.up_y);
@@ -753,6 +767,8 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
             y = xin;
         }
     }
+    if (side && !join_pending()) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: joining the side stream failed");
+    if (hook_failed) return hook_stop();
     if (on_block_done && on_block_done(user, -1) != 0) return hook_stop();
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fwn_set_error(FWN_ERR_HIP, "fwn_train_loss_and_grads: %s", hipGetErrorString(e));
