@@ -11,7 +11,10 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 _ISA = {}
-UNITS = ("flow_kernels", "train_kernels", "aux_kernels")
+# (unit, extra flags): every kernel translation unit of libfwn.so, and the diagnostic -DFWN_PS_STAMP build of the one-launch flow
+# (flow_persist.hip - weights, P tile and plane tiles by LDS-DMA in flight across a barrier, parks overlaying the
+# weight regions, ds_reads kept three k-steps ahead - was the one unit the checks skipped)
+UNITS = (("flow_kernels", ()), ("train_kernels", ()), ("aux_kernels", ()), ("flow_persist", ()), ("flow_persist", ("-DFWN_PS_STAMP",)))
 
 
 def _makefile_flags():
@@ -27,11 +30,13 @@ def _makefile_flags():
 
 
 def _isa(unit, tmp_path_factory):
-    """<unit>.hip -> gfx950 ISA, once per session (flow_kernels.hip: four minutes of hipcc)."""
+    """(<unit>, extra flags) -> gfx950 ISA, once per session (flow_kernels.hip: four minutes of hipcc)."""
     if unit not in _ISA:
-        out = tmp_path_factory.mktemp("isa") / (unit + ".s")
-        subprocess.run([HIPCC] + _makefile_flags() + ["-S", "--cuda-device-only", "-c", os.path.join(CSRC, unit + ".hip"), "-o", str(out)],
+        name, extra = unit
+        out = tmp_path_factory.mktemp("isa") / (name + ".s")
+        subprocess.run([HIPCC] + _makefile_flags() + list(extra) + ["-S", "--cuda-device-only", "-c", os.path.join(CSRC, name + ".hip"), "-o", str(out)],
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert any(True for _ in open(str(out))), out
         _ISA[unit] = str(out)
     return _ISA[unit]
 
