@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define FWN_VERSION 310            /* 0.3.10 (round 5): + fwn_flow_run_persist / fwn_flow_persist_* (one launch per small-M flow), fwn_model_desc.persist_mode
+#define FWN_VERSION 320            /* 0.3.20 (round 6): + fwn_flow_desc.Wts and fwn_tail_stream_bytes / fwn_pack_tail_stream / fwn_tail_stream_rows (the
+                                    * register-streamed tail, csrc/tail_rs.h; additive: a 0.3.10 host that zero-fills its descriptors keeps working);
+                                    * fwn_tail_partials / fwn_tail_partials_chained are upper bounds now.  0.3.10 (round 5): + fwn_flow_run_persist / fwn_flow_persist_* (one launch per small-M flow), fwn_model_desc.persist_mode
                                     * (was `reserved`: 0 keeps working), fwn_set_option.  0.3.1: + fwn_gate_clock (additive: a 0.3.0 host keeps working).  0.3.0: fwn_flow_desc gained Wfront3 / kf3 (round 3) and Wgs (round 4), fwn_model_desc
                                     * chain_mode, fwn_block_done_fn returns int; Wskip / Wfinal rows and biases are in
                                     * acc_k_perm order, Wzero's K axis is natural.  A host built against 0.2.0 must be
@@ -141,7 +143,20 @@ typedef struct fwn_flow_desc {
     /* Register-streamed gate (csrc/gate_rs.h; NULL = not packed): Wd[l] and Wc[l] once more in MFMA-fragment order
      * (fwn_pack_gate_stream), read by the gate kernel of the largest row counts (fwn_gate_stream_rows) instead of them. */
     const void* Wgs[FWN_MAX_LAYERS];
+    /* Register-streamed tail (csrc/tail_rs.h; NULL = not packed): Wskip | Wfinal once more in MFMA-fragment order
+     * (fwn_pack_tail_stream), read by the tail kernel of the larger row counts (fwn_tail_stream_rows) instead of them. */
+    const void* Wts;
 } fwn_flow_desc;
+
+/* ---- fragment-order tail weights (round 6, csrc/tail_rs.h; replaces nothing in the reference: a second packing of the
+ * operands of modules.py:175-179 for the kernel that streams them to registers).
+ * fwn_tail_stream_bytes: size of the stream of one flow with L layers, 0 if no kernel is built for that L (L = 2 only);
+ * fwn_pack_tail_stream : Wskip [256][L*256], Wfinal [256][256] (rows in accumulator order, as in fwn_flow_desc) -> out;
+ * fwn_tail_stream_rows : smallest M from which fwn_tail / fwn_tail_chained / fwn_tail_train and the flow and model calls
+ *                        use the stream (one ZeroConv pair tile: Ch <= 32). */
+int64_t fwn_tail_stream_bytes(int L);
+int fwn_pack_tail_stream(const void* Wskip, const void* Wfinal, int L, void* out, void* stream);
+int fwn_tail_stream_rows(void);
 
 /* ---- fragment-order gate weights (round 4, csrc/gate_rs.h; replaces nothing in the reference: a second packing of the
  * operands of modules.py:113-124 for the kernel that streams them to registers).
@@ -204,7 +219,8 @@ int fwn_cond_split(const void* ca, const void* Wc_base, float* P_base, int64_t w
 int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit, int64_t n, void* stream);
 /* K6'+K7+K8 tail: skip sum, final 1x1, ZeroConv1d, affine coupling, ActNorm, log-det partials
  * (modules.py:175-180,51-56; model.py:86-102,124-141,146-161).  o = [L][M][256].
- * partial (forward only, may be NULL) receives fwn_tail_partials(M) partial sums.
+ * partial (forward only, may be NULL) receives AT MOST fwn_tail_partials(M) partial sums (how many depends on the kernel
+ * that serves the flow's packed operands at this M: zero the buffer first, its sum is the log-det).
  * Large M: one register-chained kernel.  M <= 12288 rows: three GEMM launches whose weights are split over the
  * workgroups by output column (a workgroup of the fused kernel streams all 0.4 - 0.5 MB of tail weights itself:
  * 22 - 36 us whatever the row count); they keep S and U in `scratch` = [2][M][256] bf16 (may be NULL for larger M). */

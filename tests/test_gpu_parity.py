@@ -595,6 +595,90 @@ def test_chained_tail_stage_equals_tail_then_front(full_model, blk, b, ti, inver
     assert float((dh != 0).float().mean()) < 0.05
 
 
+def _without_tail_stream(d):
+    d_plain = _lib.FlowDesc.from_buffer_copy(d)
+    d_plain.Wts = None
+    return d_plain
+
+
+@pytest.mark.parametrize("inverse", [0, 1])
+@pytest.mark.parametrize("blk,b,ti", [(0, 26, 1000), (0, 4, 8064), (0, 127, 254), (1, 13, 1000), (1, 8, 4032), (1, 97, 126), (2, 7, 1000),
+                                      (2, 130, 62), (3, 9, 896), (3, 33, 252), (4, 13, 504), (5, 40, 252)])
+def test_register_streamed_tail_equals_the_register_chained_tail_bit_for_bit(full_model, blk, b, ti, inverse):
+    """The register-streamed tail (csrc/tail_rs.h: a wave owns 32 output channels x all rows of the tile, weights streamed to
+    registers in fragment order, S and U exchanged through LDS) against the kernels it replaces (the same call with the
+    flow's Wts = NULL: the register-chained tail_kernel, or the N-split ring GEMM + 64-row chain below 12 288 rows): same
+    MFMA shape, same accumulation order, same epilogue expressions - identical bits in the planes, in S / U / Z as the
+    training step keeps them, in the chained out_b and in the next flow's h0; the log-det partials are the same sum over a
+    different tiling.  Shapes: 128-, 64- and 32-row workgroups (M >= 24 576 / 12 288 / 6 144), Ch = 1 .. 32, clip edges on and
+    off tile boundaries, partial last tiles, both directions."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    L, ch, m = hp.n_layer, 1 << blk, b * ti
+    d, nx = model._packed.flow_descs[blk * hp.n_flow], model._packed.flow_descs[blk * hp.n_flow + 1]
+    assert d.Wts and m >= lib.fwn_tail_stream_rows() and lib.fwn_tail_stream_bytes(L) > 0
+    d0 = _without_tail_stream(d)
+    rng = np.random.default_rng(blk * 1000 + b + inverse)
+    o = torch.from_numpy((rng.random((L, m, 256)) * 0.8).astype(np.float32)).cuda().to(torch.bfloat16)
+    planes = [torch.from_numpy(rng.standard_normal((m, ch)).astype(np.float32)).cuda() for _ in range(2)]
+    st = torch.cuda.current_stream().cuda_stream
+    scratch = torch.empty(2, m, 256, device="cuda", dtype=torch.bfloat16)
+    npart = lib.fwn_tail_partials(m)
+
+    def plain(desc):
+        pa = [q.clone() for q in planes]
+        part = torch.zeros(npart, device="cuda")
+        _lib.check(lib.fwn_tail(C.byref(desc), o.data_ptr(), pa[0].data_ptr(), pa[1].data_ptr(), part.data_ptr(), m, inverse, scratch.data_ptr(), st), "fwn_tail")
+        return pa, part
+
+    (pa1, part1), (pa0, part0) = plain(d), plain(d0)
+    torch.cuda.synchronize()
+    assert torch.equal(pa1[0], pa0[0]), "out_a differs"
+    assert torch.equal(pa1[1], pa0[1]), ("out_b differs", int((pa1[1] != pa0[1]).sum()), torch.nonzero(pa1[1] != pa0[1])[:4].tolist())
+    if not inverse:
+        s1, s0 = float(part1.double().sum()), float(part0.double().sum())
+        assert abs(s1 - s0) <= 1e-5 * abs(s0) + 1e-3, (s1, s0)
+        # the training form keeps S, U, Z
+        outs = []
+        for desc in (d, d0):
+            pb = [q.clone() for q in planes]
+            part = torch.zeros(npart, device="cuda")
+            S = torch.full((m + 2, 256), 7.0, device="cuda", dtype=torch.bfloat16)       # two guard rows behind each matrix
+            U = torch.full((m + 2, 256), 7.0, device="cuda", dtype=torch.bfloat16)
+            Z = torch.full((m + 2, 2 * ch), 7.0, device="cuda", dtype=torch.float32)
+            _lib.check(lib.fwn_tail_train(C.byref(desc), o.data_ptr(), m * 256, pb[0].data_ptr(), pb[1].data_ptr(), part.data_ptr(), m,
+                                          S.data_ptr(), U.data_ptr(), Z.data_ptr(), st), "fwn_tail_train")
+            outs.append((pb, S, U, Z))
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(outs[0][0][k], pa0[k]) and torch.equal(outs[1][0][k], pa0[k])
+        for k, name in ((1, "S"), (2, "U"), (3, "Z")):
+            assert bool((outs[0][k][m:] == 7.0).all()), name + ": the kernel wrote past row M"
+            assert torch.equal(outs[0][k], outs[1][k]), (name, int((outs[0][k] != outs[1][k]).sum()))
+    # chained: out_b to a third buffer, and (Ch <= 8) the next flow's front conv in the same launch
+    if lib.fwn_tail_can_chain(C.byref(d), m, 1 if ch <= 8 else 0):
+        res = []
+        for desc in (d, d0):
+            pb = [q.clone() for q in planes]
+            xb_out = torch.full((m, ch), 7.0, device="cuda")
+            h_new = torch.full((m + 2, 256), 9.0, device="cuda", dtype=torch.bfloat16)
+            part = torch.zeros(lib.fwn_tail_partials_chained(m, ch, 1), device="cuda")
+            _lib.check(lib.fwn_tail_chained(C.byref(desc), C.byref(nx) if ch <= 8 else None, o.data_ptr(), pb[0].data_ptr(), pb[1].data_ptr(),
+                                            xb_out.data_ptr(), h_new.data_ptr() if ch <= 8 else None, part.data_ptr(), m, ti, inverse,
+                                            scratch.data_ptr(), st), "fwn_tail_chained")
+            res.append((pb, xb_out, h_new, part))
+        torch.cuda.synchronize()
+        assert torch.equal(res[0][0][1], planes[1]), "xb must stay untouched when out_b goes elsewhere"
+        assert torch.equal(res[0][0][0], pa0[0]) and torch.equal(res[0][1], pa0[1]), "chained out_a / out_b differ from the plain tail"
+        assert torch.equal(res[1][1], pa0[1])
+        if ch <= 8:
+            assert bool((res[0][2][m:] == 9.0).all()), "h0: the kernel wrote past row M"
+            assert torch.equal(res[0][2], res[1][2]), ("h0 of the next flow differs", int((res[0][2] != res[1][2]).sum()))
+        if not inverse:
+            s1, s0 = float(res[0][3].double().sum()), float(res[1][3].double().sum())
+            assert abs(s1 - s0) <= 1e-5 * abs(s0) + 1e-3, (s1, s0)
+
+
 FLOW_CASES = [(0, 13, 1000), (0, 26, 1000), (1, 7, 1000), (3, 9, 700), (5, 4, 200), (7, 3, 70)]
 
 

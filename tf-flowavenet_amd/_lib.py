@@ -32,6 +32,7 @@ class FlowDesc(C.Structure):
         ("an", vp),
         ("Wd8", vp * FWN_MAX_LAYERS), ("wd8_exp", i32 * FWN_MAX_LAYERS),
         ("Wfront3", vp), ("kf3", i32), ("reserved", i32), ("Wgs", vp * FWN_MAX_LAYERS),
+        ("Wts", vp),
     ]
 
 
@@ -155,6 +156,9 @@ SIGNATURES = {
     "fwn_gate_stream_bytes": (i64, [C.c_int]),
     "fwn_pack_gate_stream": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_gate_stream_rows": (C.c_int, []),
+    "fwn_tail_stream_bytes": (i64, [C.c_int]),
+    "fwn_pack_tail_stream": (C.c_int, [vp, vp, C.c_int, vp, vp]),
+    "fwn_tail_stream_rows": (C.c_int, []),
     "fwn_gate_clock": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_gate_fp8_supported": (C.c_int, [C.c_int, C.c_int]),
     "fwn_gate_fp8": (C.c_int, [C.POINTER(FlowDesc), C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]),

@@ -147,6 +147,8 @@ static int check_desc(const fwn_flow_desc* d) {
     for (int l = 0; l < d->L; ++l)
         REQUIRE(!d->Wgs[l] || (ALIGNED16(d->Wgs[l]) && fwn_gate_stream_size(d->cin) != 0),
                 "flow desc: Wgs[%d] given but no register-streamed gate kernel exists for cin = %d (or misaligned)", l, d->cin);
+    REQUIRE(!d->Wts || (ALIGNED16(d->Wts) && fwn_tail_stream_size(d->L) != 0),
+            "flow desc: Wts given but no register-streamed tail kernel exists for L = %d (or misaligned)", d->L);
     if (d->Wfront3)
         REQUIRE(d->Ch <= 8 && d->kf3 == (6 * d->Ch + 15) / 16 * 16 && ALIGNED16(d->Wfront3),
                 "flow desc: Wfront3 needs Ch <= 8 and kf3 = 6 Ch rounded up to 16 (Ch %d, kf3 %d)", d->Ch, d->kf3);
@@ -295,16 +297,29 @@ int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit
     return check_launch("fwn_cond_reduce");
 }
 
+// 32-row tiles per workgroup of the register-streamed tail when that kernel serves flow d at M rows, else 0
+static int desc_rs_mt(const fwn_flow_desc* d, int M) { return fwn_tail_rs_mt(M, d->L, d->Ch, d->npt, d->Wts != nullptr); }
+
+int64_t fwn_tail_stream_bytes(int L) { return L > 0 ? (int64_t)fwn_tail_stream_size(L) : 0; }
+int fwn_tail_stream_rows(void) { return fwn_tail_stream_min_rows(); }
+int fwn_pack_tail_stream(const void* Wskip, const void* Wfinal, int L, void* out, void* stream) {
+    REQUIRE(Wskip && Wfinal && out, "fwn_pack_tail_stream: bad argument");
+    REQUIRE(fwn_tail_stream_size(L) != 0, "fwn_pack_tail_stream: no register-streamed tail kernel for L = %d", L);
+    REQUIRE(ALIGNED16(Wskip) && ALIGNED16(Wfinal) && ALIGNED16(out), "fwn_pack_tail_stream: buffers must be 16-byte aligned");
+    fwn_launch_tail_stream_pack(Wskip, Wfinal, out, (hipStream_t)stream);
+    return check_launch("fwn_pack_tail_stream");
+}
+
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
              int inverse, void* scratch, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     REQUIRE(o && xa && xb && M > 0, "fwn_tail: bad argument");
-    REQUIRE(!fwn_tail_is_split(M) || scratch, "fwn_tail: M=%d runs the N-split tail: pass scratch [2][M][256] bf16", M);
+    REQUIRE(!fwn_tail_is_split(M) || scratch || desc_rs_mt(d, M), "fwn_tail: M=%d runs the N-split tail: pass scratch [2][M][256] bf16", M);
     REQUIRE(!scratch || ALIGNED16(scratch), "fwn_tail: scratch must be 16-byte aligned");
     fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
                     d->ezero, d->an, xa, xb, partial, M, d->Ch, d->npt, inverse, scratch,
-                    scratch ? (char*)scratch + (size_t)M * 512 : nullptr, nullptr, (hipStream_t)stream);
+                    scratch ? (char*)scratch + (size_t)M * 512 : nullptr, nullptr, d->Wts, (hipStream_t)stream);
     return check_launch("fwn_tail");
 }
 
@@ -312,7 +327,15 @@ int fwn_tail_can_chain(const fwn_flow_desc* d, int M, int with_front) {
     if (!d || M <= 0 || !fwn_tail_chain_xb_out(M, d->npt)) return 0;
     return with_front ? (fwn_tail_chain_front(M, d->Ch, d->npt) ? 1 : 0) : 1;
 }
-int fwn_tail_partials_chained(int M, int Ch, int with_front) { return M > 0 ? fwn_tail_npartials_chain(M, Ch, with_front != 0) : 0; }
+// the public counts are upper bounds over the kernels that may serve the shape (which one runs depends on the flow's packed
+// operands): callers zero the buffer, a launch writes its first n slots
+static int tail_partials_bound(int M, int Ch, int front) {
+    int n = fwn_tail_npartials_chain(M, Ch, front, 0);
+    const int mt = fwn_tail_rs_mt(M, 2, 1, 1, true);
+    if (mt) { const int b = fwn_tail_npartials_chain(M, Ch, front, mt); n = b > n ? b : n; }
+    return n;
+}
+int fwn_tail_partials_chained(int M, int Ch, int with_front) { return M > 0 ? tail_partials_bound(M, Ch, with_front != 0) : 0; }
 int fwn_tail_chained(const fwn_flow_desc* d, const fwn_flow_desc* next, const void* o, float* xa, const float* xb, float* xb_out,
                      void* h0_next, float* partial, int M, int Ti, int inverse, void* scratch, void* stream) {
     int rc = check_desc(d);
@@ -322,7 +345,7 @@ int fwn_tail_chained(const fwn_flow_desc* d, const fwn_flow_desc* next, const vo
     REQUIRE(fwn_tail_can_chain(d, M, next != nullptr), "fwn_tail_chained: the tail at M=%d, Ch=%d cannot chain%s", M, d->Ch, next ? " a front conv" : "");
     REQUIRE(!next || (h0_next && ALIGNED16(h0_next) && next->Wfront3 && next->kf3 > 0 && next->Ch == d->Ch),
             "fwn_tail_chained: next needs Wfront3 / kf3, the same Ch, and h0_next");
-    REQUIRE(!fwn_tail_is_split(M) || scratch, "fwn_tail_chained: M=%d runs the N-split tail: pass scratch [2][M][256] bf16", M);
+    REQUIRE(!fwn_tail_is_split(M) || scratch || desc_rs_mt(d, M), "fwn_tail_chained: M=%d runs the N-split tail: pass scratch [2][M][256] bf16", M);
     fwn_tail_chain tc;
     memset(&tc, 0, sizeof(tc));
     tc.xb_out = xb_out;
@@ -334,7 +357,7 @@ int fwn_tail_chained(const fwn_flow_desc* d, const fwn_flow_desc* next, const vo
     // (xb is read only; the launcher's xb parameter is not written when xb_out is given)
     fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero, d->ezero, d->an, xa,
                     const_cast<float*>(xb), inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, scratch,
-                    scratch ? (char*)scratch + (size_t)M * 512 : nullptr, &tc, (hipStream_t)stream);
+                    scratch ? (char*)scratch + (size_t)M * 512 : nullptr, &tc, d->Wts, (hipStream_t)stream);
     return check_launch("fwn_tail_chained");
 }
 
@@ -350,11 +373,11 @@ int fwn_tail_train(const fwn_flow_desc* d, const void* o, int64_t o_stride, floa
     memset(&tc, 0, sizeof(tc));
     tc.save_s = save_s; tc.save_u = save_u; tc.save_z = save_z;
     fwn_launch_tail(o, (long)o_stride, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero, d->ezero, d->an, xa, xb,
-                    partial, M, d->Ch, d->npt, 0, nullptr, nullptr, &tc, (hipStream_t)stream);
+                    partial, M, d->Ch, d->npt, 0, nullptr, nullptr, &tc, d->Wts, (hipStream_t)stream);
     return check_launch("fwn_tail_train");
 }
 
-int fwn_tail_partials(int M) { return M > 0 ? fwn_tail_npartials(M) : 0; }
+int fwn_tail_partials(int M) { return M > 0 ? tail_partials_bound(M, 0, 0) : 0; }
 
 // ddi: 0 none, 1 local two-pass init, 2 moments -> reduce callback (may be NULL) -> tables
 // Chain context of one flow inside a whole-model call (NULL: a flow on its own, everything in place).
@@ -404,7 +427,7 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
         if (!inside)
             fwn_launch_front(xa, d->an, d->Wfront, d->Wfront2, d->bfront, h0, h1, M, Ti, d->Ch, d->kfpad, inverse ? 0 : 1, nullptr, st);
         fwn_launch_flow_persist_desc(d, xa, xb, h0, h1, o, P, inverse ? nullptr : partial, sync, M, Ti, inverse, inside, st);
-        if (chain) { chain->h0_next = nullptr; chain->n_partial = fwn_tail_npartials_chain(M, d->Ch, false); }
+        if (chain) { chain->h0_next = nullptr; chain->n_partial = fwn_tail_npartials_chain(M, d->Ch, false, 0); }
         return check_launch("fwn_flow_run_persist");
     }
     void* h8c = h8a;
@@ -440,10 +463,10 @@ static int flow_run_impl(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa
             tc.Wfn = nx->Wfront3; tc.bfn = nx->bfront; tc.an_next = inverse ? nullptr : nx->an; tc.kfn = nx->kf3; tc.Ti = Ti;
             chain->h0_next = hc;
         }
-        chain->n_partial = fwn_tail_npartials_chain(M, d->Ch, tc.h0_next != nullptr);
+        chain->n_partial = fwn_tail_npartials_chain(M, d->Ch, tc.h0_next != nullptr, desc_rs_mt(d, M));
     }
     fwn_launch_tail(o, (long)M * 256, d->L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero,
-                    d->ezero, d->an, xa, xb, inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, hn, hc, chain ? &tc : nullptr, st);
+                    d->ezero, d->an, xa, xb, inverse ? nullptr : partial, M, d->Ch, d->npt, inverse, hn, hc, chain ? &tc : nullptr, d->Wts, st);
     return check_launch("fwn_flow_run");
 }
 
@@ -767,7 +790,7 @@ static int check_model(const fwn_model_desc* m, int64_t B, int64_t T) {
 }
 
 static int tail_partials_max(int M, int Ch) {       // a flow's tail runs plain or chained (overlapping tiles): room for either
-    const int a = fwn_tail_npartials(M), b = fwn_tail_npartials_chain(M, Ch, 1);
+    const int a = tail_partials_bound(M, Ch, 0), b = tail_partials_bound(M, Ch, 1);
     return a > b ? a : b;
 }
 

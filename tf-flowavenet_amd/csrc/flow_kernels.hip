@@ -828,12 +828,13 @@ static bool tail_split_chain(int M) {
 static int tail_chain_rows(int M) { return fwn_tail_is_split(M) ? 64 : fwn_tail_rows(M); }
 int fwn_tail_chain_xb_out(int M, int npt) { return !fwn_tail_is_split(M) || tail_split_chain(M); }
 int fwn_tail_chain_front(int M, int Ch, int npt) { return fwn_tail_chain_xb_out(M, npt) && Ch <= 8 && npt == 1; }
-int fwn_tail_npartials_chain(int M, int Ch, int front) {       // log-det partial slots one tail launch writes
-    if (fwn_tail_is_split(M) && !tail_split_chain(M)) return ((M + 63) / 64) * 8;
-    const int rw = tail_chain_rows(M) - (front ? 2 : 0);      // chained front conv: tiles overlap by one row on either side
+// rs_mt: 32-row tiles per workgroup of the register-streamed tail (tail_rs.h) when that kernel runs the launch (fwn_tail_rs_mt), else 0
+int fwn_tail_npartials_chain(int M, int Ch, int front, int rs_mt) {       // log-det partial slots one tail launch writes
+    if (rs_mt == 0 && fwn_tail_is_split(M) && !tail_split_chain(M)) return ((M + 63) / 64) * 8;
+    const int rw = (rs_mt ? 32 * rs_mt : tail_chain_rows(M)) - (front ? 2 : 0);      // chained front conv: tiles overlap by one row on either side
     return (M + rw - 1) / rw;
 }
-int fwn_tail_npartials(int M) { return fwn_tail_npartials_chain(M, 0, 0); }
+int fwn_tail_npartials(int M, int rs_mt) { return fwn_tail_npartials_chain(M, 0, 0, rs_mt); }
 
 // process-wide developer option (fwn_set_option in api.hip; round 4 read two environment variables on every gate launch)
 int g_fwn_opt_rs_persist = -1;
@@ -1141,7 +1142,7 @@ void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
                      const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,
                      float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse, void* scratch_s,
-                     void* scratch_u, const fwn_tail_chain* chain, hipStream_t st) {
+                     void* scratch_u, const fwn_tail_chain* chain, const void* Wts, hipStream_t st) {
     TailArgs a{(const bf16*)o, (const bf16*)Ws, bs, (const bf16*)Wf, bfin, (const bf16*)Wz, bz, ez, an,
                xa, xb, partial, o_stride, L, M, Ch, npt, inverse};
     const bool front = chain && chain->h0_next;
@@ -1157,6 +1158,11 @@ void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const 
     a.save_s = chain ? (bf16*)chain->save_s : nullptr;
     a.save_u = chain ? (bf16*)chain->save_u : nullptr;
     a.save_z = chain ? chain->save_z : nullptr;
+    // the register-streamed tail (tail_rs.h) wherever the flow's fragment stream is packed and the shape is one of its
+    if (const int mt = fwn_tail_rs_mt(M, L, Ch, npt, Wts != nullptr)) {
+        fwn_launch_tail_rs(a, Wts, mt, st);
+        return;
+    }
 #define TAIL_LAUNCH(NW, D, BK1, WDB, NPT, P1, FRONT)                                                                  \
     hipLaunchKernelGGL((tail_kernel<NW, D, BK1, WDB, NPT, P1, FRONT>),                                                 \
                        dim3((M + 32 * NW - (FRONT ? 2 : 0) - 1) / (32 * NW - (FRONT ? 2 : 0))), dim3(64 * NW), 0, st, a)

@@ -63,7 +63,15 @@ struct fwn_tail_chain {
 void fwn_launch_tail(const void* o, long o_stride, int L, const void* Ws, const float* bs, const void* Wf,
                      const float* bfin, const void* Wz, const float* bz, const float* ez, const float* an,
                      float* xa, float* xb, float* partial, int M, int Ch, int npt, int inverse, void* scratch_s,
-                     void* scratch_u, const fwn_tail_chain* chain, hipStream_t st);
+                     void* scratch_u, const fwn_tail_chain* chain, const void* Wts, hipStream_t st);
+// register-streamed tail (tail_rs.h / tail_rs.hip).  Wts: Wskip | Wfinal in fragment order (fwn_launch_tail_stream_pack) or
+// nullptr; fwn_tail_rs_mt: 32-row tiles per workgroup of that kernel at this shape, 0 = another tail serves it
+struct TailArgs;
+long fwn_tail_stream_size(int L);          // bytes, 0: no kernel for this layer count
+int fwn_tail_stream_min_rows();
+int fwn_tail_rs_mt(int M, int L, int Ch, int npt, bool have_stream);
+void fwn_launch_tail_stream_pack(const void* Ws, const void* Wf, void* out, hipStream_t st);
+void fwn_launch_tail_rs(const TailArgs& a, const void* Wts, int mt, hipStream_t st);
 
 // one flow of the small-M chain as one launch (flow_persist.h)
 struct fwn_flow_desc;
@@ -79,8 +87,9 @@ int fwn_device_cus();            // compute units of the current device (cached 
 
 int fwn_tail_rows(int M);        // rows per fused-tail workgroup
 int fwn_tail_is_split(int M);    // the N-split tail (ring GEMMs; needs [2][M][256] bf16 scratch) serves this M
-int fwn_tail_npartials(int M);   // log-det partial slots a plain (un-chained) tail launch writes
-int fwn_tail_npartials_chain(int M, int Ch, int front);   // ... a chained launch (fwn_tail_chain given; front: h0_next set)
+// rs_mt: fwn_tail_rs_mt of the launch (0: the register-streamed tail does not run it)
+int fwn_tail_npartials(int M, int rs_mt);   // log-det partial slots a plain (un-chained) tail launch writes
+int fwn_tail_npartials_chain(int M, int Ch, int front, int rs_mt);   // ... a chained launch (fwn_tail_chain given; front: h0_next set)
 int fwn_tail_chain_xb_out(int M, int npt);                // whether the tail at this shape can write out_b elsewhere (xb_out)
 int fwn_tail_chain_front(int M, int Ch, int npt);         // ... and can compute the next flow's front conv
 

@@ -211,7 +211,10 @@ void plan(const fwn_train_desc* t, long B, long T, void* ws, Plan& pl) {
             s.s_act = b.take((size_t)m * 256 * 2);
             s.u_act = b.take((size_t)m * 256 * 2);
             s.z = (float*)b.take((size_t)m * 2 * ch * 4);
-            s.nb = fwn_tail_npartials((int)m);          // log-det partial slots of the flow's tail launch
+            {       // log-det partial slots of the flow's tail launch (the register-streamed tail tiles differently: tail_rs.hip)
+                const fwn_flow_desc* fd = &md->flows[i * md->n_flow + j];
+                s.nb = fwn_tail_npartials((int)m, fwn_tail_rs_mt((int)m, fd->L, fd->Ch, fd->npt, fd->Wts != nullptr));
+            }
             npart += s.nb;
         }
     }
@@ -415,7 +418,7 @@ int fwn_train_loss_and_grads(const fwn_train_desc* t, int64_t B_, int64_t T_, co
                 memset(&tc, 0, sizeof(tc));
                 tc.save_s = s.s_act; tc.save_u = s.u_act; tc.save_z = s.z;
                 fwn_launch_tail(s.o[0], o_stride, L, d->Wskip, d->bskip, d->Wfinal, d->bfinal, d->Wzero, d->bzero, d->ezero, d->an, xa, xb, s.part,
-                                (int)m, ch, d->npt, 0, nullptr, nullptr, &tc, st);
+                                (int)m, ch, d->npt, 0, nullptr, nullptr, &tc, d->Wts, st);
             }
             p ^= 1;
         }

@@ -604,6 +604,14 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
             wfin = bf16_zeros(FILTER, FILTER)
             pack(wp + "/Conv_final", ident256, accperm, FILTER, FILTER, wfin, FILTER)
             d.Wfinal = wfin.data_ptr()
+            # Wskip | Wfinal once more in MFMA-fragment order for the register-streamed tail (csrc/tail_rs.h): one ZeroConv pair
+            # tile only, and - like the gate's stream - only without a PackPlan (a plan re-packs the weights every step)
+            ts_bytes = int(lib.fwn_tail_stream_bytes(L)) if (plan is None and npt == 1) else 0
+            if ts_bytes:
+                wts = pm.keep(torch.empty(ts_bytes, dtype=torch.uint8, device=dev))
+                pm.weight_bytes += ts_bytes
+                _lib.check(lib.fwn_pack_tail_stream(wskip.data_ptr(), wfin.data_ptr(), L, wts.data_ptr(), stream), "fwn_pack_tail_stream")
+                d.Wts = wts.data_ptr()
             put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), lambda wp=wp: np.asarray(hostp[wp + "/Conv_final/bias"]).reshape(-1)[accperm_host],
                 dict(terms=[(wp + "/Conv_final/bias", accperm_host)]))
 

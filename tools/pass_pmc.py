@@ -31,7 +31,7 @@ def passes_of(rows):
             continue
         cur.append((base, val))
         if base.startswith("prior_kernel") or base.startswith("merge_kernel"):
-            closes = sum(1 for n, _ in cur if n.startswith("tail_kernel") or "TailZeroProb" in n or n.startswith("flow_persist_kernel"))
+            closes = sum(1 for n, _ in cur if n.startswith("tail_kernel") or n.startswith("tail_rs_kernel") or "TailZeroProb" in n or n.startswith("flow_persist_kernel"))
             if closes == 48 and not any(n.startswith("ddi_") for n, _ in cur):
                 out["fwd" if base.startswith("prior_kernel") else "inv"].append(sum(v for _, v in cur))
             cur = None

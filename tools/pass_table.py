@@ -35,7 +35,7 @@ def stage_of(name):
         return "gate"
     if "ResProb" in name:
         return "res"
-    if name.startswith("tail_kernel") or "TailLinProb" in name or "TailZeroProb" in name:
+    if name.startswith("tail_kernel") or name.startswith("tail_rs_kernel") or "TailLinProb" in name or "TailZeroProb" in name:
         return "tail"
     if name.startswith("cond_"):
         return "cond"
@@ -76,7 +76,7 @@ def main():
     for direction in ("fwd", "inv"):
         sel = [p for d, p in passes if d == direction]
         # only whole-model passes without the data-dependent init: 48 coupling launches, no ddi kernel
-        closes = lambda n: n.startswith("tail_kernel") or "TailZeroProb" in n or n.startswith("flow_persist_kernel")
+        closes = lambda n: n.startswith("tail_kernel") or n.startswith("tail_rs_kernel") or "TailZeroProb" in n or n.startswith("flow_persist_kernel")
         good = []
         for p in sel:
             if sum(1 for _, _, n in p if closes(n)) == N_BLOCK * N_FLOW and not any(n.startswith("ddi_") for _, _, n in p):
