@@ -602,7 +602,7 @@ def _without_tail_stream(d):
 
 
 @pytest.mark.parametrize("inverse", [0, 1])
-@pytest.mark.parametrize("blk,b,ti", [(0, 26, 1000), (0, 4, 8064), (0, 127, 254), (1, 13, 1000), (1, 8, 4032), (1, 97, 126), (2, 7, 1000),
+@pytest.mark.parametrize("blk,b,ti", [(0, 26, 1000), (0, 4, 8064), (0, 127, 254), (0, 49, 1000), (1, 13, 1000), (1, 8, 4032), (1, 97, 126), (2, 7, 1000),
                                       (2, 130, 62), (3, 9, 896), (3, 33, 252), (4, 13, 504), (5, 40, 252)])
 def test_register_streamed_tail_equals_the_register_chained_tail_bit_for_bit(full_model, blk, b, ti, inverse):
     """The register-streamed tail (csrc/tail_rs.h: a wave owns 32 output channels x all rows of the tile, weights streamed to
@@ -610,13 +610,13 @@ def test_register_streamed_tail_equals_the_register_chained_tail_bit_for_bit(ful
     flow's Wts = NULL: the register-chained tail_kernel, or the N-split ring GEMM + 64-row chain below 12 288 rows): same
     MFMA shape, same accumulation order, same epilogue expressions - identical bits in the planes, in S / U / Z as the
     training step keeps them, in the chained out_b and in the next flow's h0; the log-det partials are the same sum over a
-    different tiling.  Shapes: 128-, 64- and 32-row workgroups (M >= 24 576 / 12 288 / 6 144), Ch = 1 .. 32, clip edges on and
-    off tile boundaries, partial last tiles, both directions."""
+    different tiling.  Shapes: 128- and 64-row workgroups (M >= 12 288 / 6 144), Ch = 1 .. 32, clip edges on and off tile
+    boundaries, partial last tiles, both directions."""
     hp, model, _, _, _ = full_model
     lib = _lib.load()
     L, ch, m = hp.n_layer, 1 << blk, b * ti
     d, nx = model._packed.flow_descs[blk * hp.n_flow], model._packed.flow_descs[blk * hp.n_flow + 1]
-    assert d.Wts and m >= lib.fwn_tail_stream_rows() and lib.fwn_tail_stream_bytes(L) > 0
+    assert d.Wts and lib.fwn_tail_stream_rows() <= m < 49152 and lib.fwn_tail_stream_bytes(L) > 0
     d0 = _without_tail_stream(d)
     rng = np.random.default_rng(blk * 1000 + b + inverse)
     o = torch.from_numpy((rng.random((L, m, 256)) * 0.8).astype(np.float32)).cuda().to(torch.bfloat16)

@@ -50,7 +50,7 @@ __host__ __device__ constexpr int trs_default_r(int mt) { return mt >= 4 ? 8 : 1
 
 // Vector-memory operations a wave has issued AFTER a given one at the point where it waits for that one (every wave of the
 // workgroup issues the same sequence):
-//   prologue : one constant piece, the o pieces of items 0 .. 2 (PP each), W(0 .. R-2)
+//   prologue : one constant piece, then W(0 .. R-2) with the o pieces of item k / 2 (PP each) in front of W(k), k = 0, 2, 4
 //   phase 1  : k-step g = 0 .. 31 (item g / 4): [wait W(g)] [g % 4 == 0: wait own pieces of the item, barrier]; behind MFMA
 //              slot j < PP of an item's first k-step piece j of item + 3; behind slot WSLOT W(g + R - 1)
 //   S        : SAVE: 2 MT stores; barrier; 4 Wz pieces; 4 plane loads (the coupling's in_b values, registers 0 - 3)
@@ -72,9 +72,11 @@ struct TrsCount {
 #define T_QK(g) do { if (!done && qk == 0 && qa == (g)) { result = count; done = true; } } while (0)
 #define T_QB(i) do { if (!done && qk == 1 && qa == (i)) { result = count; done = true; } } while (0)
         T_OP();
-        for (int i = 0; i < LA; ++i)
-            for (int j = 0; j < PP; ++j) T_P1(i, j);
-        for (int k = 0; k < R - 1; ++k) T_W(k);
+        for (int k = 0; k < R - 1; ++k) {
+            if (k % 2 == 0 && k / 2 < LA)
+                for (int j = 0; j < PP; ++j) T_P1(k / 2, j);
+            T_W(k);
+        }
         for (int g = 0; g < 32; ++g) {
             T_QK(g);
             if ((g & 3) == 0) T_QB(g >> 2);
@@ -102,10 +104,17 @@ struct TrsCount {
 
 // bf16 pack of four accumulator registers (ReLU applied): two dwords
 typedef __attribute__((ext_vector_type(2))) __bf16 trs_bf16x2;
+// ReLU AFTER the rounding, on the packed pair, as ONE v_pk_max_i16 against zero: a negative bf16 is a negative int16, -0 the
+// most negative one; a value that rounds to zero is zero either way - the same bits as (bf16)fmaxf(x, 0) for every x that is
+// not a NaN.  fmaxf on a register fresh from an MFMA costs a canonicalising v_max_f32 besides the real one: 128 + 32 VALU
+// instructions per parked tile set against 32 + 32 here, at two waves per SIMD (the exchange was VALU-bound).
+typedef __attribute__((ext_vector_type(2))) short trs_i16x2;
+__device__ __forceinline__ uint32_t trs_relu_pk(f32x2 v) {
+    const trs_i16x2 w = __builtin_bit_cast(trs_i16x2, __builtin_convertvector(v, trs_bf16x2));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(w, trs_i16x2{0, 0}));
+}
 __device__ __forceinline__ uint2 trs_pack4_relu(const f32x16& a, int q) {
-    const f32x2 lo = {fmaxf(a[4 * q], 0.0f), fmaxf(a[4 * q + 1], 0.0f)}, hi = {fmaxf(a[4 * q + 2], 0.0f), fmaxf(a[4 * q + 3], 0.0f)};
-    return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, trs_bf16x2)),
-                      __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, trs_bf16x2)));
+    return make_uint2(trs_relu_pk(f32x2{a[4 * q], a[4 * q + 1]}), trs_relu_pk(f32x2{a[4 * q + 2], a[4 * q + 3]}));
 }
 // A lane's four packs of one time tile (channels 8 q + 4 lh .. + 3 of its row, q = 0 .. 3) as two 16-byte pieces: one
 // v_permlane32_swap per dword (guide T21) gives the lower half-wave channels 16 p .. + 7 and the upper one 16 p + 8 .. + 15.
@@ -117,6 +126,24 @@ __device__ __forceinline__ void trs_store_row32(const uint2 (&pk)[4], srd_t dst,
         const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
         __builtin_amdgcn_raw_buffer_store_b128(out, dst, voff, p * 32, 0);
     }
+}
+
+// LDS-DMA piece (64 lanes x 16 bytes -> LDS at the wave-uniform byte address lds_addr + lane * 16) issued from inline asm.
+// Through the builtin (buf_load16_lds) hipcc knows that LDS writes are in flight and puts an s_waitcnt vmcnt(0) in front of the
+// next ds_read / ds_write it emits (it cannot tell that the access is to another slot): in this kernel that drained the whole
+// prologue - two more o slices and R - 1 weight fragments - in front of the first k-step, and the Wz image in front of phase
+// 2 (stamps: 3.6 k cycles at barrier 0).  Issued from asm the pieces are invisible to that pass; every wait for them is one of
+// TrsCount's.  M0 (the LDS address) is compiler-reserved: saved and restored inside the statement (guide section 5.7).
+__device__ __forceinline__ void trs_dma16(u32x4 srd, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(srd), "s"(lds_addr) : "memory");
+}
+// raw buffer descriptor (stride 0, range check on the byte offset) in SGPRs an asm statement can name
+__device__ __forceinline__ u32x4 trs_srd(const void* p, uint32_t bytes) {
+    const unsigned long long b = (unsigned long long)(uintptr_t)p;
+    return u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)) & 0xffffu,
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
 }
 
 // one dword per lane, hidden from hipcc's wait bookkeeping like rs_wload (the caller counts vmcnt)
@@ -148,6 +175,7 @@ __global__ __launch_bounds__(512, (MT <= 2 ? 4 : 2)) void tail_rs_kernel(TailArg
     constexpr int T_FLOATS = FRONT ? BM * 8 : 0;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[A_BYTES + B_BYTES + CST * 4 + T_FLOATS * 4 + 64];
     unsigned char* const lA = lds;
+    const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t)lds);   // LDS byte address of the array (0: the kernel's only LDS object)
     unsigned char* const lB = lds + A_BYTES;
     float* const cst = (float*)(lds + A_BYTES + B_BYTES);
     float* const Tt = cst + CST;
@@ -172,12 +200,12 @@ __global__ __launch_bounds__(512, (MT <= 2 ? 4 : 2)) void tail_rs_kernel(TailArg
         else if (wave == 4) { src = a.an; bytes = (uint32_t)Ch * 32u; }
         else if (wave == 5 && front) { src = a.bfn; bytes = 1024u; }
         else if (wave == 6 && front && a.an_next) { src = a.an_next; bytes = (uint32_t)Ch * 32u; }
-        buf_load16_lds(make_srd(src, bytes), (uint32_t)lane * 16u, (unsigned char*)(cst + 256 * wave));
+        trs_dma16(trs_srd(src, bytes), (uint32_t)lane * 16u, lds0 + (uint32_t)(A_BYTES + B_BYTES + 1024 * wave));
     }
 
     // ---- o slices: item i = (layer i / 4, columns 64 (i % 4) ..), image [rows][64] in slot i % 4; piece j of this wave =
     // image rows 8 (wave + 8 j) .. + 7 (rows past the tile or the matrix: out of range = zeros)
-    const srd_t srd_o = make_srd(a.o, (uint32_t)(((size_t)(a.L - 1) * a.o_stride + (size_t)M * FWN_HID) * 2));
+    const u32x4 srd_o = trs_srd(a.o, (uint32_t)(((size_t)(a.L - 1) * a.o_stride + (size_t)M * FWN_HID) * 2));
     auto issue_piece = [&](int item, int j) {
         const int pi = wave + 8 * j;
         const int jrow = 8 * pi + (lane >> 3);
@@ -185,7 +213,7 @@ __global__ __launch_bounds__(512, (MT <= 2 ? 4 : 2)) void tail_rs_kernel(TailArg
         const int gr = g0 + jrow;
         const bool ok = (jrow < BM) & ((unsigned)gr < (unsigned)M);
         const uint32_t off = (uint32_t)((item >> 2) * a.o_stride + (long)gr * FWN_HID + (item & 3) * 64 + c * 8) * 2u;
-        buf_load16_lds(srd_o, ok ? off : FWN_OOB, lA + (item & 3) * SLOT + pi * 1024);
+        trs_dma16(srd_o, ok ? off : FWN_OOB, lds0 + (uint32_t)((item & 3) * SLOT + (wave + 8 * j) * 1024));
     };
 
     // ---- this wave's weight stream: k-step g -> ring stage g % R; g >= 48: the next flow's front weights [256][kfn]
@@ -214,11 +242,17 @@ __global__ __launch_bounds__(512, (MT <= 2 ? 4 : 2)) void tail_rs_kernel(TailArg
         else rs_wwait<C::wait_kstep(g)>(wq[g % R]);
     };
 
+    // prologue order: what the first k-steps need first - slice 0 and two weight fragments, then the other slices between the
+    // rest of the ring's first R - 1 fragments (TrsCount::walk mirrors it)
+    rs_static_for<R - 1>([&](auto G) {
+        constexpr int g = decltype(G)::value;
+        if constexpr (g % 2 == 0 && g / 2 < LA) {
 #pragma unroll
-    for (int i = 0; i < LA; ++i)
-#pragma unroll
-        for (int j = 0; j < PP; ++j) issue_piece(i, j);
-    rs_static_for<R - 1>([&](auto G) { issue_w(G); });
+            for (int j = 0; j < PP; ++j) issue_piece(g / 2, j);
+        }
+        issue_w(G);
+    });
+    static_assert((R - 2) / 2 >= LA - 1, "the prologue issues the first LA slices among its weight loads");
     TRS_STAMP(1);
 
     // bias tables are in accumulator order (packing.acc_k_perm swaps bits 2 and 3 of the channel index): register r of this
@@ -297,12 +331,12 @@ __global__ __launch_bounds__(512, (MT <= 2 ? 4 : 2)) void tail_rs_kernel(TailArg
     TRS_STAMP(4);
     // ---- the ZeroConv weights [64][256] as 4 sub-tiles [64][64] of 8 KB into region A (tail_chain.h's image): 4 pieces per wave
     {
-        const srd_t srd_z = make_srd(a.Wz, 64u * 256u * 2u);
+        const u32x4 srd_z = trs_srd(a.Wz, 64u * 256u * 2u);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int pi = wave + 8 * j, q = pi >> 3;
             const int r = (pi & 7) * 8 + (lane >> 3);
-            buf_load16_lds(srd_z, (uint32_t)(r * FWN_HID + q * 64 + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2u, lA + pi * 1024);
+            trs_dma16(srd_z, (uint32_t)(r * FWN_HID + q * 64 + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2u, lds0 + (uint32_t)(pi * 1024));
         }
     }
     // ---- the coupling's in_b values of the tile waves' rows (accumulator registers 0 - 3: channels 4 lh .. + 3, all there are for

@@ -9,17 +9,28 @@ long fwn_tail_stream_size(int L) { return L == 2 ? 8L * 48 * 1024 : 0; }
 #ifndef FWN_TRS_MIN_ROWS
 #define FWN_TRS_MIN_ROWS 6144        // fewer rows: the N-split ring GEMMs / the one-launch flow (flow_kernels.hip, flow_persist.h)
 #endif
+// Tile height: the larger the better down to a few dozen workgroups - a workgroup streams all 384 KB of Wskip | Wfinal from L2
+// whatever its rows (at ~64 B / clock / CU that alone is 6 k cycles), so smaller tiles buy occupancy with L2 traffic and lose
+// (tools/bench_tail_rs.hip, us per launch: 16 128 rows 17.1 as 126 workgroups of 128 rows / 19.0 as 252 of 64; 8 064 rows
+// 11.8 as 126 of 64 / 14.6 as 252 of 32).
 #ifndef FWN_TRS_ROWS128
-#define FWN_TRS_ROWS128 24576        // from here on 128-row workgroups (one per CU: 140 KB of LDS); below 64-row ones (two per CU) ...
+#define FWN_TRS_ROWS128 12288        // from here on 128-row workgroups (one per CU: 140 KB of LDS)
 #endif
 #ifndef FWN_TRS_ROWS64
-#define FWN_TRS_ROWS64 12288         // ... and below this 32-row ones, so that every CU still has a workgroup
+#define FWN_TRS_ROWS64 6144          // 64-row workgroups down to here (32-row ones below: not selected by default)
+#endif
+// From 49 152 rows on (block 0 of the 8-clip pass: 504 workgroups of 128 rows = two rounds on 256 CUs) the 256-row register-chained
+// tail_kernel (252 workgroups, one round, weights read once per 256 rows) is still ahead in situ: 38 against 41 us per launch
+// (rocprofv3 per-block tables of the same box), although the stand-alone harness has this kernel ahead (42.8 against 46).
+#ifndef FWN_TRS_MAX_ROWS
+#define FWN_TRS_MAX_ROWS 49152
 #endif
 int fwn_tail_stream_min_rows() { return FWN_TUNE(FWN_TRS_MIN_ROWS, FWN_TRS_MIN_ROWS); }
 
 // 32-row time tiles per workgroup of the register-streamed tail at this shape, 0: it does not serve the shape
 int fwn_tail_rs_mt(int M, int L, int Ch, int npt, bool have_stream) {
-    if (!have_stream || L != 2 || npt != 1 || Ch > 32 || M < fwn_tail_stream_min_rows() || !FWN_TUNE(FWN_TRS, 1)) return 0;
+    if (!have_stream || L != 2 || npt != 1 || Ch > 32 || M < fwn_tail_stream_min_rows() || M >= FWN_TUNE(FWN_TRS_MAX_ROWS, FWN_TRS_MAX_ROWS) ||
+        !FWN_TUNE(FWN_TRS, 1)) return 0;
     if (M >= FWN_TUNE(FWN_TRS_ROWS128, FWN_TRS_ROWS128)) return 4;
     if (M >= FWN_TUNE(FWN_TRS_ROWS64, FWN_TRS_ROWS64)) return 2;
     return 1;
