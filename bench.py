@@ -302,17 +302,8 @@ def one_launch_twin(model, hp, params, dev):
     p2 = dict(params)
     for k, v in model.export_actnorm().items():
         p2[k] = np.asarray(v, dtype=np.float32).reshape(np.asarray(p2[k]).shape)
-    old = os.environ.get("FWN_PERSIST_MODE")
-    try:
-        os.environ["FWN_PERSIST_MODE"] = "1"
-        plain = FloWaveNet(hp, device=dev).load_params(p2)
-        os.environ["FWN_PERSIST_MODE"] = "2"
-        one = FloWaveNet(hp, device=dev).load_params(p2)
-    finally:
-        if old is None:
-            del os.environ["FWN_PERSIST_MODE"]
-        else:
-            os.environ["FWN_PERSIST_MODE"] = old
+    plain = FloWaveNet(hp, device=dev, persist_mode=1).load_params(p2)
+    one = FloWaveNet(hp, device=dev, persist_mode=2).load_params(p2)
     return one, plain
 
 
@@ -576,6 +567,8 @@ def main():
     ap.add_argument("--samples", type=int, default=16128, help="samples per clip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cond-mode", type=int, default=0)
+    ap.add_argument("--chain-mode", type=int, default=0, help="fwn_model_desc.chain_mode (developer A/B: 1 = every flow on its own)")
+    ap.add_argument("--persist-mode", type=int, default=0, help="fwn_model_desc.persist_mode (0 default, 1 no one-launch flows, 2 wherever they exist)")
     ap.add_argument("--serial", action="store_true", help="forward and inverse on one stream (no overlap)")
     ap.add_argument("--lanes", type=int, default=7,
                     help="HIP streams per direction; successive (independent) steps rotate over them")
@@ -641,7 +634,8 @@ def main():
     hp = default_hparams()
     b, t = args.batch, args.samples
     params = W.synthetic_params(hp, 1234)
-    model = FloWaveNet(hp, init=True, device=dev, cond_mode=args.cond_mode).load_params(params)
+    model = FloWaveNet(hp, init=True, device=dev, cond_mode=args.cond_mode, chain_mode=args.chain_mode,
+                       persist_mode=args.persist_mode).load_params(params)
     inp = W.synthetic_inputs(hp, b, t)
     # each rank works on its own shard of the global batch (different clips per rank)
     roll = rank * 997

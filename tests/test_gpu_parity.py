@@ -763,9 +763,7 @@ def test_chained_flows_agree_with_every_flow_on_its_own(full_model, monkeypatch)
     params = dict(W.synthetic_params(hp, 1234))
     for k, v in model.export_actnorm().items():          # the tables the data-dependent init of `full_model` produced
         params[k] = np.asarray(v, dtype=np.float32).reshape(params[k].shape)
-    monkeypatch.setenv("FWN_CHAIN_MODE", "1")
-    plain = FloWaveNet(hp).load_params(params)
-    monkeypatch.delenv("FWN_CHAIN_MODE")
+    plain = FloWaveNet(hp, chain_mode=1).load_params(params)
     assert plain._packed.model_desc.chain_mode == 1 and model._packed.model_desc.chain_mode == 0
     for xx, cc, zz in ((x, c, z), (x[2:3], c[2:3], z[2:3])):
         lp0, ld0, zp0 = model.forward(xx, cc, return_z=True)
@@ -788,11 +786,8 @@ def _persist_twins(hp, model, monkeypatch, with_default=False):
     params = dict(W.synthetic_params(hp, 1234))
     for k, v in model.export_actnorm().items():
         params[k] = np.asarray(v, dtype=np.float32).reshape(params[k].shape)
-    monkeypatch.setenv("FWN_PERSIST_MODE", "1")
-    plain = FloWaveNet(hp).load_params(params)
-    monkeypatch.setenv("FWN_PERSIST_MODE", "2")
-    one = FloWaveNet(hp).load_params(params)
-    monkeypatch.delenv("FWN_PERSIST_MODE")
+    plain = FloWaveNet(hp, persist_mode=1).load_params(params)
+    one = FloWaveNet(hp, persist_mode=2).load_params(params)
     assert plain._packed.model_desc.persist_mode == 1 and one._packed.model_desc.persist_mode == 2
     if with_default:
         auto = FloWaveNet(hp).load_params(params)
@@ -839,11 +834,8 @@ def test_one_launch_flows_on_other_model_shapes(monkeypatch, variant):
     else:
         hp, b, t = default_hparams().replace(n_block=5, n_flow=2, n_layer=3), 2, 4096
     params = W.synthetic_params(hp, 99, actnorm="random")
-    monkeypatch.setenv("FWN_PERSIST_MODE", "1")
-    plain = FloWaveNet(hp).load_params(params)
-    monkeypatch.setenv("FWN_PERSIST_MODE", "2")
-    one = FloWaveNet(hp).load_params(params)
-    monkeypatch.delenv("FWN_PERSIST_MODE")
+    plain = FloWaveNet(hp, persist_mode=1).load_params(params)
+    one = FloWaveNet(hp, persist_mode=2).load_params(params)
     inp = W.synthetic_inputs(hp, b, t)
     x, c, z = dev(inp["x"]), dev(inp["c"]), dev(inp["z"])
     for _ in range(2):

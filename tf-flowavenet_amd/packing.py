@@ -350,7 +350,7 @@ class PackedModel:
 
 
 def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | None" = None,
-               gate_fp8: bool = False) -> PackedModel:
+               gate_fp8: bool = False, persist_mode: int = 0, chain_mode: int = 0) -> PackedModel:
     """Upload ``params`` (reference layouts, fp32) and run the packing kernels (K10).
     With ``plan`` (params must then be device tensors at stable addresses) the work is recorded into it
     and executed once; ``plan.refresh()`` repeats it after the parameters changed."""
@@ -662,11 +662,11 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
         pm.plan = plan
     md.flows = C.cast(pm.flow_descs, C.POINTER(_lib.FlowDesc))
     md.cond_mode = int(cond_mode)
-    # developer switch (same-box A/B, tests): FWN_CHAIN_MODE=1 runs every flow on its own like round 2 (fwn.h chain_mode)
-    md.chain_mode = int(os.environ.get("FWN_CHAIN_MODE", "0"))
-    # developer switch (fwn.h persist_mode): FWN_PERSIST_MODE=2 runs every small-M flow as ONE launch, 1 none; default 0 = those
-    # of <= 512 rows, where the form measured faster
-    md.persist_mode = int(os.environ.get("FWN_PERSIST_MODE", "0"))
+    # fwn.h chain_mode: 1 runs every flow on its own like round 2 (same-box A/B, tests); an argument, not a process variable
+    md.chain_mode = int(chain_mode)
+    # fwn.h persist_mode: 2 runs every small-M flow as ONE launch, 1 none; default 0 = those of <= 512 rows, where the form
+    # measured faster (FloWaveNet(..., persist_mode=) / hparams.persist_mode)
+    md.persist_mode = int(persist_mode)
     md.gate_fp8 = 1 if gate_fp8 else 0
     torch.cuda.current_stream(dev).synchronize()
     if gate_fp8:                                   # the exponents the pack kernels chose, in one copy

@@ -13,7 +13,9 @@ from tf_flowavenet_amd.hparams import default_hparams
 from tf_flowavenet_amd import weights as W
 from tf_flowavenet_amd.model import FloWaveNet
 hp = default_hparams()
-m = FloWaveNet(hp, init=True).load_params(W.synthetic_params(hp, 1234))
+# the model's kernel-selection arguments from the environment of THIS developer tool (the package itself reads none)
+m = FloWaveNet(hp, init=True, chain_mode=int(os.environ.get("FWN_CHAIN_MODE", "0")),
+               persist_mode=int(os.environ.get("FWN_PERSIST_MODE", "0"))).load_params(W.synthetic_params(hp, 1234))
 def timed(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
