@@ -261,15 +261,16 @@ def full_model():
 
 
 @pytest.mark.parametrize("layer", [0, 1])
-@pytest.mark.parametrize("blk,b,ti", [(0, 3, 100), (0, 7, 1000), (0, 13, 1000), (0, 26, 1000), (1, 13, 1000), (1, 26, 1000),
-                                      (2, 13, 1000), (2, 26, 1000)])
+@pytest.mark.parametrize("blk,b,ti", [(0, 3, 100), (0, 7, 1000), (0, 13, 1000), (0, 26, 1000), (1, 7, 1000), (1, 13, 1000), (1, 26, 1000),
+                                      (2, 7, 1000), (2, 13, 1000), (2, 26, 1000), (3, 7, 1000), (3, 13, 1000)])
 def test_gate_stage_kernel_matches_oracle(full_model, blk, b, ti, layer):
     """fwn_gate alone (flow 0 of blocks 0 - 2; dilation 1 and 3) against the oracle's ResBlock gate
     (modules.py:113-124) on rows that straddle clip edges inside every tile.  Block 0: M = 300 runs the plain ring tiles,
     7000 the 128 x 128 tap-sharing tiles (gate_halo.h), 13 000 and 26 000 the register-streamed kernel (gate_rs.h) in its
     128- and 256-row forms (clip edges every 1000 rows inside its tiles, a partial last tile).  Blocks 1 and 2 at the same two
     sizes: the other instantiations of that kernel (10 and 20 conditioning k-steps) - every (NKC, tile height) pair has a case
-    against the fp64 oracle, not only against the tap-sharing tile."""
+    against the fp64 oracle, not only against the tap-sharing tile.  Round 6: the 64-row form (7 000 rows: every block's
+    instantiation, twelve ring stages) and block 3's 40 conditioning k-steps (64- and 128-row forms)."""
     hp, model, _, _, _ = full_model
     lib = _lib.load()
     p64 = onp.to_f64(W.synthetic_params(hp, 1234))
@@ -298,7 +299,9 @@ def test_gate_stage_kernel_matches_oracle(full_model, blk, b, ti, layer):
 
 
 @pytest.mark.parametrize("blk,b,ti,layer", [(0, 26, 1000, 0), (0, 4, 8064, 1), (1, 8, 4032, 0), (1, 25, 1000, 1), (1, 97, 256, 1),
-                                             (2, 8, 2016, 0), (2, 13, 1000, 1), (1, 4, 4032, 1), (0, 16, 1000, 0), (2, 49, 256, 0)])
+                                             (2, 8, 2016, 0), (2, 13, 1000, 1), (1, 4, 4032, 1), (0, 16, 1000, 0), (2, 49, 256, 0),
+                                             (3, 8, 1008, 0), (3, 8, 1008, 1), (3, 31, 256, 1), (0, 1, 8064, 1), (1, 2, 4032, 0), (2, 25, 256, 1),
+                                             (3, 16, 1008, 0)])
 def test_gate_stream_kernel_against_tap_sharing_kernel(full_model, blk, b, ti, layer):
     """The register-streamed gate (gate_rs.h, through fwn_gate with the flow's fragment stream Wgs) against the tap-sharing
     tile (the same call with Wgs = NULL) on the same operands: both multiply the same bf16 values and differ only in the
@@ -406,24 +409,24 @@ def test_gate_clock_diagnostic_runs_the_same_kernel(full_model):
 
 
 def test_gate_stream_is_what_the_model_runs(full_model):
-    """The packed model carries fragment streams for the blocks the kernel is built for (cin = 80, 160, 320 at num_mels = 80) and
-    none elsewhere; fwn_pack_gate_stream refuses a cin without a kernel; a descriptor that claims a stream for such a cin
-    is rejected."""
+    """The packed model carries fragment streams for the blocks the kernel is built for (cin = 80, 160, 320 and - round 6 - 640
+    at num_mels = 80) and none elsewhere; fwn_pack_gate_stream refuses a cin without a kernel; a descriptor that claims a
+    stream for such a cin is rejected."""
     hp, model, _, _, _ = full_model
     lib = _lib.load()
     for i in range(hp.n_block):
         d = model._packed.flow_descs[i * hp.n_flow]
         have = lib.fwn_gate_stream_bytes(d.cin) > 0
-        assert have == (i < 3)
+        assert have == (i < 4)
         assert all(bool(d.Wgs[l]) == have for l in range(hp.n_layer))
-    d3 = _lib.FlowDesc.from_buffer_copy(model._packed.flow_descs[3 * hp.n_flow])
-    buf = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    d4 = _lib.FlowDesc.from_buffer_copy(model._packed.flow_descs[4 * hp.n_flow])
+    buf = torch.empty(1 << 21, dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
-    assert lib.fwn_pack_gate_stream(d3.Wd[0], d3.Wc[0], d3.cin, d3.kcpad, buf.data_ptr(), st) == -1
-    d3.Wgs[0] = buf.data_ptr()
+    assert lib.fwn_pack_gate_stream(d4.Wd[0], d4.Wc[0], d4.cin, d4.kcpad, buf.data_ptr(), st) == -1
+    d4.Wgs[0] = buf.data_ptr()
     h = torch.zeros(64, 256, device="cuda", dtype=torch.bfloat16)
-    ca = torch.zeros(64, d3.cin, device="cuda", dtype=torch.bfloat16)
-    assert lib.fwn_gate(C.byref(d3), 0, h.data_ptr(), ca.data_ptr(), None, h.data_ptr(), 64, 64, st) == -1
+    ca = torch.zeros(64, d4.cin, device="cuda", dtype=torch.bfloat16)
+    assert lib.fwn_gate(C.byref(d4), 0, h.data_ptr(), ca.data_ptr(), None, h.data_ptr(), 64, 64, st) == -1
 
 
 def _flow_case(full_model, blk, b, ti, seed):

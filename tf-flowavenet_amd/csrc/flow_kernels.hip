@@ -526,7 +526,6 @@ struct GateProb {
 };
 
 #include "gate_halo.h"
-#include "gate_rs.h"
 
 // ---- residual 1x1: h' = (h + res_conv(o)) * sqrt(0.5), modules.py:126-128 ------------------
 struct ResProb {
@@ -930,58 +929,12 @@ void fwn_launch_front(const float* xa, const float* an_a, const void* W, const v
     launch_gemm128(p, M, 2, st);
 }
 
-// ---- register-streamed gate (gate_rs.h): one instantiation per number of conditioning k-steps
-#define FWN_RS_CASES(X) X(5) X(10) X(20)    // cin = 80 (block 0), 160 (block 1), 320 (block 2) at num_mels = 80
-long fwn_gate_stream_size(int cin) {
-    const int nkc = (cin + 15) / 16;
-#define X(n) if (nkc == n) return 16L * RsPlan<n>::NK * 1024;
-    FWN_RS_CASES(X)
-#undef X
-    return 0;
-}
-// 256-row tiles from 24 576 rows on (x 2 channel halves: the chip is full, as for the 256 x 256 tap-sharing tile); 128-row
-// tiles from 12 288 rows on (block 2 of the 8-clip pass, block 1 of a 4-clip pass: 256-row tiles would leave half the CUs empty)
-int fwn_gate_stream_min_rows() { return FWN_TUNE(FWN_RS_MIN_ROWS, 12288); }
-static int gate_stream_mt(int M) { return M >= FWN_TUNE(FWN_RS_MIN_ROWS256, 24576) ? 8 : 4; }
-int fwn_gate_stream_ok(int M, int Ti, int dil, int cin, bool fused_cond, bool aux) {
-    // a tile may cross one clip edge only; dilations whose halo fits the slot
-    return fused_cond && !aux && dil <= FWN_HALO_MAXDIL && Ti >= 256 && M >= fwn_gate_stream_min_rows() &&
-           fwn_gate_stream_size(cin) != 0 && cin % 8 == 0;
-}
-void fwn_launch_gate_stream_pack(const void* Wd, const void* Wc, int cin, int kcpad, void* out, hipStream_t st) {
-    const int nkc = (cin + 15) / 16;
-#define X(n) if (nkc == n) hipLaunchKernelGGL(gate_stream_pack_kernel<n>, dim3(128), dim3(256), 0, st, (const bf16*)Wd, (const bf16*)Wc, kcpad, (bf16*)out);
-    FWN_RS_CASES(X)
-#undef X
-}
-
+// (the register-streamed gate - gate_rs.h - and its dispatch rule live in gate_rs.hip: fwn_launch_gate_rs)
 void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* Wd, const void* Wc, const void* Wgs,
                      const float* bias, void* o, int M, int Ti, int dil, int cin, int kcpad, void* aux,
                      hipStream_t st) {
     if (Wgs && fwn_gate_stream_ok(M, Ti, dil, cin, ca != nullptr && P == nullptr, aux != nullptr)) {
-        GateRsArgs a{(const bf16*)h, (const bf16*)ca, (const bf16*)Wgs, bias, (bf16*)o, M, Ti, dil, cin};
-        const int nkc = (cin + 15) / 16;
-        // gate_rs_kernel<.., PERSIST = true>: one workgroup per CU loops over its tiles, the next tile's first items and
-        // weights issued under the tail of the current one (-10 % cycles per two-tile workgroup at block 0,
-        // tools/bench_gate_rs.hip).  Its race of the first half of round 4 is root-caused and fixed (a register copy hipcc
-        // placed in front of a branch-dependent asm wait: gate_rs.h; tools/check_async_loads.py); it
-        // soaks clean inside overlapped passes at 8 / 16 / 32 clips.  Used where a workgroup gets three tiles or more (from
-        // 13 clips of 16128 samples on at block 0: 32 clips -1.9 % on the one-stream pair, -0.8 % on the overlapped step);
-        // at the bench's 8 clips (two tiles per workgroup) the overlapped step is 1.5 % slower with it: one tile per
-        // workgroup there.  fwn_set_option("rs_persist", 0 / 1) forces either form (round 4 read an environment variable here, per launch).
-        const int ncu = fwn_device_cus() & ~1;
-        const int mt = gate_stream_mt(M);
-        const int pe = g_fwn_opt_rs_persist;            // fwn_set_option("rs_persist", ..): -1 auto
-        const bool persist = mt == 8 && (pe >= 0 ? pe == 1 : ((M + 255) / 256) * 2 >= 3 * ncu);
-        const int ntiles = ((M + 32 * mt - 1) / (32 * mt)) * 2, grid = persist && ntiles > ncu ? ncu : ntiles;
-#define X(n)                                                                                                                   \
-        if (nkc == n) {                                                                                                        \
-            if (mt == 8 && !persist) hipLaunchKernelGGL((gate_rs_kernel<n, 8, false>), dim3(grid), dim3(512), 0, st, a, ntiles);  \
-            else if (mt == 8) hipLaunchKernelGGL((gate_rs_kernel<n, 8, true>), dim3(grid), dim3(512), 0, st, a, ntiles);          \
-            else hipLaunchKernelGGL((gate_rs_kernel<n, 4, false>), dim3(grid), dim3(512), 0, st, a, ntiles);                     \
-        }
-        FWN_RS_CASES(X)
-#undef X
+        fwn_launch_gate_rs(h, ca, Wgs, bias, o, M, Ti, dil, cin, st);
         return;
     }
     GateProb p{(const bf16*)h, (const bf16*)ca, P, (const bf16*)Wd, (const bf16*)Wc, bias, (bf16*)o,
@@ -1007,20 +960,6 @@ void fwn_launch_gate(const void* h, const void* ca, const float* P, const void* 
         return;
     }
     launch_ring(p, M, 512, (768 + (ca ? kcpad : 0)) / 16, st);
-}
-
-// Diagnostic launch of the dominant kernel with two clock stamps per wave (fwn_gate_clock): the 256-row register-streamed
-// gate, same code otherwise.  Returns the number of workgroups (8 stamp records each) or 0 if the shape has no such kernel.
-int fwn_launch_gate_clock(const void* h, const void* ca, const void* Wgs, const float* bias, void* o, int M, int Ti, int dil, int cin,
-                          unsigned long long* clk, hipStream_t st) {
-    if (!Wgs || !fwn_gate_stream_ok(M, Ti, dil, cin, ca != nullptr, false) || gate_stream_mt(M) != 8) return 0;
-    GateRsArgs a{(const bf16*)h, (const bf16*)ca, (const bf16*)Wgs, bias, (bf16*)o, M, Ti, dil, cin};
-    a.clk = clk;
-    const int nkc = (cin + 15) / 16, ntiles = ((M + 255) / 256) * 2;
-#define X(n) if (nkc == n) hipLaunchKernelGGL((gate_rs_kernel<n, 8, false, FWN_RS_R, true>), dim3(ntiles), dim3(512), 0, st, a, ntiles);
-    FWN_RS_CASES(X)
-#undef X
-    return ntiles;
 }
 
 int fwn_gate_fp8_ok(int M, int dil) { return dil <= FWN_HALO_MAXDIL && ((M + 255) / 256) * 4 >= 192; }

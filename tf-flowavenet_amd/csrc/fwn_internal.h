@@ -26,6 +26,9 @@ long fwn_gate_stream_size(int cin);        // bytes, 0: no kernel for this cin
 int fwn_gate_stream_min_rows();
 int fwn_gate_stream_ok(int M, int Ti, int dil, int cin, bool fused_cond, bool aux);
 void fwn_launch_gate_stream_pack(const void* Wd, const void* Wc, int cin, int kcpad, void* out, hipStream_t st);
+// gate_rs.hip: the register-streamed launch itself (the caller has checked fwn_gate_stream_ok)
+void fwn_launch_gate_rs(const void* h, const void* ca, const void* Wgs, const float* bias, void* o, int M, int Ti, int dil, int cin,
+                        hipStream_t st);
 // the gate with its dilated taps in fp8 (h8 e4m3 [M][256], Wd8 e4m3 [512][768] stored as W 2^wexp); fwn_gate_fp8_ok says
 // whether this shape has such a kernel (the tap-sharing tiles: M >= 12288 rows, dilation <= 3, conditioning fused)
 int fwn_gate_fp8_ok(int M, int dil);

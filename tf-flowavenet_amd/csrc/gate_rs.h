@@ -30,8 +30,9 @@
 #include <type_traits>
 
 // MT: 32-row time tiles per wave (8: 256-row workgroup tiles; 4: 128-row tiles for row counts at which 256-row tiles would
-// leave CUs empty).  DMA pieces per wave and item: 8 waves x PP x 8 rows must hold the tile, its halo and a zero row.
-__host__ __device__ constexpr int rs_pp(int mt) { return mt == 8 ? 5 : 3; }      // 320- / 192-row slots
+// leave CUs empty; 2: 64-row tiles, round 6 - block 3 of the 8-clip pass, 8 064 rows x cin 640, where the 128 x 128 tap-sharing
+// tile ran at 0.22 of the MFMA peak).  DMA pieces per wave and item: 8 waves x PP x 8 rows must hold the tile, its halo and a zero row.
+__host__ __device__ constexpr int rs_pp(int mt) { return mt == 8 ? 5 : mt == 4 ? 3 : 2; }      // 320- / 192- / 128-row slots
 __host__ __device__ constexpr int rs_zrow(int mt) { return 32 * mt + 24; }       // a slot row no item ever stages
 
 #ifndef FWN_RABL
@@ -100,6 +101,15 @@ __device__ __forceinline__ float rs_gated1(float u, float v) {
     return (1.0f - a) * r;
 }
 
+// every ring stage made opaque at this point (behind a wait: no use of a stage is scheduled above it)
+template <int I, int R>
+__device__ __forceinline__ void rs_touch_all(bf16x8 (&wq)[R]) {
+    if constexpr (I < R) {
+        asm volatile("" : "+v"(wq[I]));
+        rs_touch_all<I + 1, R>(wq);
+    }
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void rs_static_for_impl(F&& f) {
     if constexpr (I < N) {
@@ -109,23 +119,6 @@ __device__ __forceinline__ void rs_static_for_impl(F&& f) {
 }
 template <int N, class F>
 __device__ __forceinline__ void rs_static_for(F&& f) { rs_static_for_impl<0, N>(f); }
-
-#ifdef FWN_RS_SHAPE16
-// Developer timing experiment (WRONG results; tools/bench_gate_rs.hip -DFWN_RS_SHAPE16): the slot's MFMA as two
-// v_mfma_f32_16x16x32_bf16 on half of the tile's accumulator registers (the other half on the next k-step) - the same operand
-// traffic, the same matrix cycles (2 x 16 for 32), the other instruction shape: does the chip hold a higher clock on it
-// (guide, DVFS give-back item 7: 1.12 - 1.15 x the FLOP/s in bare loops)?
-typedef __attribute__((ext_vector_type(4))) float rs_f32x4;
-template <int PAR>
-__device__ __forceinline__ f32x16 rs_mfma_shape16(bf16x8 a, bf16x8 b, f32x16 c) {
-    rs_f32x4 c0 = {c[8 * PAR], c[8 * PAR + 1], c[8 * PAR + 2], c[8 * PAR + 3]}, c1 = {c[8 * PAR + 4], c[8 * PAR + 5], c[8 * PAR + 6], c[8 * PAR + 7]};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { c[8 * PAR + i] = c0[i]; c[8 * PAR + 4 + i] = c1[i]; }
-    return c;
-}
-#endif
 
 // Packed row (packing.py gate order: row cg*64 + kind*32 + c of channel cg*32 + c) of accumulator row rho of channel
 // group grp (16 channels): a lane's registers 8 pp + j (filter) and 8 pp + 4 + j (gate) belong to the same channel
@@ -435,11 +428,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
             // issue cycles behind the MFMA it has just issued)
             rs_static_for<MT>([&](auto MI) {
                 constexpr int mi = decltype(MI)::value;
-#ifdef FWN_RS_SHAPE16
-                acc[mi] = rs_mfma_shape16<g & 1>(wq[g % R], hf[mi], acc[mi]);
-#else
                 acc[mi] = mfma32(wq[g % R], hf[mi], acc[mi]);
-#endif
                 if constexpr (!last && FWN_RABL != 5) ldfrag1(la, nview, kon, mi);
                 if constexpr (!LAG && g == 0 && mi < PP) {
                     if (first) issue_piece(std::integral_constant<int, 1>{}, 1, m0, mi);
@@ -514,10 +503,9 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
     }
     // behind the last tile: the look-ahead loads of a tile that does not exist (they re-read this wave's stream into the ring
     // registers) and its out-of-range pieces must have landed before the registers / the LDS are anyone else's
-#define RSW_(i) "+v"(wq[i])
-    static_assert(R == 6, "the final wait names the six ring stages");
-    asm volatile("s_waitcnt vmcnt(0)" : RSW_(0), RSW_(1), RSW_(2), RSW_(3), RSW_(4), RSW_(5) : : "memory");
-#undef RSW_
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    rs_touch_all<0, R>(wq);           // every ring stage named behind the wait (any R)
 }
 
 // NKC: conditioning k-steps of 16 (cin / 16 rounded up); MT: 32-row time tiles per wave; R: ring stages of weight fragments
@@ -528,7 +516,7 @@ __device__ __forceinline__ void gate_rs_wave(const GateRsArgs& p, unsigned char*
 template <int NKC, int MT = 8, bool PERSIST = false, int R = FWN_RS_R, bool CLK = false>
 __global__ __launch_bounds__(512) void gate_rs_kernel(GateRsArgs p, int ntiles) {
     static_assert(R >= 3 && R <= 12, "ring depth");
-    static_assert(MT == 8 || MT == 4, "256- or 128-row tiles");
+    static_assert(MT == 8 || MT == 4 || MT == 2, "256-, 128- or 64-row tiles");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 8 * rs_pp(MT) * 1024];
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x;

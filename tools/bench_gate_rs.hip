@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize tools/bench_gate_rs.hip -o /tmp/bench_gate_rs
 //   /tmp/bench_gate_rs [B] [first block] [last block] [dil]
 #include "../tf-flowavenet_amd/csrc/flow_kernels.hip"
+#include "../tf-flowavenet_amd/csrc/gate_rs.hip"
 #include "../tf-flowavenet_amd/csrc/tail_rs.hip"      // (flow_kernels.hip's tail dispatch refers to it)
 #include "gate_co.h"       // the co-resident gate left the library in round 5 (tools/gate_co.h)
 #include <cstdio>
