@@ -292,7 +292,7 @@ def _median_pass_s(fn, iters):
     return ts[len(ts) // 2] * 1e-3
 
 
-def one_launch_twin(model, hp, params, dev):
+def one_launch_twin(model, hp, params, dev, tail_stream=True):
     """The same parameters (the data-dependent init's tables exported from `model`) packed twice more: with
     fwn_model_desc.persist_mode = 2 (csrc/flow_persist.h: ONE launch per flow wherever the form exists) and 1 (a launch per
     stage everywhere; the default, 0, takes the one-launch form up to 512 rows) - the pair whose results must be equal bit for bit (the device init and the host packing of `model` itself differ
@@ -302,8 +302,8 @@ def one_launch_twin(model, hp, params, dev):
     p2 = dict(params)
     for k, v in model.export_actnorm().items():
         p2[k] = np.asarray(v, dtype=np.float32).reshape(np.asarray(p2[k]).shape)
-    plain = FloWaveNet(hp, device=dev, persist_mode=1).load_params(p2)
-    one = FloWaveNet(hp, device=dev, persist_mode=2).load_params(p2)
+    plain = FloWaveNet(hp, device=dev, persist_mode=1, tail_stream=tail_stream).load_params(p2)
+    one = FloWaveNet(hp, device=dev, persist_mode=2, tail_stream=tail_stream).load_params(p2)
     return one, plain
 
 
@@ -328,11 +328,17 @@ def latency_b1(model, hp, t, dev, iters=10, params=None):
             one, plain = one_launch_twin(model, hp, params, dev)
             f1, i1 = timed(lambda: one.forward(x, c)), timed(lambda: one.reverse(z, c))
             f0, i0 = timed(lambda: plain.forward(x, c)), timed(lambda: plain.reverse(z, c))
+            del one, plain
+            # the identity check on a pair WITHOUT the tail's fragment stream: the one-launch flow reproduces the N-split tail's
+            # arithmetic, which the launch-per-stage path runs below 4 097 rows only when csrc/tail_rs.h does not
+            one, plain = one_launch_twin(model, hp, params, dev, tail_stream=False)
             a, b_ = one.forward(x, c, return_z=True), plain.forward(x, c, return_z=True)
             same = bool(torch.equal(a[2], b_[2])) and float(a[0]) == float(b_[0]) and float(a[1]) == float(b_[1]) and \
                 bool(torch.equal(one.reverse(z, c), plain.reverse(z, c)))
             one_launch = {"fwd_ms": f1 * 1e3, "inv_ms": i1 * 1e3, "launch_per_stage_fwd_ms": f0 * 1e3, "launch_per_stage_inv_ms": i0 * 1e3,
                           "bit_identical_to_launch_per_stage": same,
+                          "bit_identity_pair": "both twins packed with tail_stream=False (the N-split tail below 4 097 rows, whose arithmetic "
+                                               "the one-launch flow reproduces); the timed twins carry the product's operands",
                           "what": "fwn_model_desc.persist_mode = 2: blocks 2 - 7 of this clip as one launch per flow "
                                   "(csrc/flow_persist.h; DESIGN.md section 3.7), and = 1: a launch per stage everywhere; the "
                                   "line's fwd_ms / inv_ms are the default (0): one launch per flow up to 512 rows (blocks 4 - 7)"}

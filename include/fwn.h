@@ -225,6 +225,9 @@ int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit
  * workgroups by output column (a workgroup of the fused kernel streams all 0.4 - 0.5 MB of tail weights itself:
  * 22 - 36 us whatever the row count); they keep S and U in `scratch` = [2][M][256] bf16 (may be NULL for larger M). */
 int fwn_tail_partials(int M);
+/* The exact count for flow d at M rows (which kernel serves it depends on its packed operands: d->Wts): mode -1 = fwn_tail /
+ * fwn_tail_train, 0 = fwn_tail_chained without a next flow, 1 = with one.  Always <= the bounds above. */
+int fwn_tail_partials_desc(const fwn_flow_desc* d, int M, int mode);
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
              int inverse, void* scratch, void* stream);
 /* The tail as the whole-model calls chain it (csrc/tail_chain.h), exposed for stage-level parity tests: out_b goes to

@@ -119,7 +119,7 @@ def loss_and_grads(self, tp, params, x, c):
                 if l + 1 < L:
                     self._call("fwn_res", C.byref(d), l, o[l].data_ptr(), h[l].data_ptr(), h[l + 1].data_ptr(), m, st)
             s_act, u_act, z = b16(m, 256), b16(m, 256), f32(m, 2 * ch)
-            part = f32(int(self.lib.fwn_tail_partials(m)))
+            part = f32(int(self.lib.fwn_tail_partials_desc(C.byref(d), m, -1)))      # the exact count (fwn_tail_partials is an upper bound)
             self._call("fwn_tail_train", C.byref(d), o_all.data_ptr(), m * 256, xa.data_ptr(), xb.data_ptr(), part.data_ptr(), m,
                        s_act.data_ptr(), u_act.data_ptr(), z.data_ptr(), st)
             partials.append(part)

@@ -72,6 +72,14 @@ def _golden_cases():
     return mg
 
 
+def _chain_scalar_tol(n_samples):
+    """Relative tolerance on log-p / log-det between a pass with chained flows (front conv on the MFMA from hi | lo bf16 halves
+    of the fp32 state) and one without (fp32 FMAs): the two are different realisations of the same bf16 rounding noise, the
+    scalars are MEANS over the samples - 2e-5 at the 129 024 samples of the bench workload, growing as 1 / sqrt(samples) below
+    (measured 2.4e-5 .. 5.1e-5 at 2 048 samples, 2.5e-5 at 16 128)."""
+    return max(2e-5, 6e-3 / np.sqrt(n_samples))
+
+
 @pytest.mark.parametrize("name", ["tiny_b2f2", "tiny_b3f3", "tiny_b4f2l3", "tiny_ddi", "config0_b2f2_T16128",
                                   "full_b8f6_T2048", "full_b8f6_B2_T1024", "hp8000_b5f6_T1536"])
 @pytest.mark.parametrize("cond_mode", [1, 2])
@@ -96,8 +104,11 @@ def test_forward_and_inverse_match_golden(name, cond_mode):
         # (a flow's ActNorm table does not exist while the previous flow's tail runs), later passes chain the flows of a
         # block and compute the front conv on the MFMA (hi | lo bf16 halves of the fp32 state) - and the third the second
         # bit for bit
+        # (round 6: the register-streamed tail chains flows from 1 008 rows on, so the small cases see the chained front conv too:
+        # _chain_scalar_tol; both passes are held to the oracle above)
         lp2, ld2 = model.forward(dev(inp["x"]), dev(inp["c"]))
-        assert abs(float(lp2) - float(log_p)) <= 2e-5 * abs(float(log_p)) and abs(float(ld2) - float(logdet)) <= 2e-5 * max(1.0, abs(float(logdet)))
+        tol = _chain_scalar_tol(b * t)
+        assert abs(float(lp2) - float(log_p)) <= tol * abs(float(log_p)) and abs(float(ld2) - float(logdet)) <= tol * max(1.0, abs(float(logdet)))
         lp3, ld3 = model.forward(dev(inp["x"]), dev(inp["c"]))
         assert float(lp3) == float(lp2) and float(ld3) == float(ld2)
     if "x_rev" in g:
@@ -606,20 +617,24 @@ def _without_tail_stream(d):
 
 @pytest.mark.parametrize("inverse", [0, 1])
 @pytest.mark.parametrize("blk,b,ti", [(0, 26, 1000), (0, 4, 8064), (0, 127, 254), (0, 49, 1000), (1, 13, 1000), (1, 8, 4032), (1, 97, 126), (2, 7, 1000),
-                                      (2, 130, 62), (3, 9, 896), (3, 33, 252), (4, 13, 504), (5, 40, 252)])
+                                      (2, 130, 62), (3, 9, 896), (3, 33, 252), (4, 13, 504), (5, 40, 252),
+                                      (1, 1, 4032), (2, 1, 2016), (3, 1, 1008), (3, 5, 252), (4, 8, 504), (5, 8, 252), (0, 3, 1000)])
 def test_register_streamed_tail_equals_the_register_chained_tail_bit_for_bit(full_model, blk, b, ti, inverse):
     """The register-streamed tail (csrc/tail_rs.h: a wave owns 32 output channels x all rows of the tile, weights streamed to
     registers in fragment order, S and U exchanged through LDS) against the kernels it replaces (the same call with the
-    flow's Wts = NULL: the register-chained tail_kernel, or the N-split ring GEMM + 64-row chain below 12 288 rows): same
-    MFMA shape, same accumulation order, same epilogue expressions - identical bits in the planes, in S / U / Z as the
-    training step keeps them, in the chained out_b and in the next flow's h0; the log-det partials are the same sum over a
-    different tiling.  Shapes: 128- and 64-row workgroups (M >= 12 288 / 6 144), Ch = 1 .. 32, clip edges on and off tile
-    boundaries, partial last tiles, both directions."""
+    flow's Wts = NULL).  From 6 144 rows on those are the register-chained tail_kernel and the N-split ring GEMM + 64-row
+    chain: same MFMA shape, same accumulation order, same epilogue expressions - IDENTICAL BITS in the planes, in S / U / Z
+    as the training step keeps them, in the chained out_b and in the next flow's h0; the log-det partials are the same sum
+    over a different tiling.  Below (one clip's blocks 1 - 3, blocks 4 / 5 of the 8-clip pass) the replaced path is three
+    ring GEMMs whose small tiles split K over wave groups - another summation order: there the two agree to the rounding of
+    the bf16 intermediates.  Shapes: 128-, 64- and 32-row workgroups (M >= 12 288 / 6 144 / 1 008), Ch = 1 .. 32, clip edges
+    on and off tile boundaries, partial last tiles, both directions."""
     hp, model, _, _, _ = full_model
     lib = _lib.load()
     L, ch, m = hp.n_layer, 1 << blk, b * ti
     d, nx = model._packed.flow_descs[blk * hp.n_flow], model._packed.flow_descs[blk * hp.n_flow + 1]
     assert d.Wts and lib.fwn_tail_stream_rows() <= m < 49152 and lib.fwn_tail_stream_bytes(L) > 0
+    exact = m >= 6144
     d0 = _without_tail_stream(d)
     rng = np.random.default_rng(blk * 1000 + b + inverse)
     o = torch.from_numpy((rng.random((L, m, 256)) * 0.8).astype(np.float32)).cuda().to(torch.bfloat16)
@@ -627,6 +642,17 @@ def test_register_streamed_tail_equals_the_register_chained_tail_bit_for_bit(ful
     st = torch.cuda.current_stream().cuda_stream
     scratch = torch.empty(2, m, 256, device="cuda", dtype=torch.bfloat16)
     npart = lib.fwn_tail_partials(m)
+
+    def same(a_, b_, what, rel=4e-3, frac=1.0):
+        """== where the replaced kernel sums in the same order; else |a - b| <= rel * max(1, |b|) (and at most `frac` of
+        the elements differ at all)."""
+        if exact:
+            assert torch.equal(a_, b_), (what, int((a_ != b_).sum()), torch.nonzero(a_ != b_)[:4].tolist())
+            return
+        da = (a_.float() - b_.float()).abs()
+        tol = rel * torch.clamp(b_.float().abs(), min=1.0)
+        assert bool((da <= tol).all()), (what, float(da.max()), int((da > tol).sum()))
+        assert float((da != 0).float().mean()) <= frac, (what, float((da != 0).float().mean()))
 
     def plain(desc):
         pa = [q.clone() for q in planes]
@@ -636,11 +662,11 @@ def test_register_streamed_tail_equals_the_register_chained_tail_bit_for_bit(ful
 
     (pa1, part1), (pa0, part0) = plain(d), plain(d0)
     torch.cuda.synchronize()
-    assert torch.equal(pa1[0], pa0[0]), "out_a differs"
-    assert torch.equal(pa1[1], pa0[1]), ("out_b differs", int((pa1[1] != pa0[1]).sum()), torch.nonzero(pa1[1] != pa0[1])[:4].tolist())
+    assert torch.equal(pa1[0], pa0[0]), "out_a differs"            # ActNorm only: the same fp32 expression everywhere
+    same(pa1[1], pa0[1], "out_b")
     if not inverse:
         s1, s0 = float(part1.double().sum()), float(part0.double().sum())
-        assert abs(s1 - s0) <= 1e-5 * abs(s0) + 1e-3, (s1, s0)
+        assert abs(s1 - s0) <= 1e-5 * abs(s0) + 1e-3 * (1 if exact else m * ch * 1e-2), (s1, s0)
         # the training form keeps S, U, Z
         outs = []
         for desc in (d, d0):
@@ -653,33 +679,48 @@ def test_register_streamed_tail_equals_the_register_chained_tail_bit_for_bit(ful
                                           S.data_ptr(), U.data_ptr(), Z.data_ptr(), st), "fwn_tail_train")
             outs.append((pb, S, U, Z))
         torch.cuda.synchronize()
-        for k in range(2):
-            assert torch.equal(outs[0][0][k], pa0[k]) and torch.equal(outs[1][0][k], pa0[k])
-        for k, name in ((1, "S"), (2, "U"), (3, "Z")):
+        assert torch.equal(outs[0][0][0], pa1[0]) and torch.equal(outs[0][0][1], pa1[1]), "fwn_tail_train differs from fwn_tail"
+        assert torch.equal(outs[1][0][0], pa0[0]) and torch.equal(outs[1][0][1], pa0[1])
+        for k, name, rel in ((1, "S", 8e-3), (2, "U", 8e-3), (3, "Z", 4e-3)):      # a bf16 ulp is 2^-8 of the value
             assert bool((outs[0][k][m:] == 7.0).all()), name + ": the kernel wrote past row M"
-            assert torch.equal(outs[0][k], outs[1][k]), (name, int((outs[0][k] != outs[1][k]).sum()))
+            same(outs[0][k], outs[1][k], name, rel=rel)
     # chained: out_b to a third buffer, and (Ch <= 8) the next flow's front conv in the same launch
-    if lib.fwn_tail_can_chain(C.byref(d), m, 1 if ch <= 8 else 0):
-        res = []
-        for desc in (d, d0):
-            pb = [q.clone() for q in planes]
-            xb_out = torch.full((m, ch), 7.0, device="cuda")
-            h_new = torch.full((m + 2, 256), 9.0, device="cuda", dtype=torch.bfloat16)
-            part = torch.zeros(lib.fwn_tail_partials_chained(m, ch, 1), device="cuda")
-            _lib.check(lib.fwn_tail_chained(C.byref(desc), C.byref(nx) if ch <= 8 else None, o.data_ptr(), pb[0].data_ptr(), pb[1].data_ptr(),
-                                            xb_out.data_ptr(), h_new.data_ptr() if ch <= 8 else None, part.data_ptr(), m, ti, inverse,
-                                            scratch.data_ptr(), st), "fwn_tail_chained")
-            res.append((pb, xb_out, h_new, part))
-        torch.cuda.synchronize()
-        assert torch.equal(res[0][0][1], planes[1]), "xb must stay untouched when out_b goes elsewhere"
-        assert torch.equal(res[0][0][0], pa0[0]) and torch.equal(res[0][1], pa0[1]), "chained out_a / out_b differ from the plain tail"
+    assert lib.fwn_tail_can_chain(C.byref(d), m, 1 if ch <= 8 else 0)
+    res = []
+    for desc in (d, d0):
+        if not lib.fwn_tail_can_chain(C.byref(desc), m, 1 if ch <= 8 else 0):      # (below 6 144 rows only the streamed kernel chains)
+            res.append(None)
+            continue
+        pb = [q.clone() for q in planes]
+        xb_out = torch.full((m, ch), 7.0, device="cuda")
+        h_new = torch.full((m + 2, 256), 9.0, device="cuda", dtype=torch.bfloat16)
+        part = torch.zeros(lib.fwn_tail_partials_chained(m, ch, 1), device="cuda")
+        _lib.check(lib.fwn_tail_chained(C.byref(desc), C.byref(nx) if ch <= 8 else None, o.data_ptr(), pb[0].data_ptr(), pb[1].data_ptr(),
+                                        xb_out.data_ptr(), h_new.data_ptr() if ch <= 8 else None, part.data_ptr(), m, ti, inverse,
+                                        scratch.data_ptr(), st), "fwn_tail_chained")
+        res.append((pb, xb_out, h_new, part))
+    torch.cuda.synchronize()
+    assert torch.equal(res[0][0][1], planes[1]), "xb must stay untouched when out_b goes elsewhere"
+    assert torch.equal(res[0][0][0], pa1[0]) and torch.equal(res[0][1], pa1[1]), "chained out_a / out_b differ from the plain (streamed) tail"
+    if ch <= 8:
+        assert bool((res[0][2][m:] == 9.0).all()), "h0: the kernel wrote past row M"
+    if res[1] is not None:
         assert torch.equal(res[1][1], pa0[1])
         if ch <= 8:
-            assert bool((res[0][2][m:] == 9.0).all()), "h0: the kernel wrote past row M"
             assert torch.equal(res[0][2], res[1][2]), ("h0 of the next flow differs", int((res[0][2] != res[1][2]).sum()))
-        if not inverse:
-            s1, s0 = float(res[0][3].double().sum()), float(res[1][3].double().sum())
-            assert abs(s1 - s0) <= 1e-5 * abs(s0) + 1e-3, (s1, s0)
+    elif ch <= 8:
+        # the stand-alone front conv on the chained out_b (fp32 FMAs there, hi | lo bf16 halves on the MFMA here: a bf16 ulp on a few elements)
+        h_ref = torch.empty(m, 256, device="cuda", dtype=torch.bfloat16)
+        fscr = torch.empty(m, 256, device="cuda", dtype=torch.bfloat16)
+        _lib.check(lib.fwn_front(C.byref(nx), res[0][1].data_ptr(), h_ref.data_ptr(), fscr.data_ptr(), m, ti, 0 if inverse else 1, st), "fwn_front")
+        torch.cuda.synchronize()
+        dh = (res[0][2][:m].float() - h_ref.float()).abs()
+        tol = 2.0 ** -7 * torch.maximum(h_ref.float().abs(), torch.ones_like(dh) * 0.25)
+        assert not bool((dh > tol).any()), (int((dh > tol).sum()), float(dh.max()))
+    if not inverse:
+        s1 = float(res[0][3].double().sum())
+        s0 = float(part1.double().sum())
+        assert abs(s1 - s0) <= 1e-5 * abs(s0) + 1e-3, (s1, s0)
 
 
 FLOW_CASES = [(0, 13, 1000), (0, 26, 1000), (1, 7, 1000), (3, 9, 700), (5, 4, 200), (7, 3, 70)]
@@ -773,7 +814,8 @@ def test_chained_flows_agree_with_every_flow_on_its_own(full_model, monkeypatch)
         w0 = model.reverse(zz, cc)
         lp1, ld1, zp1 = plain.forward(xx, cc, return_z=True)
         w1 = plain.reverse(zz, cc)
-        assert abs(float(lp0) - float(lp1)) <= 2e-5 * abs(float(lp1)) and abs(float(ld0) - float(ld1)) <= 2e-5 * max(1.0, abs(float(ld1)))
+        tol = _chain_scalar_tol(xx.shape[0] * xx.shape[1])
+        assert abs(float(lp0) - float(lp1)) <= tol * abs(float(lp1)) and abs(float(ld0) - float(ld1)) <= tol * max(1.0, abs(float(ld1)))
         dzz = (zp0 - zp1).abs()
         dw = (w0 - w1).abs()
         print("chained vs plain, B=%d: z mean %.2e max %.2e   wav mean %.2e max %.2e" % (xx.shape[0], float(dzz.mean()), float(dzz.max()),
@@ -789,11 +831,13 @@ def _persist_twins(hp, model, monkeypatch, with_default=False):
     params = dict(W.synthetic_params(hp, 1234))
     for k, v in model.export_actnorm().items():
         params[k] = np.asarray(v, dtype=np.float32).reshape(params[k].shape)
-    plain = FloWaveNet(hp, persist_mode=1).load_params(params)
-    one = FloWaveNet(hp, persist_mode=2).load_params(params)
+    # (tail_stream=False: below 4 097 rows the one-launch flow reproduces the N-split tail's arithmetic, not the register-streamed
+    # tail's - csrc/tail_rs.h sums S in another order than the ring GEMM's split-K - so the launch-per-stage twin runs that tail)
+    plain = FloWaveNet(hp, persist_mode=1, tail_stream=False).load_params(params)
+    one = FloWaveNet(hp, persist_mode=2, tail_stream=False).load_params(params)
     assert plain._packed.model_desc.persist_mode == 1 and one._packed.model_desc.persist_mode == 2
     if with_default:
-        auto = FloWaveNet(hp).load_params(params)
+        auto = FloWaveNet(hp, tail_stream=False).load_params(params)
         assert auto._packed.model_desc.persist_mode == 0
         return one, plain, auto
     return one, plain
@@ -837,8 +881,10 @@ def test_one_launch_flows_on_other_model_shapes(monkeypatch, variant):
     else:
         hp, b, t = default_hparams().replace(n_block=5, n_flow=2, n_layer=3), 2, 4096
     params = W.synthetic_params(hp, 99, actnorm="random")
-    plain = FloWaveNet(hp, persist_mode=1).load_params(params)
-    one = FloWaveNet(hp, persist_mode=2).load_params(params)
+    # (tail_stream=False: below 4 097 rows the one-launch flow reproduces the N-split tail's arithmetic, not the register-streamed
+    # tail's - csrc/tail_rs.h sums S in another order than the ring GEMM's split-K - so the launch-per-stage twin runs that tail)
+    plain = FloWaveNet(hp, persist_mode=1, tail_stream=False).load_params(params)
+    one = FloWaveNet(hp, persist_mode=2, tail_stream=False).load_params(params)
     inp = W.synthetic_inputs(hp, b, t)
     x, c, z = dev(inp["x"]), dev(inp["c"]), dev(inp["z"])
     for _ in range(2):
@@ -858,7 +904,7 @@ def test_one_launch_flow_entry_point_and_its_status_word(full_model, blk, b, inv
     form."""
     hp, model, _, _, _ = full_model
     lib = _lib.load()
-    d = model._packed.flow_descs[blk * hp.n_flow + 2]
+    d = _without_tail_stream(model._packed.flow_descs[blk * hp.n_flow + 2])      # (the launch-per-stage side then runs the N-split tail the one-launch flow reproduces)
     T = 16128
     ch = 1 << blk
     ti = T // (2 * ch)

@@ -175,6 +175,7 @@ SIGNATURES = {
                                  C.c_int, vp]),
     "fwn_cond_reduce": (C.c_int, [vp, vp, i64, C.c_int, i64, vp]),
     "fwn_tail_partials": (C.c_int, [C.c_int]),
+    "fwn_tail_partials_desc": (C.c_int, [C.POINTER(FlowDesc), C.c_int, C.c_int]),
     "fwn_tail": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "fwn_tail_train": (C.c_int, [C.POINTER(FlowDesc), vp, C.c_int64, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
     "fwn_flow_run": (C.c_int, [C.POINTER(FlowDesc), i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int,

@@ -324,8 +324,8 @@ int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float*
 }
 
 int fwn_tail_can_chain(const fwn_flow_desc* d, int M, int with_front) {
-    if (!d || M <= 0 || !fwn_tail_chain_xb_out(M, d->npt)) return 0;
-    return with_front ? (fwn_tail_chain_front(M, d->Ch, d->npt) ? 1 : 0) : 1;
+    if (!d || M <= 0 || !fwn_tail_chain_xb_out(M, d->npt, desc_rs_mt(d, M))) return 0;
+    return with_front ? (fwn_tail_chain_front(M, d->Ch, d->npt, desc_rs_mt(d, M)) ? 1 : 0) : 1;
 }
 // the public counts are upper bounds over the kernels that may serve the shape (which one runs depends on the flow's packed
 // operands): callers zero the buffer, a launch writes its first n slots
@@ -336,6 +336,13 @@ static int tail_partials_bound(int M, int Ch, int front) {
     return n;
 }
 int fwn_tail_partials_chained(int M, int Ch, int with_front) { return M > 0 ? tail_partials_bound(M, Ch, with_front != 0) : 0; }
+// exact: the slots the tail of flow d writes at M rows - mode -1: fwn_tail / fwn_tail_train (in place), 0: fwn_tail_chained
+// without a next flow, 1: with one
+int fwn_tail_partials_desc(const fwn_flow_desc* d, int M, int mode) {
+    if (!d || M <= 0) return 0;
+    const int mt = desc_rs_mt(d, M);
+    return mode < 0 ? fwn_tail_npartials(M, mt) : fwn_tail_npartials_chain(M, d->Ch, mode != 0, mt);
+}
 int fwn_tail_chained(const fwn_flow_desc* d, const fwn_flow_desc* next, const void* o, float* xa, const float* xb, float* xb_out,
                      void* h0_next, float* partial, int M, int Ti, int inverse, void* scratch, void* stream) {
     int rc = check_desc(d);
@@ -928,12 +935,14 @@ static int check_block_contiguity(const fwn_model_desc* m, int blk) {
 // that kernel exists (Ch <= 8) - not during the data-dependent init (next's ActNorm table does not exist yet) and not on
 // the fp8 path (its first gate reads an e4m3 copy of h0 that only the stand-alone front conv writes).
 static FlowChain flow_chain(const fwn_model_desc* m, const fwn_flow_desc* d, const fwn_flow_desc* next, int M, bool init, float* spare,
-                            int have_h0) {
+                            int have_h0, bool one_launch) {
     FlowChain ch;
     memset(&ch, 0, sizeof(ch));
-    const bool on = m->chain_mode != 1;
-    ch.xb_out = (on && fwn_tail_chain_xb_out(M, d->npt)) ? spare : nullptr;
-    ch.next = (ch.xb_out && next && !init && !m->gate_fp8 && next->Wfront3 && next->kf3 > 0 && fwn_tail_chain_front(M, d->Ch, d->npt)) ? next : nullptr;
+    // (a block whose flows run as ONE launch each - flow_persist.h - does not chain: that form holds the whole flow already)
+    const bool on = m->chain_mode != 1 && !one_launch;
+    const int rs_mt = desc_rs_mt(d, M);
+    ch.xb_out = (on && fwn_tail_chain_xb_out(M, d->npt, rs_mt)) ? spare : nullptr;
+    ch.next = (ch.xb_out && next && !init && !m->gate_fp8 && next->Wfront3 && next->kf3 > 0 && fwn_tail_chain_front(M, d->Ch, d->npt, rs_mt)) ? next : nullptr;
     ch.have_h0 = have_h0;
     return ch;
 }
@@ -986,8 +995,8 @@ static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, con
             const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
             double* mom = (double*)(ws + c.mom) + (size_t)(i * m->n_flow + j) * (4 * ((size_t)1 << (m->n_block - 1)) + 1);
-            FlowChain ch = flow_chain(m, d, j + 1 < m->n_flow ? d + 1 : nullptr, (int)M, init != 0, pl.spare, have_h0);
             unsigned* sync = (!init && persist_block(m, M, i)) ? (unsigned*)(ws + c.sync + (size_t)(i * m->n_flow + j) * c.sync_stride) : nullptr;
+            FlowChain ch = flow_chain(m, d, j + 1 < m->n_flow ? d + 1 : nullptr, (int)M, init != 0, pl.spare, have_h0, sync != nullptr);
             rc = flow_run_impl(d, B, T, pl.at[p], pl.at[p ^ 1], ca, hA, hB, ws + c.o, P, partial + poff, 0, init, mom, reduce, user,
                                m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, &ch, stream, sync);
             if (rc) return rc;
@@ -1068,8 +1077,8 @@ int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float
             const fwn_flow_desc* d = &m->flows[i * m->n_flow + j];
             const void* ca = hoist ? nullptr : (const void*)(ws + c.cplanes + (size_t)p * cplane_bytes);
             const float* P = hoist ? (const float*)(ws + c.P) + (size_t)j * m->n_layer * M * 512 : nullptr;
-            FlowChain ch = flow_chain(m, d, j > 0 ? d - 1 : nullptr, (int)M, false, pl.spare, have_h0);
             unsigned* sync = persist_block(m, M, i) ? (unsigned*)(ws + c.sync + (size_t)(i * m->n_flow + j) * c.sync_stride) : nullptr;
+            FlowChain ch = flow_chain(m, d, j > 0 ? d - 1 : nullptr, (int)M, false, pl.spare, have_h0, sync != nullptr);
             rc = flow_run_impl(d, B, T, pl.at[p], pl.at[p ^ 1], ca, hA, hB, ws + c.o, P, nullptr, 1, 0, nullptr, nullptr, nullptr,
                                m->gate_fp8 ? ws + c.h8a : nullptr, m->gate_fp8 ? ws + c.h8b : nullptr, &ch, stream, sync);
             if (rc) return rc;

@@ -825,8 +825,9 @@ static bool tail_split_chain(int M) {
     return FWN_TUNE(FWN_TAIL_SPLIT_CHAIN, FWN_TAIL_SPLIT_CHAIN) != 0 && M >= FWN_TUNE(FWN_TAIL_SPLIT_CHAIN_MIN, FWN_TAIL_SPLIT_CHAIN_MIN);
 }
 static int tail_chain_rows(int M) { return fwn_tail_is_split(M) ? 64 : fwn_tail_rows(M); }
-int fwn_tail_chain_xb_out(int M, int npt) { return !fwn_tail_is_split(M) || tail_split_chain(M); }
-int fwn_tail_chain_front(int M, int Ch, int npt) { return fwn_tail_chain_xb_out(M, npt) && Ch <= 8 && npt == 1; }
+// rs_mt != 0: the register-streamed tail runs the launch (tail_rs.h: it can always write out_b elsewhere)
+int fwn_tail_chain_xb_out(int M, int npt, int rs_mt) { return rs_mt != 0 || !fwn_tail_is_split(M) || tail_split_chain(M); }
+int fwn_tail_chain_front(int M, int Ch, int npt, int rs_mt) { return fwn_tail_chain_xb_out(M, npt, rs_mt) && Ch <= 8 && npt == 1; }
 // rs_mt: 32-row tiles per workgroup of the register-streamed tail (tail_rs.h) when that kernel runs the launch (fwn_tail_rs_mt), else 0
 int fwn_tail_npartials_chain(int M, int Ch, int front, int rs_mt) {       // log-det partial slots one tail launch writes
     if (rs_mt == 0 && fwn_tail_is_split(M) && !tail_split_chain(M)) return ((M + 63) / 64) * 8;

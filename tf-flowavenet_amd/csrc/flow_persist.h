@@ -568,7 +568,7 @@ int fwn_flow_persist_sync_words(int M, int L) {
 // the log-det partial slots and the S / U buffers are the launch-per-stage path's), n_layer <= 2
 int fwn_flow_persist_ok(int M, int Ch, int L, int npt, bool has_w2, bool xa_aligned) {
     if (M > FWN_TUNE(FWN_PERSIST_MAX_ROWS, FWN_PERSIST_MAX_ROWS) || L > FWN_PS_MAXL || L < 1) return 0;
-    if (fwn_tail_chain_xb_out(M, npt)) return 0;      // only where the tail is the three N-split ring GEMMs
+    if (fwn_tail_chain_xb_out(M, npt, 0)) return 0;   // only where the tail (without a fragment stream) is the three N-split ring GEMMs
     if (Ch > 128 || npt < 1 || npt > 4) return 0;
     if (Ch >= 16 && !(has_w2 && xa_aligned)) return 0;
     return 1;

@@ -93,8 +93,8 @@ int fwn_tail_is_split(int M);    // the N-split tail (ring GEMMs; needs [2][M][2
 // rs_mt: fwn_tail_rs_mt of the launch (0: the register-streamed tail does not run it)
 int fwn_tail_npartials(int M, int rs_mt);   // log-det partial slots a plain (un-chained) tail launch writes
 int fwn_tail_npartials_chain(int M, int Ch, int front, int rs_mt);   // ... a chained launch (fwn_tail_chain given; front: h0_next set)
-int fwn_tail_chain_xb_out(int M, int npt);                // whether the tail at this shape can write out_b elsewhere (xb_out)
-int fwn_tail_chain_front(int M, int Ch, int npt);         // ... and can compute the next flow's front conv
+int fwn_tail_chain_xb_out(int M, int npt, int rs_mt);         // whether the tail at this shape can write out_b elsewhere (xb_out)
+int fwn_tail_chain_front(int M, int Ch, int npt, int rs_mt);  // ... and can compute the next flow's front conv
 
 void fwn_launch_wn_scale(const float* v, const float* g, int k_src, int n_src, float* scale, hipStream_t st);
 void fwn_launch_pack(const float* v, const float* scale, const int* src_k, const int* src_n, int n_src,

@@ -7,7 +7,7 @@
 long fwn_tail_stream_size(int L) { return L == 2 ? 8L * 48 * 1024 : 0; }
 
 #ifndef FWN_TRS_MIN_ROWS
-#define FWN_TRS_MIN_ROWS 6144        // fewer rows: the N-split ring GEMMs / the one-launch flow (flow_kernels.hip, flow_persist.h)
+#define FWN_TRS_MIN_ROWS 1008        // fewer rows: the N-split ring GEMMs / the one-launch flow (flow_kernels.hip, flow_persist.h)
 #endif
 // Tile height: the larger the better down to a few dozen workgroups - a workgroup streams all 384 KB of Wskip | Wfinal from L2
 // whatever its rows (at ~64 B / clock / CU that alone is 6 k cycles), so smaller tiles buy occupancy with L2 traffic and lose
@@ -17,7 +17,9 @@ long fwn_tail_stream_size(int L) { return L == 2 ? 8L * 48 * 1024 : 0; }
 #define FWN_TRS_ROWS128 12288        // from here on 128-row workgroups (one per CU: 140 KB of LDS)
 #endif
 #ifndef FWN_TRS_ROWS64
-#define FWN_TRS_ROWS64 6144          // 64-row workgroups down to here (32-row ones below: not selected by default)
+#define FWN_TRS_ROWS64 6144          // 64-row workgroups down to here; 32-row ones below (one clip's blocks 1 - 3, blocks 4 / 5 of the
+                                     // 8-clip pass: a few dozen workgroups - 9.0 - 9.5 us per launch against 10.5 - 11 with 64 rows,
+                                     // where the N-split tail took three launches)
 #endif
 // From 49 152 rows on (block 0 of the 8-clip pass: 504 workgroups of 128 rows = two rounds on 256 CUs) the 256-row register-chained
 // tail_kernel (252 workgroups, one round, weights read once per 256 rows) is still ahead in situ: 38 against 41 us per launch

@@ -350,7 +350,7 @@ class PackedModel:
 
 
 def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | None" = None,
-               gate_fp8: bool = False, persist_mode: int = 0, chain_mode: int = 0) -> PackedModel:
+               gate_fp8: bool = False, persist_mode: int = 0, chain_mode: int = 0, tail_stream: bool = True) -> PackedModel:
     """Upload ``params`` (reference layouts, fp32) and run the packing kernels (K10).
     With ``plan`` (params must then be device tensors at stable addresses) the work is recorded into it
     and executed once; ``plan.refresh()`` repeats it after the parameters changed."""
@@ -606,7 +606,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
             d.Wfinal = wfin.data_ptr()
             # Wskip | Wfinal once more in MFMA-fragment order for the register-streamed tail (csrc/tail_rs.h): one ZeroConv pair
             # tile only, and - like the gate's stream - only without a PackPlan (a plan re-packs the weights every step)
-            ts_bytes = int(lib.fwn_tail_stream_bytes(L)) if (plan is None and npt == 1) else 0
+            ts_bytes = int(lib.fwn_tail_stream_bytes(L)) if (plan is None and npt == 1 and tail_stream) else 0
             if ts_bytes:
                 wts = pm.keep(torch.empty(ts_bytes, dtype=torch.uint8, device=dev))
                 pm.weight_bytes += ts_bytes
