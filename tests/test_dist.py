@@ -250,3 +250,69 @@ def test_bf16_gradient_exchange_is_lockstep_and_bounds_the_step():
     # cancel and the bf16 sum differs in relative terms - or in sign - an element can end up to 2 x 3 lr away; those are few:
     d = np.abs(outs[1] - outs[0])
     assert d.max() <= 6.1e-3 and np.median(d) < 3e-6 and (d > 3e-4).mean() < 0.01, (d.max(), np.median(d), (d > 3e-4).mean())
+
+
+# ---- the sharded-optimiser exchange (round 6: optim.DataParallelAdam(exchange="zero1"), SURVEY section 8e's alternative) ----
+def _zero1_worker(rank, world, port, q):
+    import numpy as np
+    from oracle import optim_np
+    from tf_flowavenet_amd import optim
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    D.init_from_env("gloo")
+    n = 100003                      # not a multiple of world * 4: the last shard is short
+    rng = np.random.default_rng(11 + rank)
+    g_np = (rng.standard_normal(n) * np.exp(rng.standard_normal(n))).astype(np.float32)
+    w0 = np.random.default_rng(5).standard_normal(n).astype(np.float32)         # the same masters on every rank
+    # all-reduce path: every rank reduces everything and updates everything
+    g = torch.from_numpy(g_np.copy())
+    for wk in optim.allreduce_flat(g, None, 30000, True):
+        wk.wait()
+    g_all = g.numpy().astype(np.float64) / world
+    (gc,), gn_all = optim_np.clip_by_global_norm([g_all], 1.0)
+    w_all, _, _ = optim_np.adam_step(w0.astype(np.float64), gc, np.zeros(n), np.zeros(n), 1, 1e-3)
+    # sharded path: reduce onto the owners, shard norms all-reduced, update of the own shard, gather
+    g = torch.from_numpy(g_np.copy())
+    (lo, hi), _ = optim.reduce_to_owners(g)
+    bounds = optim.shard_bounds(n, world)
+    assert (lo, hi) == bounds[rank] and bounds[0][0] == 0 and bounds[-1][1] == n and all(b[0] % 4 == 0 for b in bounds)
+    gs = g[lo:hi].numpy().astype(np.float64) / world
+    sq = torch.tensor([float((gs * gs).sum())], dtype=torch.float64)
+    dist.all_reduce(sq)
+    gn = float(sq.sqrt())
+    w = torch.from_numpy(w0.copy())
+    ws, _, _ = optim_np.adam_step(w0[lo:hi].astype(np.float64), gs * (1.0 / max(gn, 1.0)), np.zeros(hi - lo), np.zeros(hi - lo), 1, 1e-3)
+    w[lo:hi] = torch.from_numpy(ws.astype(np.float32))
+    optim.gather_from_owners(w)
+    q.put((rank, dict(shard=(lo, hi), g_shard=g[lo:hi].numpy().copy(), g_all=(g_all * world).astype(np.float32), gn=gn, gn_all=gn_all,
+                      w=w.numpy().copy(), w_all=w_all.astype(np.float32))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_optimiser_exchange_reproduces_the_all_reduced_update():
+    """exchange = "zero1" on two gloo ranks: a shard's owner holds exactly the all-reduced gradient of its shard, the global
+    norm from the all-reduced shard norms is the norm of the whole gradient, and after clip + Adam on the shards and the
+    gather EVERY rank holds the same masters - the ones the all-reduce path's full update (oracle/optim_np.py, the restatement
+    of train.py:15-32 / utils.py:34-60) produces."""
+    import numpy as np
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zero1_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        lo, hi = res[r]["shard"]
+        assert np.array_equal(res[r]["g_shard"], res[r]["g_all"][lo:hi])           # the owner's shard = the all-reduced gradient
+        assert abs(res[r]["gn"] - res[r]["gn_all"]) <= 1e-12 * res[r]["gn_all"]
+    assert np.array_equal(res[0]["w"], res[1]["w"])                                # lock-step: identical masters everywhere
+    assert np.array_equal(res[0]["w"], res[0]["w_all"])                            # ... and the all-reduce path's
+    assert res[0]["shard"][1] == res[1]["shard"][0] and res[1]["shard"][1] == 100003

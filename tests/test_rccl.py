@@ -101,3 +101,52 @@ def test_bench_launches_two_rccl_ranks_itself():
     rec = _bench("--gpus", "2")
     assert rec["n_gpus"] == 2 and rec["train"]["n_gpus"] == 2 and "error" not in rec["train"]
     assert rec["train"]["allreduce_ms"] > 0 and 0.0 <= rec["train"]["overlap"] <= 1.0
+
+
+def _zero1_one_rank_worker(q):
+    """DataParallelAdam(exchange="zero1") over a one-rank RCCL group with the collectives forced on, next to the all-reduce
+    exchange on the same gradients: three steps (below / above / below the clip threshold)."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import small_hparams
+    from tf_flowavenet_amd import optim, weights as W
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    hp = small_hparams(n_block=2, n_flow=2)
+    params = W.synthetic_params(hp, 11, actnorm="random")
+    opts = {ex: optim.DataParallelAdam(hp, params, exchange=ex) for ex in optim.EXCHANGES}
+    for o in opts.values():
+        o.force_collectives = True
+    rng = np.random.default_rng(5)
+    norms = {ex: [] for ex in opts}
+    for amp in (1e-4, 3.0, 0.05):
+        g = torch.from_numpy((amp * rng.standard_normal(opts["zero1"].layout.size)).astype(np.float32)).cuda()
+        for ex, o in opts.items():
+            o.g[:g.numel()].copy_(g)
+            norms[ex].append(float(o.step(loss_scale=64.0)))
+    torch.cuda.synchronize()
+    a, b = opts["allreduce"], opts["zero1"]
+    q.put((norms, float((a.w - b.w).abs().max()), float(a.w.abs().max()), bool(torch.equal(a.m, b.m)), float((a.v - b.v).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_sharded_optimiser_step_on_rccl_equals_the_all_reduce_step():
+    """exchange="zero1" through RCCL (reduce onto the owner, all-reduced shard norms, fwn_clip_adam on the shard, broadcast of
+    the masters): with one rank the shard is the whole buffer, so the step equals the all-reduce exchange's up to the one
+    fp32 rounding of the norm (sqrt of the all-reduced square against fwn_grad_norm's own root)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_zero1_one_rank_worker, args=(q,), daemon=True)
+    p.start()
+    try:
+        norms, dw, wmax, same_m, dv = q.get(timeout=300)
+    finally:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    for x, y in zip(norms["allreduce"], norms["zero1"]):
+        assert abs(x - y) <= 1e-6 * abs(x), (x, y)
+    assert dw <= 1e-6 * max(1.0, wmax) and dv <= 1e-9, (dw, wmax, same_m, dv)

@@ -27,6 +27,10 @@ _COMMON = dict(
     # not in the reference: dtype of the data-parallel gradient exchange (utils.py:34-60 averages fp32 tower gradients):
     # "fp32", or "bf16" = half the bytes over xGMI; masters, Adam slots and the update stay fp32
     grad_reduce_dtype="fp32",
+    # not in the reference: "allreduce" (every rank clips and updates all masters) or "zero1" (SURVEY section 8e's alternative:
+    # the gradient is reduced onto shard owners, each rank clips / updates its 1 / world of the masters, the masters are
+    # gathered back; eager steps only)
+    grad_exchange="allreduce",
 )
 
 _22K = dict(n_fft=1024, hop_size=256, sample_rate=22050, fmax=7600, max_time_steps=6400,

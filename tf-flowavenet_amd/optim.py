@@ -112,15 +112,69 @@ def allreduce_flat(grad, group=None, bucket_elems=64 << 20, async_op=True, reduc
     return works
 
 
+# ---- the sharded-optimiser exchange (SURVEY section 8e's alternative: "clip/Adam on the reduce-scattered shard, all-gather
+# weights"; ZeRO-1 shape).  Rank r owns elements [lo_r, hi_r) of the flat buffers: the gradient is REDUCED ONTO ITS OWNER
+# instead of all-reduced, the global norm is the all-reduced sum of the owners' shard norms, every rank runs clip + Adam on
+# its shard only (1 / world of the optimiser's HBM traffic: 28 B per parameter read + 12 B written per step), and the
+# updated fp32 masters are gathered back so that every rank packs the same weights.  Exchange volume = the all-reduce's
+# (reduce-scatter + all-gather ARE its two halves).  Written with per-shard reduce / broadcast collectives, which every
+# backend has (gloo has no reduce_scatter): on RCCL a padded reduce_scatter_tensor / all_gather_into_tensor pair moves the
+# same bytes in two calls.
+EXCHANGES = ("allreduce", "zero1")
+
+
+def shard_bounds(n: int, world: int, align: int = 4):
+    """[lo, hi) of every rank's shard of an n-element flat buffer: equal chunks rounded up to `align` elements (16-byte
+    kernel accesses), the last ones short or empty."""
+    chunk = (-(-n // world) + align - 1) // align * align
+    return [(min(n, r * chunk), min(n, (r + 1) * chunk)) for r in range(world)]
+
+
+def _group_ranks(group):
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    return [dist.get_global_rank(group, r) if group is not None else r for r in range(world)]
+
+
+def reduce_to_owners(g, group=None, async_op=False):
+    """Sum every shard of the flat gradient ``g`` onto its owner: afterwards ``g[lo_r:hi_r]`` on rank r is the sum over the
+    ranks (the rest of g is stale).  Returns (this rank's (lo, hi), work handles)."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bounds, ranks = shard_bounds(g.numel(), world), _group_ranks(group)
+    works = [dist.reduce(g[lo:hi], dst=ranks[r], group=group, async_op=True) for r, (lo, hi) in enumerate(bounds) if hi > lo]
+    if not async_op:
+        for w in works:
+            w.wait()
+        works = []
+    return bounds[rank], works
+
+
+def gather_from_owners(w, group=None):
+    """Every owner's shard of the flat tensor ``w`` to everyone (the all-gather half)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    bounds, ranks = shard_bounds(w.numel(), world), _group_ranks(group)
+    works = [dist.broadcast(w[lo:hi], src=ranks[r], group=group, async_op=True) for r, (lo, hi) in enumerate(bounds) if hi > lo]
+    for x in works:
+        x.wait()
+
+
 class DataParallelAdam:
     """fp32 master weights + Adam slots in flat device buffers; ``step()`` = all-reduce -> global
-    norm -> clip -> Adam, returning the (device) global gradient norm."""
+    norm -> clip -> Adam, returning the (device) global gradient norm.  exchange = "zero1": reduce onto the shard owners ->
+    norm of the shards (all-reduced) -> clip + Adam on the own shard -> gather the masters (see above)."""
 
     def __init__(self, hp, params, device="cuda", clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8, group=None,
-                 bucket_elems=64 << 20, grad_reduce_dtype="fp32"):
+                 bucket_elems=64 << 20, grad_reduce_dtype="fp32", exchange="allreduce"):
         import torch
         if grad_reduce_dtype not in REDUCE_DTYPES:
             raise ValueError("grad_reduce_dtype must be one of %s" % (REDUCE_DTYPES,))
+        if exchange not in EXCHANGES:
+            raise ValueError("exchange must be one of %s" % (EXCHANGES,))
+        if exchange == "zero1" and grad_reduce_dtype != "fp32":
+            raise ValueError("exchange='zero1' reduces in fp32")
+        self.exchange = exchange
         self.layout = FlatLayout(hp)
         self.device = device
         self.group = group
@@ -199,6 +253,8 @@ class DataParallelAdam:
             return None
         if dist.get_world_size(self.group) == 1 and not self.force_collectives:
             return None
+        if self.exchange == "zero1":         # the sharded exchange runs in step(): a block's range is not a shard
+            return None
         return allreduce_slice(self.g, lo, hi, self.group, self.grad_reduce_dtype, self._stage())
 
     def _stage(self):
@@ -213,6 +269,8 @@ class DataParallelAdam:
         import torch
         import torch.distributed as dist
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        if self.exchange == "zero1" and (world > 1 or (self.force_collectives and dist.is_available() and dist.is_initialized())):
+            return self._step_zero1(world, loss_scale)
         for w in (allreduce_flat(self.g, self.group, self.bucket_elems, True, self.grad_reduce_dtype, self._stage()) if works is None else works):
             if w is not None:
                 w.wait()
@@ -228,11 +286,43 @@ class DataParallelAdam:
                                            self.b1, self.b2, self.eps, st), "fwn_clip_adam")
         return self._gnorm
 
+    def _step_zero1(self, world, loss_scale):
+        """The sharded update: this rank's clip + Adam touch its shard only."""
+        import torch
+        import torch.distributed as dist
+        (lo, hi), _ = reduce_to_owners(self.g, self.group)
+        gscale = 1.0 / (world * float(loss_scale))
+        st = torch.cuda.current_stream(torch.device(self.device)).cuda_stream
+        n = hi - lo
+        # ||g||^2 = the sum of the owners' shard norms squared (fp32 all-reduce of one scalar per rank; the shard norm itself
+        # is fwn_grad_norm's deterministic fp64 tree): the same value on every rank, the summation order of the all-reduce
+        # path's single tree is not reproduced - the two paths agree to fp32 rounding of the clip factor, not bit for bit
+        if n > 0:
+            _lib.check(self._lib.fwn_grad_norm(self.g.data_ptr() + 4 * lo, n, gscale, self._partial.data_ptr(),
+                                               self._gnorm.data_ptr(), st), "fwn_grad_norm")
+        else:
+            self._gnorm.zero_()
+        sq = (self._gnorm.double() ** 2)
+        if sq.is_cuda and dist.get_backend(self.group) == "gloo":
+            sq = sq.cpu()
+        dist.all_reduce(sq, group=self.group)
+        self._gnorm.copy_(sq.sqrt().to(self._gnorm.dtype))
+        lr = learning_rate(self.global_step)
+        self.global_step += 1
+        if n > 0:
+            _lib.check(self._lib.fwn_clip_adam(self.w.data_ptr() + 4 * lo, self.g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
+                                               self.v.data_ptr() + 4 * lo, n, self._gnorm.data_ptr(), gscale, self.clip, lr,
+                                               self.global_step, self.b1, self.b2, self.eps, st), "fwn_clip_adam")
+        gather_from_owners(self.w, self.group)
+        return self._gnorm
+
     # -- the same update split for a recorded step: ``record_update`` puts the two launches on the current
     # (capturing) stream with the rate read from device memory; ``advance`` is called before every replay.
     def record_update(self, loss_scale=1.0):
         import torch
         import torch.distributed as dist
+        if self.exchange == "zero1":
+            raise NotImplementedError("the recorded (hipGraph) step runs the all-reduce exchange; exchange='zero1' is eager only")
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
         gscale = 1.0 / (world * float(loss_scale))
         st = torch.cuda.current_stream(torch.device(self.device)).cuda_stream

@@ -724,7 +724,8 @@ class Trainer:
         import os
         from .optim import DataParallelAdam
         self.hp, self.device = hparams, device
-        self.opt = DataParallelAdam(hparams, params, device, group=group, grad_reduce_dtype=getattr(hparams, "grad_reduce_dtype", "fp32"))
+        self.opt = DataParallelAdam(hparams, params, device, group=group, grad_reduce_dtype=getattr(hparams, "grad_reduce_dtype", "fp32"),
+                                    exchange=getattr(hparams, "grad_exchange", "allreduce"))
         self.engine = GradEngine(hparams, device)
         if graph is None:
             graph = os.environ.get("FWN_TRAIN_GRAPH", "1") != "0"
@@ -755,7 +756,7 @@ class Trainer:
 
     def step(self, x, c):
         """-> (loss, log_p, logdet, grad_norm) device scalars; the masters are updated in place."""
-        if self.graph:
+        if self.graph and self.opt.exchange == "allreduce":     # (the sharded exchange is eager only: optim.record_update)
             return self._step_recorded(x, c)
         return self._step_eager(x, c)
 
