@@ -14,7 +14,10 @@ _ISA = {}
 # (unit, extra flags): every kernel translation unit of libfwn.so, and the diagnostic -DFWN_PS_STAMP build of the one-launch flow
 # (flow_persist.hip - weights, P tile and plane tiles by LDS-DMA in flight across a barrier, parks overlaying the
 # weight regions, ds_reads kept three k-steps ahead - was the one unit the checks skipped)
-UNITS = (("flow_kernels", ()), ("train_kernels", ()), ("aux_kernels", ()), ("flow_persist", ()), ("flow_persist", ("-DFWN_PS_STAMP",)))
+# round 6: gate_rs.hip (the register-streamed gate left flow_kernels.hip) and tail_rs.hip (the register-streamed tail: LDS-DMA
+# AND weight loads from inline asm, every wait hand-counted)
+UNITS = (("flow_kernels", ()), ("gate_rs", ()), ("tail_rs", ()), ("train_kernels", ()), ("aux_kernels", ()), ("flow_persist", ()),
+         ("flow_persist", ("-DFWN_PS_STAMP",)))
 
 
 def _makefile_flags():
@@ -30,14 +33,24 @@ def _makefile_flags():
 
 
 def _isa(unit, tmp_path_factory):
-    """(<unit>, extra flags) -> gfx950 ISA, once per session (flow_kernels.hip: four minutes of hipcc)."""
-    if unit not in _ISA:
-        name, extra = unit
-        out = tmp_path_factory.mktemp("isa") / (name + ".s")
-        subprocess.run([HIPCC] + _makefile_flags() + list(extra) + ["-S", "--cuda-device-only", "-c", os.path.join(CSRC, name + ".hip"), "-o", str(out)],
-                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        assert any(True for _ in open(str(out))), out
-        _ISA[unit] = str(out)
+    """(<unit>, extra flags) -> gfx950 ISA, once per session.  Every unit is compiled on the first call, four at a time (the two
+    big ones - flow_kernels.hip, gate_rs.hip - take two minutes of hipcc each)."""
+    if not _ISA:
+        from concurrent.futures import ThreadPoolExecutor
+        flags = _makefile_flags()
+        root = tmp_path_factory.mktemp("isa")
+
+        def build(u):
+            name, extra = u
+            out = root / ("%s%s.s" % (name, "_" + "".join(c for c in "".join(extra) if c.isalnum()) if extra else ""))
+            subprocess.run([HIPCC] + flags + list(extra) + ["-S", "--cuda-device-only", "-c", os.path.join(CSRC, name + ".hip"), "-o", str(out)],
+                           check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            assert os.path.getsize(str(out)) > 0, out
+            return u, str(out)
+
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            for u, path in ex.map(build, UNITS):
+                _ISA[u] = path
     return _ISA[unit]
 
 
@@ -52,7 +65,9 @@ def test_no_register_is_touched_while_an_asm_load_into_it_is_in_flight(tmp_path_
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_async_loads as chk
     for unit in UNITS:       # round 5: the training and auxiliary kernels too (train_kernels.hip runs the same LDS-DMA rings)
-        flagged = [(name, rep[:2]) for name, body in chk.kernels(_isa(unit, tmp_path_factory)) for rep in [chk.check(name, body)] if rep]
+        ks = list(chk.kernels(_isa(unit, tmp_path_factory)))
+        assert ks, ("no kernel found in the ISA of", unit)
+        flagged = [(name, rep[:2]) for name, body in ks for rep in [chk.check(name, body)] if rep]
         assert not flagged, (unit, flagged[:3])
     body = ["\tbuffer_load_dwordx4 v[0:3], v9, s[0:3], s4 offen offset:0\n", "\tbuffer_load_dwordx4 v[4:7], v9, s[0:3], s4 offen offset:1024\n",
             "\ts_cbranch_vccz .LBB0_1\n", "\tv_mov_b64_e32 v[10:11], v[0:1]\n", "\ts_waitcnt vmcnt(1)\n", ".LBB0_1:\n",
@@ -83,7 +98,9 @@ def test_no_ring_barrier_is_crossed_with_lds_reads_in_flight(tmp_path, tmp_path_
     import check_barrier_lgkm as chk
     for unit in UNITS:
         out = _isa(unit, tmp_path_factory)
-        flagged = [(name, rep) for name, body in chk.kernels(str(out)) for rep in [chk.check(name, body)] if rep]
+        ks = list(chk.kernels(str(out)))
+        assert ks, ("no kernel found in the ISA of", unit)
+        flagged = [(name, rep) for name, body in ks for rep in [chk.check(name, body)] if rep]
         assert not flagged, (unit, flagged[:3])
     # the checker on a hand-made body: reads in flight at the barrier, a refill behind it
     body = ["\tds_read_b128 v[0:3], v4\n", "\ts_waitcnt vmcnt(4)\n", "\ts_barrier\n",
