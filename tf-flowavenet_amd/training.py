@@ -799,6 +799,13 @@ class Trainer:
                     def cut(i):
                         if world == 1 and i >= 0 and not self.opt.force_collectives:
                             return
+                        if i == -1 and segs and segs[-1][1] == 0:
+                            # fwn_train_loss_and_grads reports block 0 and then the up-sampling convs (-1) back to back - block 0 is
+                            # joined behind the up-sampling backward since round 5, nothing is enqueued between the two hooks
+                            # (csrc/train_api.hip: join_pending, then the -1 hook) - so there is nothing to cut: no empty
+                            # hipGraph segment, only the exchange of the up-sampling range to start
+                            segs.append((None, -1))
+                            return
                         cur[0].capture_end()
                         segs.append((cur[0], i))
                         cur[0] = torch.cuda.CUDAGraph()
@@ -834,7 +841,8 @@ class Trainer:
                 for w in works:
                     if w is not None:
                         w.wait()
-            g.replay()
+            if g is not None:
+                g.replay()
             if i is not None and self.exchange:
                 lo, hi = ranges["upsample" if i < 0 else i]
                 works.append(self.opt.allreduce_range(lo, hi))
