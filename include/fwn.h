@@ -271,7 +271,6 @@ int64_t fwn_flow_persist_sync_bytes(int M, int L);
 int fwn_flow_run_persist(const fwn_flow_desc* d, int64_t B, int64_t T, float* xa, float* xb, void* h0, void* h1, void* o,
                          const float* P, float* partial, int inverse, void* sync, void* stream);
 int fwn_flow_persist_status(const void* sync, void* stream);
-
 /* ---- process-wide developer options (replaces the environment variables the launch path read in round 4) ----
  * name: "rs_persist" (-1 auto, 0 / 1: the register-streamed gate's persistent form off / on); "persist_spin_us" (bound of the
  * one-launch flow's dependency spins in microseconds, 0 = the default 2 s: tests shorten it to provoke a give-up).  Returns the previous value,
@@ -473,6 +472,10 @@ int fwn_model_forward_init(const fwn_model_desc* m, int64_t B, int64_t T, const 
 /* z [B][T] fp32, mel -> x_out [B][T] fp32. */
 int fwn_model_reverse(const fwn_model_desc* m, int64_t B, int64_t T, const float* z, const float* mel,
                       void* workspace, size_t workspace_bytes, float* x_out, void* stream);
+/* The same question for a whole-model call (0.3.20): the per-flow sync blocks of fwn_model_forward / fwn_model_reverse live inside
+ * their workspace.  After a pass with the same (m, B, T, workspace): 0 = no one-launch flow gave up, > 0 = the give-up code of the
+ * first that did (log_p / logdet / the waveform are NaN then: retry, e.g. with fwn_model_desc.persist_mode = 1).  Synchronises. */
+int fwn_model_persist_status(const fwn_model_desc* m, int64_t B, int64_t T, const void* workspace, void* stream);
 
 /* ---- training: loss = -(log_p + logdet) (train.py:56-60) and its gradient with respect to every trainable tensor
  * (the one tf.gradients call of train.py:63-66) for one batch, in ONE call: training forward with what the backward

@@ -947,8 +947,9 @@ def test_one_launch_flow_that_gives_up_waiting_returns_nans_and_says_so(full_mod
     """A bounded spin of the one-launch flow that gives up must not pass silently: with the bound shortened to 1 us
     (fwn_set_option("persist_spin_us")) consumers give up long before their producers publish; the call then returns
     (no hang), fwn_flow_persist_status reports the give-up word, and the flow's outputs - plane elements and log-det partials -
-    are NaN, so that the whole-model calls built on it return NaN for log_p / logdet / the waveform, never a wrong number.  With the
-    default bound restored the same call is clean again."""
+    are NaN, so that the whole-model calls built on it return NaN for log_p / logdet / the waveform, never a wrong number - and
+    fwn_model_persist_status (FloWaveNet.persist_status) says which pass it was.  With the default bound restored the same call is
+    clean again."""
     hp, model, x, c, z = full_model
     lib = _lib.load()
     blk, b, T = 5, 3, 16128
@@ -990,13 +991,18 @@ def test_one_launch_flow_that_gives_up_waiting_returns_nans_and_says_so(full_mod
     old = lib.fwn_set_option(b"persist_spin_us", 1)
     try:
         lp, ld = model.forward(xs, cs)
+        st_fwd = model.persist_status(1, T)                   # fwn_model_persist_status: the give-up word of the pass (round 6)
         wav = model.reverse(zs, cs)
+        st_inv = model.persist_status(1, T)
         torch.cuda.synchronize()
     finally:
         lib.fwn_set_option(b"persist_spin_us", old)
     assert not np.isfinite(float(lp) + float(ld)) and not bool(torch.isfinite(wav).all())
+    assert st_fwd > 0 and st_inv > 0, (st_fwd, st_inv)
     lp, ld = model.forward(xs, cs)
+    assert model.persist_status(1, T) == 0
     assert np.isfinite(float(lp)) and np.isfinite(float(ld)) and bool(torch.isfinite(model.reverse(zs, cs)).all())
+    assert model.persist_status(1, T) == 0
 
 
 def test_full_size_inverse_is_deterministic_and_bounded(full_model):

@@ -223,6 +223,7 @@ SIGNATURES = {
     "fwn_train_workspace_bytes": (C.c_size_t, [C.POINTER(TrainDesc), i64, i64]),
     "fwn_train_loss_and_grads": (C.c_int, [C.POINTER(TrainDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, BLOCK_DONE_FN, vp, vp]),
     "fwn_model_reverse": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp, vp, C.c_size_t, vp, vp]),
+    "fwn_model_persist_status": (C.c_int, [C.POINTER(ModelDesc), i64, i64, vp, vp]),
 }
 
 _lib = None

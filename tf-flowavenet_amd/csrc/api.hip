@@ -952,6 +952,28 @@ static int record_block_event(const fwn_model_desc* m, int k, hipStream_t st) {
     return hipEventRecord((hipEvent_t)m->block_events[k], st) != hipSuccess;
 }
 
+// Whether any one-launch flow of the LAST pass run in `workspace` (fwn_model_forward / fwn_model_reverse with the same m, B, T)
+// gave up a bounded dependency wait (its outputs are NaN then: never silently wrong, but the pass itself returned FWN_OK):
+// 0 = none, > 0 = the give-up code of the first such flow (1 + the stage that waited).  Synchronises the stream.  ADVICE r5: the
+// per-flow sync blocks live inside the workspace, out of reach of fwn_flow_persist_status.
+int fwn_model_persist_status(const fwn_model_desc* m, int64_t B, int64_t T, const void* workspace, void* stream) {
+    int rc = check_model(m, B, T);
+    if (rc) return rc;
+    REQUIRE(workspace, "fwn_model_persist_status: null workspace");
+    const Carve c = carve(m, B, T);
+    if (!c.sync_bytes) return 0;
+    const int nf = m->n_block * m->n_flow;
+    unsigned w[1024];
+    REQUIRE(nf <= 1024, "fwn_model_persist_status: more than 1024 flows");
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+        hipMemcpy2D(w, sizeof(unsigned), (const char*)workspace + c.sync + sizeof(unsigned), c.sync_stride, sizeof(unsigned), (size_t)nf,
+                    hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(FWN_ERR_HIP, "fwn_model_persist_status: copy failed");
+    for (int k = 0; k < nf; ++k)
+        if (w[k]) return (int)w[k];
+    return 0;
+}
+
 static int model_forward_impl(const fwn_model_desc* m, int64_t B, int64_t T, const float* x, const float* mel,
                               void* workspace, size_t workspace_bytes, float* out2, float* z_planes, int init,
                               fwn_reduce_fn reduce, void* user, void* stream) {

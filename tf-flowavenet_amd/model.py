@@ -144,6 +144,14 @@ class FloWaveNet:
         import torch
         return torch.cuda.current_stream(torch.device(self._device)).cuda_stream
 
+    def persist_status(self, b, t):
+        """0 unless a one-launch flow (csrc/flow_persist.h) of the last ``forward`` / ``reverse`` with batch ``b`` and length ``t`` on
+        the current stream gave up a bounded dependency wait (a pass that was only delayed - a preempted queue, a debugger -
+        can: its log_p / logdet / waveform are NaN then).  > 0: the give-up code; retry, or build the model with
+        ``persist_mode=1``.  Synchronises the stream (``fwn_model_persist_status``)."""
+        ws, _ = self._workspace(b, t)
+        return int(self._lib.fwn_model_persist_status(C.byref(self._packed.model_desc), b, t, ws, self._stream()))
+
     # ------------------------------------------------------------------ reference surface
     def forward(self, x, c, g=None, return_z=False):
         """x [B,T,1], c [B,T/hop,num_mels] -> (log_p, logdet) fp32 0-dim tensors (model.py:317-347)."""
