@@ -723,6 +723,60 @@ def test_register_streamed_tail_equals_the_register_chained_tail_bit_for_bit(ful
         assert abs(s1 - s0) <= 1e-5 * abs(s0) + 1e-3, (s1, s0)
 
 
+@pytest.mark.parametrize("blk,b,ti", [(1, 8, 4032), (2, 8, 2016), (3, 8, 1008), (0, 5, 8064), (4, 8, 504)])
+def test_register_streamed_kernels_beside_a_bandwidth_hog_and_a_second_instance(full_model, blk, b, ti):
+    """The hand-counted waits of the register-streamed tail (csrc/tail_rs.h: every weight load, LDS-DMA piece and plane load is
+    issued from inline asm and waited for with a counted s_waitcnt vmcnt(N) from a compile-time walk) and of the 64-row gate
+    only matter when loads are slow: the kernels run beside a copy stream that saturates HBM and beside a second instance of
+    themselves on another stream, and every launch must reproduce the quiet result bit for bit (a wait one operation short
+    multiplies by a stale ring stage or reads a slice before it landed: wrong tiles that come and go with the load).  All
+    three tile heights of the tail, chained with the next flow's front conv where Ch <= 8; the gate at 6 144 <= M < 12 288."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    L, ch, m = hp.n_layer, 1 << blk, b * ti
+    d, nx = model._packed.flow_descs[blk * hp.n_flow + 2], model._packed.flow_descs[blk * hp.n_flow + 3]
+    assert d.Wts and m >= lib.fwn_tail_stream_rows()
+    rng = np.random.default_rng(blk + b)
+    o = torch.from_numpy((rng.random((L, m, 256)) * 0.8).astype(np.float32)).cuda().to(torch.bfloat16)
+    planes = [torch.from_numpy(rng.standard_normal((m, ch)).astype(np.float32)).cuda() for _ in range(2)]
+    h = torch.from_numpy(rng.standard_normal((m, 256)).astype(np.float32) * 0.5).cuda().to(torch.bfloat16)
+    ca = torch.from_numpy(rng.random((m, d.cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    front = ch <= 8
+    gate = bool(d.Wgs[1]) and m >= lib.fwn_gate_stream_rows() and ti >= 256
+    side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+
+    def run(stream):
+        with torch.cuda.stream(stream):
+            st = stream.cuda_stream
+            pb = [q.clone() for q in planes]
+            xb_out = torch.full((m, ch), 7.0, device="cuda")
+            h_new = torch.full((m, 256), 9.0, device="cuda", dtype=torch.bfloat16)
+            part = torch.zeros(lib.fwn_tail_partials_chained(m, ch, 1), device="cuda")
+            _lib.check(lib.fwn_tail_chained(C.byref(d), C.byref(nx) if front else None, o.data_ptr(), pb[0].data_ptr(), pb[1].data_ptr(),
+                                            xb_out.data_ptr(), h_new.data_ptr() if front else None, part.data_ptr(), m, ti, 0, None, st), "fwn_tail_chained")
+            og = torch.full((m, 256), 5.0, device="cuda", dtype=torch.bfloat16)
+            if gate:
+                _lib.check(lib.fwn_gate(C.byref(d), 1, h.data_ptr(), ca.data_ptr(), None, og.data_ptr(), m, ti, st), "fwn_gate")
+        return pb[0], xb_out, h_new, part, og
+
+    main = torch.cuda.current_stream()
+    want = run(main)
+    torch.cuda.synchronize()
+    for rep in range(16):
+        if rep >= 4:                                  # a bandwidth hog beside the launches
+            with torch.cuda.stream(side):
+                big[: 1 << 27].copy_(big[1 << 27:], non_blocking=True)
+        other = run(side2) if rep % 2 else None      # a second instance of the same launches on another stream
+        got = run(main)
+        torch.cuda.synchronize()
+        for k, (a_, b_) in enumerate(zip(got, want)):
+            assert torch.equal(a_, b_), (rep, k, int((a_ != b_).sum()))
+        if other is not None:
+            for k, (a_, b_) in enumerate(zip(other, want)):
+                assert torch.equal(a_, b_), (rep, "second stream", k)
+
+
 FLOW_CASES = [(0, 13, 1000), (0, 26, 1000), (1, 7, 1000), (3, 9, 700), (5, 4, 200), (7, 3, 70)]
 
 
