@@ -109,3 +109,31 @@ def test_no_ring_barrier_is_crossed_with_lds_reads_in_flight(tmp_path, tmp_path_
     assert len(rep) == 1 and rep[0][1] == 1 and rep[0][3] is not None
     body.insert(1, "\ts_waitcnt lgkmcnt(0)\n")
     assert chk.check("k", body) == []
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_no_packed_fp32_arithmetic_takes_its_low_half_from_src1s_high_dword(tmp_path_factory):
+    """tools/check_packed_f32.py over every unit: no v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 with `op_sel:[0,1...]`.
+    Round 6 root-caused the SLP co-residency failure (tools/probe/slp_coresidency.hip,
+    profiles/r06_slp_coresidency.txt): with that swizzle lanes 48-63 compute the low half as if src1's high dword were 0 while
+    waves of another kernel issue bf16 MFMAs on the same CU.  hipcc's SLP vectoriser emits the form for a broadcast operand
+    (front_valu_kernel: 72 instructions in the vectorised build, none anywhere else), the build has -fno-slp-vectorize, and this
+    check covers hand-written f32x2 code and the next compiler.  The forms the product does carry (`op_sel_hi:[1,0]`, pair *
+    scalar) measured clean.  The checker must still see the failing form, and must not flag the clean ones."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_packed_f32 as chk
+    assert "-fno-slp-vectorize" in _makefile_flags()
+    for unit in UNITS:
+        ks = list(chk.kernels(_isa(unit, tmp_path_factory)))
+        assert ks, ("no kernel found in the ISA of", unit)
+        flagged = [(name, rep[:2]) for name, body in ks for rep in [chk.check(name, body)] if rep]
+        assert not flagged, (unit, flagged[:3])
+    body = ["\tv_pk_mul_f32 v[6:7], v[8:9], v[10:11] op_sel:[0,1] op_sel_hi:[1,1]\n",      # the failing broadcast form
+            "\tv_pk_fma_f32 v[0:1], v[2:3], v[10:11], v[0:1] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n",
+            "\tv_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]\n",
+            "\tv_pk_mul_f32 v[4:5], v[0:1], 0.5 op_sel_hi:[1,0]\n",                       # clean: pair * scalar
+            "\tv_pk_mul_f32 v[4:5], v[0:1], v[2:3] op_sel:[1,0]\n",                        # clean: the commuted broadcast
+            "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,0,1]\n",              # clean: the addend swizzled
+            "\tv_pk_add_f32 v[0:1], v[2:3], v[4:5]\n", "\tv_pk_mov_b32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]\n",
+            "\tv_pk_mul_f16 v0, v1, v2 op_sel:[0,1]\n", "\ts_endpgm\n"]
+    assert [i for i, _ in chk.check("k", body)] == [0, 1, 2]
