@@ -1000,8 +1000,13 @@ void fwn_launch_res(const void* o, const void* hin, const void* W, const float* 
 // ---- hoisted conditioning: how many K splits, and the fixed-order sum of their partial outputs ----
 // nz (flow, layer) matrices per launch.  With a workgroup or less per two CUs and at least 8 chunks per split, the K range
 // is dealt over up to 8 workgroups (B = 1: M = 63 rows against K = 10240 at the last block).
+// Round 6: 257 .. 512 rows against K >= 8192 (the last block of the 8-clip pass: 504 rows x 10240) take 256 x 128 tiles with the K
+// range halved - 192 workgroups either way, but half the operand bytes per MFMA of the 128 x 128 tile: 109 -> 90 us
+// (tools/probe/cond_bench.py; profiles/r06_notes.md section 7).
+static bool cond_wide_split(int M, int kcpad) { return M > 256 && M <= 512 && kcpad >= 8192; }
 int fwn_cond_nsplit(int M, int nz, int kcpad) {
     const int base = ((M + 63) / 64) * 4 * nz;
+    if (FWN_TUNE(FWN_COND_WIDE, 1) && cond_wide_split(M, kcpad)) return 2;
     if (base >= FWN_TUNE(FWN_COND_BASE, 128)) return 1;
     int ns = 1;
     while (ns < 8 && base * ns * 2 <= FWN_TUNE(FWN_COND_FILL, 256) && kcpad / 64 / (ns * 2) >= 8) ns *= 2;
@@ -1057,16 +1062,14 @@ void fwn_launch_cond2(const void* ca, const void* ca_odd, const void* Wc_base, f
     CondBatch cb{(const bf16*)ca, (const bf16*)ca_odd, (const bf16*)Wc_base, P_base, w_stride, p_stride, flow0, flow_step, L,
                  M, cin, kcpad, part_base, part_stride, nsplit > 1 ? nsplit : 1};
     const int nz = nflow * L;                                    // matrices of this launch
-    if (cb.nsplit > 1) {        // only ever with few rows: the smallest tile
-        hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(((M + 63) / 64) * 4, nz, cb.nsplit), dim3(256), 0, st, cb, 4);
-        return;
-    }
-    const int t = FWN_TUNE(FWN_COND_TILE, -1) >= 0 ? FWN_TUNE(FWN_COND_TILE, -1) : fwn_cond_tile(M, nz, nullptr);
-    const int gx = ((M + kCondBM[t] - 1) / kCondBM[t]) * (512 / kCondBN[t]);
-    if (t == 0) hipLaunchKernelGGL((cond_batch_kernel<256, 256, 4, 4, 64, 2>), dim3(gx, nz), dim3(1024), 0, st, cb, 2);
-    else if (t == 1) hipLaunchKernelGGL((cond_batch_kernel<256, 128, 8, 2, 64, 3>), dim3(gx, nz), dim3(1024), 0, st, cb, 4);
-    else if (t == 2) hipLaunchKernelGGL((cond_batch_kernel<128, 128, 2, 2, 64, 3>), dim3(gx, nz), dim3(256), 0, st, cb, 4);
-    else hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), dim3(gx, nz), dim3(256), 0, st, cb, 4);
+    // a split K range: the smallest tile (few rows), 256 x 128 for the wide split above
+    const int t = cb.nsplit > 1 ? (FWN_TUNE(FWN_COND_SPLIT_TILE, -1) >= 0 ? FWN_TUNE(FWN_COND_SPLIT_TILE, -1) : cond_wide_split(M, kcpad) ? 1 : 3)
+                                : FWN_TUNE(FWN_COND_TILE, -1) >= 0 ? FWN_TUNE(FWN_COND_TILE, -1) : fwn_cond_tile(M, nz, nullptr);
+    const dim3 grid(((M + kCondBM[t] - 1) / kCondBM[t]) * (512 / kCondBN[t]), nz, cb.nsplit);
+    if (t == 0) hipLaunchKernelGGL((cond_batch_kernel<256, 256, 4, 4, 64, 2>), grid, dim3(1024), 0, st, cb, 2);
+    else if (t == 1) hipLaunchKernelGGL((cond_batch_kernel<256, 128, 8, 2, 64, 3>), grid, dim3(1024), 0, st, cb, 4);
+    else if (t == 2) hipLaunchKernelGGL((cond_batch_kernel<128, 128, 2, 2, 64, 3>), grid, dim3(256), 0, st, cb, 4);
+    else hipLaunchKernelGGL((cond_batch_kernel<64, 128, 2, 2, 64, 4>), grid, dim3(256), 0, st, cb, 4);
 }
 void fwn_launch_cond(const void* ca, const void* Wc_base, float* P_base, long w_stride, long p_stride,
                      int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part_base, long part_stride,
