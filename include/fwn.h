@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define FWN_VERSION 320            /* 0.3.20 (round 6): + fwn_flow_desc.Wts and fwn_tail_stream_bytes / fwn_pack_tail_stream / fwn_tail_stream_rows (the
+#define FWN_VERSION 321            /* 0.3.21 (round 6): + fwn_model_desc.cond_stream (appended) and fwn_cond_stream* / fwn_pack_cond_stream (the register-streamed
+                                    * conditioning projection, csrc/cond_rs.h; additive).  0.3.20 (round 6): + fwn_flow_desc.Wts and fwn_tail_stream_bytes / fwn_pack_tail_stream / fwn_tail_stream_rows (the
                                     * register-streamed tail, csrc/tail_rs.h; additive: a 0.3.10 host that zero-fills its descriptors keeps working);
                                     * fwn_tail_partials / fwn_tail_partials_chained are upper bounds now.  0.3.10 (round 5): + fwn_flow_run_persist / fwn_flow_persist_* (one launch per small-M flow), fwn_model_desc.persist_mode
                                     * (was `reserved`: 0 keeps working), fwn_set_option.  0.3.1: + fwn_gate_clock (additive: a 0.3.0 host keeps working).  0.3.0: fwn_flow_desc gained Wfront3 / kf3 (round 3) and Wgs (round 4), fwn_model_desc
@@ -217,6 +218,21 @@ int fwn_cond_split(const void* ca, const void* Wc_base, float* P_base, int64_t w
                    int flow0, int flow_step, int nflow, int L, int M, int cin, int kcpad, float* part, int64_t part_stride,
                    int nsplit, void* stream);
 int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit, int64_t n, void* stream);
+/* ---- fragment-order conditioning weights (round 6, csrc/cond_rs.h; replaces nothing in the reference: a second packing of the
+ * same [512][kcpad] matrices) for the hoisted projection from fwn_cond_stream_rows() rows on: a workgroup = 128 rows x one whole
+ * matrix, weights streamed to registers, activations staged once in LDS (63 GFLOP of block 4 - 7 of the 8-clip pass in 55 - 65 us
+ * against 76 - 93 for the ring tiles).
+ * fwn_cond_stream_bytes : size of ONE matrix's stream (= the matrix: 512 kcpad 2 bytes), 0 if kcpad is not a multiple of 64
+ * fwn_pack_cond_stream  : nz matrices Wc_base + z w_stride ([512][kcpad] bf16 each) -> out (nz streams back to back)
+ * fwn_cond_stream       : P[j L + l] = ca @ Wc[j][l] for the nflow flows and L layers of a block in one launch (flows with an odd
+ *                         index read ca_odd if given); nsplit > 1: like fwn_cond_split, then fwn_cond_reduce
+ * fwn_cond_stream_splits: the split count the model-level calls use */
+int64_t fwn_cond_stream_bytes(int kcpad);
+int fwn_cond_stream_rows(void);
+int fwn_cond_stream_splits(int M, int nz, int kcpad);
+int fwn_pack_cond_stream(const void* Wc_base, int64_t w_stride, int kcpad, int nz, void* out, void* stream);
+int fwn_cond_stream(const void* ca, const void* ca_odd, const void* Ws, float* P, int nflow, int L, int M, int cin, int kcpad,
+                    float* part, int64_t part_stride, int nsplit, void* stream);
 /* K6'+K7+K8 tail: skip sum, final 1x1, ZeroConv1d, affine coupling, ActNorm, log-det partials
  * (modules.py:175-180,51-56; model.py:86-102,124-141,146-161).  o = [L][M][256].
  * partial (forward only, may be NULL) receives AT MOST fwn_tail_partials(M) partial sums (how many depends on the kernel
@@ -452,6 +468,10 @@ typedef struct fwn_model_desc {
      * calls record [k] on `stream` in front of the first launch of the k-th block they run (forward: block k, reverse: block
      * n_block - 1 - k) and [n_block] behind the last launch of the last one. */
     void* const* block_events;
+    /* Per block: NULL, or the fragment streams (fwn_pack_cond_stream) of the block's n_flow * n_layer conditioning matrices in
+     * (flow, layer) order: the hoisted projection of the block then runs the register-streamed kernel from fwn_cond_stream_rows()
+     * rows on (0.3.21; a 0.3.20 host that zero-fills the descriptor keeps the ring tiles). */
+    const void* cond_stream[16];
 } fwn_model_desc;
 
 size_t fwn_workspace_bytes(const fwn_model_desc* m, int64_t B, int64_t T);

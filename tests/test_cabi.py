@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version(lib):
-    assert lib.fwn_version() == 320
+    assert lib.fwn_version() == 321
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -102,7 +102,7 @@ def test_plain_c_program_binds_the_abi(lib, tmp_path):
     exe = _build_c_consumer(tmp_path)
     out = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
-    assert "C ABI ok: version 320" in out.stdout
+    assert "C ABI ok: version 321" in out.stdout
 
 
 @pytest.mark.gpu

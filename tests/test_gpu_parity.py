@@ -514,6 +514,49 @@ def test_conditioning_split_k_equals_the_one_pass_projection(full_model, blk, m)
     assert lib.fwn_cond_split(ca.data_ptr(), d0.Wc[0], P1.data_ptr(), 512 * kc, m * 512, 0, 1, nf, L, m, cin, kc, None, 0, 4, st) == -1
 
 
+@pytest.mark.parametrize("blk,m,forced", [(4, 4032, 0), (5, 2016, 0), (6, 1008, 0), (7, 504, 0), (7, 504, 1), (6, 1000, 3), (5, 390, 2), (4, 4000, 2),
+                                          (7, 2016, 0), (3, 2016, 0)])
+def test_streamed_conditioning_equals_the_ring_projection_bit_for_bit(full_model, blk, m, forced):
+    """fwn_cond_stream (csrc/cond_rs.h: weights from their fragment streams to registers, 128- / 96- / 64-row tiles, the K range
+    dealt over workgroups) against fwn_cond_split on the same operands with the same split count: the same MFMAs on the same
+    fragments in the same order, so `==` - whole tiles and ragged row counts, every tile height the plan picks, split counts the
+    plan picks and forced ones, both conditioning planes (flows with an odd index read the other one), NaN-filled outputs (every
+    element is written), and twice (bit-reproducible)."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    d0 = model._packed.flow_descs[blk * hp.n_flow]
+    L, nf, cin, kc = hp.n_layer, hp.n_flow, d0.cin, d0.kcpad
+    nz = nf * L
+    st = torch.cuda.current_stream().cuda_stream
+    assert m >= lib.fwn_cond_stream_rows() and lib.fwn_cond_stream_bytes(kc) == 512 * kc * 2
+    rng = np.random.default_rng(blk * 100 + m)
+    ca = torch.from_numpy(rng.standard_normal((2, m, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    ws = torch.empty(nz * 512 * kc, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.fwn_pack_cond_stream(d0.Wc[0], 512 * kc, kc, nz, ws.data_ptr(), st), "fwn_pack_cond_stream")
+    ns = forced or int(lib.fwn_cond_stream_splits(m, nz, kc))
+    assert 1 <= ns <= kc // 64
+    ref = torch.full((nf, L, m, 512), float("nan"), device="cuda")
+    rpart = torch.full((max(ns - 1, 1), nf, L, m, 512), float("nan"), device="cuda")
+    for g in range(2):           # the ring form takes one parity group of flows per call
+        _lib.check(lib.fwn_cond_split(ca[g].data_ptr(), d0.Wc[0], ref.data_ptr(), 512 * kc, m * 512, g, 2, (nf - g + 1) // 2, L, m, cin, kc,
+                                      rpart.data_ptr(), ref.numel(), ns, st), "fwn_cond_split")
+    _lib.check(lib.fwn_cond_reduce(ref.data_ptr(), rpart.data_ptr(), ref.numel(), ns, ref.numel(), st), "fwn_cond_reduce")
+    outs = []
+    for rep in range(2):
+        P = torch.full((nf, L, m, 512), float("nan"), device="cuda")
+        part = torch.full((max(ns - 1, 1), nf, L, m, 512), float("nan"), device="cuda")
+        _lib.check(lib.fwn_cond_stream(ca[0].data_ptr(), ca[1].data_ptr(), ws.data_ptr(), P.data_ptr(), nf, L, m, cin, kc,
+                                       part.data_ptr(), P.numel(), ns, st), "fwn_cond_stream")
+        _lib.check(lib.fwn_cond_reduce(P.data_ptr(), part.data_ptr(), P.numel(), ns, P.numel(), st), "fwn_cond_reduce")
+        outs.append(P)
+    torch.cuda.synchronize()
+    assert not torch.isnan(outs[0]).any()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], ref)
+    lib_ok = lib.fwn_cond_stream(ca[0].data_ptr(), None, ws.data_ptr(), outs[0].data_ptr(), nf, L, 100, cin, kc, None, 0, 1, st)
+    assert lib_ok == -1          # below fwn_cond_stream_rows(): refused with a message, nothing launched
+
+
 @pytest.mark.parametrize("blk,m", [(0, 50000), (0, 13000), (6, 13000), (7, 12500), (2, 7000), (7, 7000), (3, 2000), (5, 700), (6, 300), (7, 150)])
 def test_tail_train_keeps_s_u_z_and_equals_the_plain_tail(full_model, blk, m):
     """fwn_tail_train (the tail as the training step's forward half runs it) at every tail variant - 256-row and 128-row

@@ -15,8 +15,9 @@ _ISA = {}
 # (flow_persist.hip - weights, P tile and plane tiles by LDS-DMA in flight across a barrier, parks overlaying the
 # weight regions, ds_reads kept three k-steps ahead - was the one unit the checks skipped)
 # round 6: gate_rs.hip (the register-streamed gate left flow_kernels.hip) and tail_rs.hip (the register-streamed tail: LDS-DMA
-# AND weight loads from inline asm, every wait hand-counted)
-UNITS = (("flow_kernels", ()), ("gate_rs", ()), ("tail_rs", ()), ("train_kernels", ()), ("aux_kernels", ()), ("flow_persist", ()),
+# AND weight loads from inline asm, every wait hand-counted); cond_rs.hip (the register-streamed conditioning projection: the same, in a
+# run-time loop over pairs of items)
+UNITS = (("flow_kernels", ()), ("gate_rs", ()), ("tail_rs", ()), ("cond_rs", ()), ("train_kernels", ()), ("aux_kernels", ()), ("flow_persist", ()),
          ("flow_persist", ("-DFWN_PS_STAMP",)))
 
 

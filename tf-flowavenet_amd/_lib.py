@@ -50,6 +50,7 @@ class ModelDesc(C.Structure):
         ("chain_mode", i32),
         ("persist_mode", i32),
         ("block_events", C.POINTER(vp)),
+        ("cond_stream", vp * 16),
     ]
 
 
@@ -174,6 +175,11 @@ SIGNATURES = {
     "fwn_cond_split": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64,
                                  C.c_int, vp]),
     "fwn_cond_reduce": (C.c_int, [vp, vp, i64, C.c_int, i64, vp]),
+    "fwn_cond_stream_bytes": (i64, [C.c_int]),
+    "fwn_cond_stream_rows": (C.c_int, []),
+    "fwn_cond_stream_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "fwn_pack_cond_stream": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, vp]),
+    "fwn_cond_stream": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64, C.c_int, vp]),
     "fwn_tail_partials": (C.c_int, [C.c_int]),
     "fwn_tail_partials_desc": (C.c_int, [C.POINTER(FlowDesc), C.c_int, C.c_int]),
     "fwn_tail": (C.c_int, [C.POINTER(FlowDesc), vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),

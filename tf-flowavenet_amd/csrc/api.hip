@@ -296,6 +296,25 @@ int fwn_cond_reduce(float* P, const float* part, int64_t part_stride, int nsplit
     fwn_launch_cond_reduce(P, part, (long)part_stride, nsplit, (long)n, (hipStream_t)stream);
     return check_launch("fwn_cond_reduce");
 }
+int64_t fwn_cond_stream_bytes(int kcpad) { return (int64_t)fwn_cond_stream_size(kcpad); }
+int fwn_cond_stream_rows(void) { return fwn_cond_stream_min_rows(); }
+int fwn_cond_stream_splits(int M, int nz, int kcpad) { return (M > 0 && nz > 0 && kcpad >= 64) ? fwn_cond_rs_nsplit(M, nz, kcpad) : 1; }
+int fwn_pack_cond_stream(const void* Wc_base, int64_t w_stride, int kcpad, int nz, void* out, void* stream) {
+    REQUIRE(Wc_base && out && nz > 0 && fwn_cond_stream_size(kcpad) != 0 && w_stride >= (int64_t)512 * kcpad && w_stride % 8 == 0,
+            "fwn_pack_cond_stream: bad argument");
+    REQUIRE(((uintptr_t)Wc_base & 15) == 0 && ((uintptr_t)out & 15) == 0, "fwn_pack_cond_stream: 16-byte aligned operands");
+    fwn_launch_cond_stream_pack(Wc_base, (long)w_stride, kcpad, nz, out, (hipStream_t)stream);
+    return check_launch("fwn_pack_cond_stream");
+}
+int fwn_cond_stream(const void* ca, const void* ca_odd, const void* Ws, float* P, int nflow, int L, int M, int cin, int kcpad,
+                    float* part, int64_t part_stride, int nsplit, void* stream) {
+    REQUIRE(ca && Ws && P && nflow > 0 && L > 0, "fwn_cond_stream: null pointer / bad counts");
+    REQUIRE(fwn_cond_rs_ok(M, cin, kcpad, true) && kcpad >= cin, "fwn_cond_stream: no register-streamed kernel for M=%d cin=%d kcpad=%d (fwn_cond_stream_rows)", M, cin, kcpad);
+    REQUIRE(nsplit >= 1 && nsplit * 8 <= kcpad / 64 * 8 && nsplit <= kcpad / 64 && (nsplit == 1 || (part && part_stride >= (int64_t)nflow * L * M * 512)),
+            "fwn_cond_stream: nsplit=%d needs a partial buffer and at most one split per 64-wide chunk", nsplit);
+    fwn_launch_cond_rs(ca, ca_odd, Ws, P, nflow * L, L, M, cin, kcpad, part, (long)part_stride, nsplit, (hipStream_t)stream);
+    return check_launch("fwn_cond_stream");
+}
 
 // 32-row tiles per workgroup of the register-streamed tail when that kernel serves flow d at M rows, else 0
 static int desc_rs_mt(const fwn_flow_desc* d, int M) { return fwn_tail_rs_mt(M, d->L, d->Ch, d->npt, d->Wts != nullptr); }
@@ -750,6 +769,17 @@ static bool hoist_cond(const fwn_model_desc* m, int64_t M, int cin) {
     // the extra launch and the P round trip
     return M < FWN_TUNE(FWN_HOIST_M, 4096) && cin >= FWN_TUNE(FWN_HOIST_CIN, 256);
 }
+// the register-streamed conditioning projection (csrc/cond_rs.h) serves this block at M rows: its stream is given
+static bool block_cond_rs(const fwn_model_desc* m, int blk, int64_t M) {
+    const fwn_flow_desc* f0 = &m->flows[blk * m->n_flow];
+    return blk < 16 && fwn_cond_rs_wanted((int)M, f0->cin, f0->kcpad, m->n_flow * m->n_layer, m->cond_stream[blk] != nullptr);
+}
+// K splits of the block's hoisted conditioning launch (sizes the partial buffer of the workspace, too)
+static int block_cond_nsplit(const fwn_model_desc* m, int blk, int64_t M) {
+    const fwn_flow_desc* f0 = &m->flows[blk * m->n_flow];
+    if (block_cond_rs(m, blk, M)) return fwn_cond_rs_nsplit((int)M, m->n_flow * m->n_layer, f0->kcpad);
+    return fwn_cond_nsplit((int)M, ((m->n_flow + 1) / 2) * m->n_layer, f0->kcpad);
+}
 
 // whether block blk's flows run as one launch each (flow_persist.h)
 static bool persist_block(const fwn_model_desc* m, int64_t M, int blk) {
@@ -851,7 +881,7 @@ static Carve carve(const fwn_model_desc* m, int64_t B, int64_t T) {
         if (hoist_cond(m, M, m->flows[i * m->n_flow].cin)) {
             const size_t need = (size_t)m->n_flow * m->n_layer * M * 512 * 4;
             if (need > pbytes) pbytes = need;
-            const size_t sp = (size_t)(fwn_cond_nsplit((int)M, ((m->n_flow + 1) / 2) * m->n_layer, m->flows[i * m->n_flow].kcpad) - 1) * need;
+            const size_t sp = (size_t)(block_cond_nsplit(m, i, M) - 1) * need;
             if (sp > ppart) ppart = sp;
         }
         npart += m->n_flow * tail_partials_max((int)M, m->flows[i * m->n_flow].Ch);
@@ -903,12 +933,15 @@ static void run_cond_groups(const fwn_model_desc* m, int blk, int64_t M, const i
     const size_t half = m->num_mels / 2;
     const size_t plane_elems = (size_t)B * T * half;
     const long pn = (long)m->n_flow * m->n_layer * M * 512;          // floats of the block's P matrices
-    const int ns = fwn_cond_nsplit((int)M, ((m->n_flow + 1) / 2) * m->n_layer, f0->kcpad);
+    const int ns = block_cond_nsplit(m, blk, M);
     // even flows of the block read plane parity_of_flow[0], odd flows the other: one launch or one per parity group
     const char* ca0 = ws + c.cplanes + (size_t)parity_of_flow[0] * plane_elems * 2;
     const char* ca1 = ws + c.cplanes + (size_t)parity_of_flow[1] * plane_elems * 2;
     const int nzg = ((m->n_flow + 1) / 2) * m->n_layer;
-    if (m->n_flow > 1 && fwn_cond_merge((int)M, nzg, ns)) {
+    if (block_cond_rs(m, blk, M)) {        // the block's matrices from their fragment streams (csrc/cond_rs.h)
+        fwn_launch_cond_rs(ca0, m->n_flow > 1 ? ca1 : nullptr, m->cond_stream[blk], (float*)(ws + c.P), m->n_flow * m->n_layer, m->n_layer,
+                           (int)M, f0->cin, f0->kcpad, (float*)(ws + c.Ppart), pn, ns, st);
+    } else if (m->n_flow > 1 && fwn_cond_merge((int)M, nzg, ns)) {
         fwn_launch_cond2(ca0, ca1, f0->Wc[0], (float*)(ws + c.P), (long)512 * f0->kcpad, (long)M * 512, 0, 1, m->n_flow,
                          m->n_layer, (int)M, f0->cin, f0->kcpad, (float*)(ws + c.Ppart), pn, ns, st);
     } else {

@@ -48,6 +48,15 @@ void fwn_launch_cond2(const void* ca, const void* ca_odd, const void* Wc_base, f
 // the partial outputs (part: [nsplit - 1][..] laid out like P) into P[0..n)
 int fwn_cond_nsplit(int M, int nz, int kcpad);
 void fwn_launch_cond_reduce(float* P, const float* part, long part_stride, int nsplit, long n, hipStream_t st);
+// register-streamed form (cond_rs.h / cond_rs.hip): whole blocks of nz = nflow * L matrices from their fragment streams
+long fwn_cond_stream_size(int kcpad);
+int fwn_cond_stream_min_rows();
+bool fwn_cond_rs_ok(int M, int cin, int kcpad, bool have_stream);               // the kernel serves the shape
+bool fwn_cond_rs_wanted(int M, int cin, int kcpad, int nz, bool have_stream);   // ... and the model-level calls use it there
+int fwn_cond_rs_nsplit(int M, int nz, int kcpad);
+void fwn_launch_cond_stream_pack(const void* Wc_base, long w_stride, int kcpad, int nz, void* out, hipStream_t st);
+void fwn_launch_cond_rs(const void* ca, const void* ca_odd, const void* Ws, float* P, int nz, int L, int M, int cin, int kcpad,
+                        float* part, long part_stride, int nsplit, hipStream_t st);
 // Chaining the flows of a block (whole-model calls): out_b to a third plane buffer, and the NEXT flow's front conv computed
 // by this tail (csrc/tail_chain.h).  NULL / all-zero = the plain in-place tail.
 struct fwn_tail_chain {

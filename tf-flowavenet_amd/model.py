@@ -27,7 +27,7 @@ from . import _lib, packing, weights
 
 class FloWaveNet:
     def __init__(self, hparams, init=False, scope="FloWaveNet", device="cuda", cond_mode=0, group=None, gate_fp8=None,
-                 persist_mode=None, chain_mode=None, tail_stream=True):
+                 persist_mode=None, chain_mode=None, tail_stream=True, cond_stream=True):
         """persist_mode (default: ``hparams.persist_mode`` if present, else 0): which small-M flows run as ONE launch
         (csrc/flow_persist.h, ``fwn_model_desc.persist_mode``) - 0: those of up to 512 rows, 1: none, 2: wherever the form
         exists.  chain_mode (``fwn_model_desc.chain_mode``): 0 chains the flows of a block, 1 runs every flow on its own.
@@ -35,6 +35,8 @@ class FloWaveNet:
         tail_stream=False leaves the fragment-order copy of Wskip | Wfinal unpacked, so that the tail runs the kernels of
         rounds 2 - 5 everywhere (csrc/tail_chain.h and the N-split ring GEMMs instead of csrc/tail_rs.h): the one-launch flows
         reproduce THOSE bit for bit below 4 097 rows (tests, bench.py's identity check).
+        cond_stream=False leaves the fragment-order copy of the hoisted conditioning's weights unpacked (csrc/cond_rs.h): the
+        ring-tile kernel then runs at every row count (same sums in the same order, other split counts).
         group: the ``torch.distributed`` process group a data-parallel job shards its batch over (None = the
         default group when one is initialised; False: none - a model only one rank builds).  It only matters for ``init=True``: the ActNorm data-dependent
         init then uses the statistics of the GLOBAL batch (moments all-reduced flow by flow) so every rank ends
@@ -58,6 +60,7 @@ class FloWaveNet:
         if self._persist_mode not in (0, 1, 2) or self._chain_mode not in (0, 1):
             raise ValueError("persist_mode must be 0, 1 or 2 and chain_mode 0 or 1")
         self._tail_stream = bool(tail_stream)
+        self._cond_stream = bool(cond_stream)
         self._packed = None
         self._ws = {}
         self._lib = _lib.load()     # fails loudly when libfwn.so is missing
@@ -77,7 +80,8 @@ class FloWaveNet:
             if got != tuple(shape):
                 raise ValueError("parameter %r has shape %r, expected %r" % (name, got, tuple(shape)))
         self._packed = packing.pack_model(params, self._hparams, self._device, self._cond_mode, gate_fp8=self._gate_fp8,
-                                          persist_mode=self._persist_mode, chain_mode=self._chain_mode, tail_stream=self._tail_stream)
+                                          persist_mode=self._persist_mode, chain_mode=self._chain_mode, tail_stream=self._tail_stream,
+                                          cond_stream=self._cond_stream)
         return self
 
     def init_synthetic(self, seed=1234, **kw):

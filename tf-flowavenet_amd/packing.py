@@ -350,7 +350,8 @@ class PackedModel:
 
 
 def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | None" = None,
-               gate_fp8: bool = False, persist_mode: int = 0, chain_mode: int = 0, tail_stream: bool = True) -> PackedModel:
+               gate_fp8: bool = False, persist_mode: int = 0, chain_mode: int = 0, tail_stream: bool = True,
+               cond_stream: bool = True) -> PackedModel:
     """Upload ``params`` (reference layouts, fp32) and run the packing kernels (K10).
     With ``plan`` (params must then be device tensors at stable addresses) the work is recorded into it
     and executed once; ``plan.refresh()`` repeats it after the parameters changed."""
@@ -514,6 +515,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
         pm.weight_bytes += t.numel() * 2
         return t
 
+    cond_blocks = []
     for i in range(hp.n_block):
         ch = 1 << i
         cin = half * (2 << i)
@@ -525,6 +527,7 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
         z_src_n = dev_i32(("zero", i), lambda: zero_src_n(i))
         zsn_host = zero_src_n(i)
         wc_blk = bf16_zeros(hp.n_flow, L, GATE_N, kcpad)     # contiguous: hoisted conditioning
+        cond_blocks.append((i, wc_blk, cin, kcpad))
         for j in range(hp.n_flow):
             fp = flow_prefix(i, j)
             wp = fp + "/WaveNet"
@@ -646,6 +649,16 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
                      exp=np.broadcast_to((rows == 1) | (rows == 2), (2, 4, ch))))
 
     md = pm.model_desc
+    # the hoisted conditioning's weights once more in MFMA-fragment order (csrc/cond_rs.h): blocks whose conditioning can be
+    # hoisted and the streamed kernel is the faster form (K >= 640), packed once - so only without a PackPlan, like the gate's and the tail's streams
+    for i, wc_blk, cin, kcpad in cond_blocks:
+        cs_bytes = int(lib.fwn_cond_stream_bytes(kcpad)) if (plan is None and cond_stream and kcpad >= 640 and i < 16) else 0
+        if cs_bytes:
+            nz = hp.n_flow * L
+            wcs = pm.keep(torch.empty(nz * cs_bytes, dtype=torch.uint8, device=dev))
+            pm.weight_bytes += nz * cs_bytes
+            _lib.check(lib.fwn_pack_cond_stream(wc_blk.data_ptr(), GATE_N * kcpad, kcpad, nz, wcs.data_ptr(), stream), "fwn_pack_cond_stream")
+            md.cond_stream[i] = wcs.data_ptr()
     md.n_block, md.n_flow, md.n_layer, md.num_mels = hp.n_block, hp.n_flow, L, hp.num_mels
     md.n_up = len(hp.upsample_scales)
     if md.n_up > _lib.FWN_MAX_UPSAMPLE:

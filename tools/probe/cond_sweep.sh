@@ -1,4 +1,4 @@
+# sweep of the hoisted conditioning projection at the bench shapes (tuning build: make -C tf-flowavenet_amd/csrc tune)
 export FWN_LIB=tf-flowavenet_amd/csrc/libfwn_tune.so
 echo "== library defaults (product lib)"; FWN_LIB= python tools/probe/cond_bench.py 8
-for t in 0 1 2 3; do echo "== no split, tile $t"; FWN_COND_TILE=$t python tools/probe/cond_bench.py 8 1,1,1,1 12; done
-for t in 0 1 2; do for ns in 2,2,2,2 2,2,4,4 2,3,5,5 2,2,4,8; do echo "== split tile $t nsplit $ns"; FWN_COND_SPLIT_TILE=$t python tools/probe/cond_bench.py 8 $ns 12; done; done
+for mt in 4 3 2; do for ns in 1,1,1,1 1,1,2,4 1,1,2,5 1,2,3,6; do echo "== streamed: tile 32 x $mt rows, nsplit $ns"; FWN_CRS_MT=$mt python tools/probe/cond_bench.py 8 0,0,0,0 12 $ns; done; done
