@@ -822,6 +822,52 @@ def test_register_streamed_kernels_beside_a_bandwidth_hog_and_a_second_instance(
                 assert torch.equal(a_, b_), (rep, "second stream", k)
 
 
+@pytest.mark.parametrize("blk,m,ns", [(4, 4032, 1), (5, 2016, 1), (7, 504, 5), (6, 1008, 2), (5, 1000, 3)])
+def test_streamed_conditioning_beside_a_bandwidth_hog_and_a_second_instance(full_model, blk, m, ns):
+    """The hand-counted waits of the register-streamed conditioning projection (csrc/cond_rs.h: two asm weight loads per k-step
+    into an 8-stage register ring, two asm LDS-DMA pieces per item, `s_waitcnt vmcnt(N)` from CrsCount in a run-time loop) under
+    slow loads: beside a copy stream that saturates HBM and beside a second instance of itself on another stream every launch
+    reproduces the quiet result bit for bit - 128- and 96-row tiles (the plan's) and a forced 64-row-free split, with and without
+    split K ranges."""
+    hp, model, _, _, _ = full_model
+    lib = _lib.load()
+    d0 = model._packed.flow_descs[blk * hp.n_flow]
+    L, nf, cin, kc = hp.n_layer, hp.n_flow, d0.cin, d0.kcpad
+    nz = nf * L
+    rng = np.random.default_rng(blk + m)
+    ca = torch.from_numpy(rng.standard_normal((2, m, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    ws = torch.empty(nz * 512 * kc, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.fwn_pack_cond_stream(d0.Wc[0], 512 * kc, kc, nz, ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "fwn_pack_cond_stream")
+    side, side2 = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    def run(stream):
+        with torch.cuda.stream(stream):
+            st = stream.cuda_stream
+            P = torch.full((nf, L, m, 512), float("nan"), device="cuda")
+            part = torch.full((max(ns - 1, 1), nf, L, m, 512), float("nan"), device="cuda")
+            _lib.check(lib.fwn_cond_stream(ca[0].data_ptr(), ca[1].data_ptr(), ws.data_ptr(), P.data_ptr(), nf, L, m, cin, kc,
+                                           part.data_ptr(), P.numel(), ns, st), "fwn_cond_stream")
+            _lib.check(lib.fwn_cond_reduce(P.data_ptr(), part.data_ptr(), P.numel(), ns, P.numel(), st), "fwn_cond_reduce")
+        return P
+
+    main = torch.cuda.current_stream()
+    want = run(main)
+    torch.cuda.synchronize()
+    assert not torch.isnan(want).any()
+    for rep in range(12):
+        if rep >= 3:
+            with torch.cuda.stream(side):
+                big[: 1 << 27].copy_(big[1 << 27:], non_blocking=True)
+        other = run(side2) if rep % 2 else None
+        got = run(main)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (rep, int((got != want).sum()))
+        if other is not None:
+            assert torch.equal(other, want), (rep, "second stream")
+
+
 FLOW_CASES = [(0, 13, 1000), (0, 26, 1000), (1, 7, 1000), (3, 9, 700), (5, 4, 200), (7, 3, 70)]
 
 
