@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define FWN_VERSION 321            /* 0.3.21 (round 6): + fwn_model_desc.cond_stream (appended) and fwn_cond_stream* / fwn_pack_cond_stream (the register-streamed
-                                    * conditioning projection, csrc/cond_rs.h; additive).  0.3.20 (round 6): + fwn_flow_desc.Wts and fwn_tail_stream_bytes / fwn_pack_tail_stream / fwn_tail_stream_rows (the
+                                    * conditioning projection, csrc/cond_rs.h; additive); fwn_pack_tail_stream_jobs.  0.3.20 (round 6): + fwn_flow_desc.Wts and fwn_tail_stream_bytes / fwn_pack_tail_stream / fwn_tail_stream_rows (the
                                     * register-streamed tail, csrc/tail_rs.h; additive: a 0.3.10 host that zero-fills its descriptors keeps working);
                                     * fwn_tail_partials / fwn_tail_partials_chained are upper bounds now.  0.3.10 (round 5): + fwn_flow_run_persist / fwn_flow_persist_* (one launch per small-M flow), fwn_model_desc.persist_mode
                                     * (was `reserved`: 0 keeps working), fwn_set_option.  0.3.1: + fwn_gate_clock (additive: a 0.3.0 host keeps working).  0.3.0: fwn_flow_desc gained Wfront3 / kf3 (round 3) and Wgs (round 4), fwn_model_desc
@@ -157,6 +157,10 @@ typedef struct fwn_flow_desc {
  *                        use the stream (one ZeroConv pair tile: Ch <= 32). */
 int64_t fwn_tail_stream_bytes(int L);
 int fwn_pack_tail_stream(const void* Wskip, const void* Wfinal, int L, void* out, void* stream);
+/* The same for njobs flows in one launch: `jobs` is a DEVICE array of {Wskip, Wfinal, out} device pointers (a training step
+ * re-packs every flow's stream behind its grouped weight packing: packing.PackPlan). */
+typedef struct fwn_tail_stream_job { const void* Wskip; const void* Wfinal; void* out; } fwn_tail_stream_job;
+int fwn_pack_tail_stream_jobs(const fwn_tail_stream_job* jobs, int njobs, int L, void* stream);
 int fwn_tail_stream_rows(void);
 
 /* ---- fragment-order gate weights (round 4, csrc/gate_rs.h; replaces nothing in the reference: a second packing of the

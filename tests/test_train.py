@@ -667,10 +667,13 @@ def test_two_rank_data_parallel_step_matches_one_process_on_the_whole_batch(tmp_
     assert cos > 0.999 and abs(np.linalg.norm(got) / np.linalg.norm(want) - 1.0) < 2e-2, (cos, np.linalg.norm(got), np.linalg.norm(want))
 
 
-def test_recorded_packing_matches_immediate_packing():
+@pytest.mark.parametrize("t", [256, 4096])
+def test_recorded_packing_matches_immediate_packing(t):
     """Device-resident parameters take the PackPlan path (grouped, transposed packing, refreshed in
     place every step); NumPy parameters the immediate one: same gradients, also after the
-    parameters changed in place."""
+    parameters changed in place.  t = 4096: 4 096 / 2 048 / 1 024 rows per block - the forward half runs the register-streamed
+    tail (csrc/tail_rs.h, SAVE form), whose fragment-order weights the plan re-packs behind the grouped packing of every
+    refresh (fwn_pack_tail_stream_jobs: all flows in one launch) - a stale or mis-ordered stream would show after the change."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from conftest import small_hparams
@@ -678,13 +681,14 @@ def test_recorded_packing_matches_immediate_packing():
     from tf_flowavenet_amd.training import GradEngine
     hp = small_hparams(n_block=3, n_flow=2, n_layer=2, hop_size=16, upsample_scales=[4, 4], num_mels=16)
     p = W.synthetic_params(hp, 9, actnorm="random")
-    inp = W.synthetic_inputs(hp, 2, 256)
-    x, c = torch.from_numpy(inp["x"]).reshape(2, 256), torch.from_numpy(inp["c"])
+    inp = W.synthetic_inputs(hp, 2, t)
+    x, c = torch.from_numpy(inp["x"]).reshape(2, t), torch.from_numpy(inp["c"])
     pd = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for k, v in p.items()}
     eng = GradEngine(hp)
     for step in range(2):
         l_d, _, _, g_d = eng.loss_and_grads(pd, x, c)
-        assert eng._tp.plan is not None
+        assert eng._tp.plan is not None and len(eng._tp.plan.tail_jobs) == hp.n_block * hp.n_flow
+        assert all(d.Wts for d in eng._tp.pm.flow_descs)
         l_n, _, _, g_n = GradEngine(hp).loss_and_grads({k: v.cpu().numpy() for k, v in pd.items()}, x, c)
         assert float(l_d) == float(l_n)
         for k in g_n:

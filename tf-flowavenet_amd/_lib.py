@@ -175,6 +175,7 @@ SIGNATURES = {
     "fwn_cond_split": (C.c_int, [vp, vp, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, i64,
                                  C.c_int, vp]),
     "fwn_cond_reduce": (C.c_int, [vp, vp, i64, C.c_int, i64, vp]),
+    "fwn_pack_tail_stream_jobs": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "fwn_cond_stream_bytes": (i64, [C.c_int]),
     "fwn_cond_stream_rows": (C.c_int, []),
     "fwn_cond_stream_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),

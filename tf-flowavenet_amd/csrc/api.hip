@@ -329,6 +329,13 @@ int fwn_pack_tail_stream(const void* Wskip, const void* Wfinal, int L, void* out
     return check_launch("fwn_pack_tail_stream");
 }
 
+int fwn_pack_tail_stream_jobs(const fwn_tail_stream_job* jobs, int njobs, int L, void* stream) {
+    REQUIRE(jobs && njobs > 0 && njobs < 65536, "fwn_pack_tail_stream_jobs: bad argument");
+    REQUIRE(fwn_tail_stream_size(L) != 0, "fwn_pack_tail_stream_jobs: no register-streamed tail kernel for L = %d", L);
+    fwn_launch_tail_stream_pack_jobs(jobs, njobs, (hipStream_t)stream);
+    return check_launch("fwn_pack_tail_stream_jobs");
+}
+
 int fwn_tail(const fwn_flow_desc* d, const void* o, float* xa, float* xb, float* partial, int M,
              int inverse, void* scratch, void* stream) {
     int rc = check_desc(d);

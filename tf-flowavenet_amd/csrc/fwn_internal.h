@@ -83,6 +83,7 @@ long fwn_tail_stream_size(int L);          // bytes, 0: no kernel for this layer
 int fwn_tail_stream_min_rows();
 int fwn_tail_rs_mt(int M, int L, int Ch, int npt, bool have_stream);
 void fwn_launch_tail_stream_pack(const void* Ws, const void* Wf, void* out, hipStream_t st);
+void fwn_launch_tail_stream_pack_jobs(const void* jobs, int njobs, hipStream_t st);     // jobs: device array of {Wskip, Wfinal, out}
 void fwn_launch_tail_rs(const TailArgs& a, const void* Wts, int mt, hipStream_t st);
 
 // one flow of the small-M chain as one launch (flow_persist.h)

@@ -620,7 +620,15 @@ __global__ __launch_bounds__(512, (MT <= 2 ? 4 : 2)) void tail_rs_kernel(TailArg
 // Wskip [256][512] | Wfinal [256][256] (rows in accumulator order: packing.acc_k_perm) -> fragment stream
 // out[wave][g][lane][8]: lane l holds channel 32 wave + (l & 31), k 16 g' + 8 (l >> 5) .. + 7 of k-step g (g < 32: Wskip
 // column 16 g; else Wfinal column 16 (g - 32)).
-__global__ void tail_stream_pack_kernel(const bf16* __restrict__ Ws, const bf16* __restrict__ Wf, bf16* __restrict__ out) {
+// jobs != NULL: the streams of gridDim.y flows in one launch (a training step re-packs every flow's stream from the freshly
+// packed Wskip | Wfinal: packing.PackPlan) - job blockIdx.y = {Wskip, Wfinal, out} device pointers
+struct TailStreamJob { const bf16* Ws; const bf16* Wf; bf16* out; };
+__global__ void tail_stream_pack_kernel(const bf16* __restrict__ Ws, const bf16* __restrict__ Wf, bf16* __restrict__ out,
+                                        const TailStreamJob* __restrict__ jobs) {
+    if (jobs) {
+        const TailStreamJob j = jobs[blockIdx.y];
+        Ws = j.Ws; Wf = j.Wf; out = j.out;
+    }
     const long total = 8L * 48 * 64;                   // 16-byte pieces
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);

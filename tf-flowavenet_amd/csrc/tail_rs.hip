@@ -39,7 +39,11 @@ int fwn_tail_rs_mt(int M, int L, int Ch, int npt, bool have_stream) {
 }
 
 void fwn_launch_tail_stream_pack(const void* Ws, const void* Wf, void* out, hipStream_t st) {
-    hipLaunchKernelGGL(tail_stream_pack_kernel, dim3(96), dim3(256), 0, st, (const bf16*)Ws, (const bf16*)Wf, (bf16*)out);
+    hipLaunchKernelGGL(tail_stream_pack_kernel, dim3(96), dim3(256), 0, st, (const bf16*)Ws, (const bf16*)Wf, (bf16*)out, (const TailStreamJob*)nullptr);
+}
+void fwn_launch_tail_stream_pack_jobs(const void* jobs, int njobs, hipStream_t st) {
+    hipLaunchKernelGGL(tail_stream_pack_kernel, dim3(24, njobs), dim3(256), 0, st, (const bf16*)nullptr, (const bf16*)nullptr, (bf16*)nullptr,
+                       (const TailStreamJob*)jobs);
 }
 
 void fwn_launch_tail_rs(const TailArgs& a, const void* Wts, int mt, hipStream_t st) {

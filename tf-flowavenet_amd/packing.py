@@ -203,6 +203,7 @@ class PackPlan:
         self._dev_ready = False
         self.hostview = None
         self._built = False
+        self.tail_jobs, self._tail_L = [], 0       # (Wskip, Wfinal, out) of the flows whose tail stream follows the weights
 
     def add(self, v, g, src_k, src_n, k_dst, n_dst, out_ptr, ld_dst, mul=1.0, transposed=False):
         slot = -1
@@ -215,6 +216,13 @@ class PackPlan:
         self.jobs.append((v.data_ptr(), src_k.data_ptr(), src_n.data_ptr(), int(out_ptr), int(ld_dst), int(v.shape[2]),
                           int(k_dst), int(n_dst), slot, int(bool(transposed)), float(mul)))
         self.keep += [v, g, src_k, src_n]
+        self._built = False
+
+    def add_tail_stream(self, wskip_ptr, wfinal_ptr, out_ptr, L):
+        """The fragment-order copy of a flow's Wskip | Wfinal (csrc/tail_rs.h) is derived from two packed matrices: it is
+        re-packed behind the grouped weight packing of every refresh (``fwn_pack_tail_stream_jobs``: one launch for all)."""
+        self.tail_jobs.append((int(wskip_ptr), int(wfinal_ptr), int(out_ptr)))
+        self._tail_L = int(L)
         self._built = False
 
     def table(self, setter, fn, recipe=None):
@@ -291,6 +299,9 @@ class PackPlan:
         self._sj = torch.frombuffer(bytearray(bytes(sj)), dtype=torch.uint8).to(self.dev)
         self._pj = torch.frombuffer(bytearray(bytes(pj)), dtype=torch.uint8).to(self.dev)
         self._scales = torch.empty(max(1, len(self.sjobs)), 512, dtype=torch.float32, device=self.dev)
+        if self.tail_jobs:
+            tj = np.asarray(self.tail_jobs, dtype=np.uint64).reshape(-1)
+            self._tj = torch.from_numpy(tj.view(np.int64).copy()).to(self.dev)
         self._built = True
 
     def run_kernels(self):
@@ -300,6 +311,8 @@ class PackPlan:
         st = torch.cuda.current_stream(self.dev).cuda_stream
         _lib.check(_lib.load().fwn_pack_jobs(self._sj.data_ptr(), len(self.sjobs), self._pj.data_ptr(), len(self.jobs),
                                              self._scales.data_ptr(), 512, st), "fwn_pack_jobs")
+        if self.tail_jobs:
+            _lib.check(_lib.load().fwn_pack_tail_stream_jobs(self._tj.data_ptr(), len(self.tail_jobs), self._tail_L, st), "fwn_pack_tail_stream_jobs")
 
     def upload_tables(self):
         import torch
@@ -608,12 +621,15 @@ def pack_model(params, hp, device="cuda", cond_mode: int = 0, plan: "PackPlan | 
             pack(wp + "/Conv_final", ident256, accperm, FILTER, FILTER, wfin, FILTER)
             d.Wfinal = wfin.data_ptr()
             # Wskip | Wfinal once more in MFMA-fragment order for the register-streamed tail (csrc/tail_rs.h): one ZeroConv pair
-            # tile only, and - like the gate's stream - only without a PackPlan (a plan re-packs the weights every step)
-            ts_bytes = int(lib.fwn_tail_stream_bytes(L)) if (plan is None and npt == 1 and tail_stream) else 0
+            # tile only.  Under a PackPlan (training: the weights are re-packed every step) the streams are re-packed too, all in one launch
+            ts_bytes = int(lib.fwn_tail_stream_bytes(L)) if (npt == 1 and tail_stream) else 0
             if ts_bytes:
                 wts = pm.keep(torch.empty(ts_bytes, dtype=torch.uint8, device=dev))
                 pm.weight_bytes += ts_bytes
-                _lib.check(lib.fwn_pack_tail_stream(wskip.data_ptr(), wfin.data_ptr(), L, wts.data_ptr(), stream), "fwn_pack_tail_stream")
+                if plan is None:
+                    _lib.check(lib.fwn_pack_tail_stream(wskip.data_ptr(), wfin.data_ptr(), L, wts.data_ptr(), stream), "fwn_pack_tail_stream")
+                else:       # re-packed behind every grouped weight packing, all flows in one launch (PackPlan.run_kernels)
+                    plan.add_tail_stream(wskip.data_ptr(), wfin.data_ptr(), wts.data_ptr(), L)
                 d.Wts = wts.data_ptr()
             put(lambda v, d=d: setattr(d, "bfinal", v.data_ptr()), lambda wp=wp: np.asarray(hostp[wp + "/Conv_final/bias"]).reshape(-1)[accperm_host],
                 dict(terms=[(wp + "/Conv_final/bias", accperm_host)]))
