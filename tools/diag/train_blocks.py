@@ -12,7 +12,7 @@ step = rows[starts[-2]:starts[-1]]
 t0 = step[0]["s"]
 ms = lambda t: (t - t0) / 1e6
 # forward: flows close with the kernel holding the coupling
-closes = [i for i, r in enumerate(step) if r["n"].startswith("tail_kernel") or "TailZeroProb" in r["n"]]
+closes = [i for i, r in enumerate(step) if r["n"].startswith(("tail_kernel", "tail_rs_kernel")) or "TailZeroProb" in r["n"]]
 bwd0 = next(i for i, r in enumerate(step) if r["n"].startswith("coupling_bwd_kernel"))
 closes = [i for i in closes if i < bwd0]
 nflow = len(closes)
